@@ -1,0 +1,109 @@
+"""Hot-path parameters of the 2D->3D pipeline.
+
+The reference reads ~10 module-level constants out of ``settings.yaml`` through
+``utils.py`` (reference utils.py:834-859, 900; defaults settings.yaml:315-323, 350).
+This module keeps exactly those, as plain dataclasses, and the Depth-Anything-v2
+architecture table (HF ``config.json`` of depth-anything/Depth-Anything-V2-*-hf;
+dims restated in SURVEY.md section 8).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, asdict
+from typing import Tuple
+
+PATCH = 14                       # DINOv2 patch size (reference depth.py:531-538)
+POS_GRID = 37                    # 518 / 14: pre-trained position-embedding grid
+IMAGENET_MEAN = (0.485, 0.456, 0.406)   # reference depth.py:1798
+IMAGENET_STD = (0.229, 0.224, 0.225)    # reference depth.py:1799
+
+DISPLAY_MODES = ("Half-SBS", "Full-SBS", "Half-TAB", "Full-TAB")  # depth.py:2178-2183
+
+
+@dataclass(frozen=True)
+class ModelConfig:
+    """Depth-Anything-v2 (DINOv2 backbone + DPT neck/head) dimensions."""
+    name: str
+    hidden: int
+    heads: int
+    layers: int
+    out_indices: Tuple[int, int, int, int]
+    neck: Tuple[int, int, int, int]
+    fusion: int
+    head_hidden: int = 32
+    mlp_ratio: int = 4
+    ln_eps: float = 1e-6
+    patch: int = PATCH
+    pos_grid: int = POS_GRID
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    @property
+    def mlp(self) -> int:
+        return self.hidden * self.mlp_ratio
+
+
+MODELS = {
+    # KAT-tiny: known-answer-test size, same structure (SURVEY.md section 8c fixtures (i))
+    "tiny": ModelConfig("tiny", 64, 2, 4, (1, 2, 3, 4), (8, 16, 32, 64), 16),
+    "vits": ModelConfig("vits", 384, 6, 12, (3, 6, 9, 12), (48, 96, 192, 384), 64),
+    "vitb": ModelConfig("vitb", 768, 12, 12, (3, 6, 9, 12), (96, 192, 384, 768), 128),
+    "vitl": ModelConfig("vitl", 1024, 16, 24, (5, 12, 18, 24), (256, 512, 1024, 1024), 256),
+}
+
+# reference utils.py:734-736 model ids -> architecture
+MODEL_IDS = {
+    "depth-anything/Depth-Anything-V2-Small-hf": "vits",
+    "depth-anything/Depth-Anything-V2-Base-hf": "vitb",
+    "depth-anything/Depth-Anything-V2-Large-hf": "vitl",
+}
+
+
+@dataclass
+class PipelineParams:
+    """Constants the hot path reads (reference utils.py:837-859, 900)."""
+    depth_resolution: int = 518        # settings "Depth Resolution" (default 336; BASELINE uses 518)
+    foreground_scale: float = 0.05     # yaml 0.5 / 10            utils.py:858
+    aa_strength: float = 4.0           # yaml 2 * 2               utils.py:859
+    gamma: float = 1.45                # depth.py:775
+    percentile: float = 2.0            # depth.py:816
+    subsample_cap: int = 6144          # depth.py:816
+    ema_alpha: float = 0.9             # depth.py:1889
+    ipd: float = 0.064                 # utils.py:851
+    depth_strength: float = 4.0        # settings "Depth Strength" utils.py:850
+    convergence: float = 0.0           # utils.py:852
+    display_mode: str = "Half-SBS"     # utils.py:840
+    fill_16_9: bool = True             # utils.py:900
+    mean: Tuple[float, float, float] = IMAGENET_MEAN
+    std: Tuple[float, float, float] = IMAGENET_STD
+
+    def asdict(self):
+        return asdict(self)
+
+
+def nearest_multiple(x: int, p: int) -> int:
+    """Ties go UP (reference depth.py:683-686)."""
+    down = (x // p) * p
+    up = down + p
+    return up if abs(up - x) <= abs(x - down) else down
+
+
+def engine_shape(h: int, w: int, target: int, patch: int = PATCH):
+    """Model-input size and the CPU-branch decimation stride for an h x w frame.
+
+    Restates the integer logic of ``_resize_patch_aligned_t`` (reference
+    depth.py:676-706): longest side -> target, each dim to the nearest patch
+    multiple (ties up); CPU branch pre-decimates by ``longest // (2*target)``.
+    Returns (new_h, new_w, stride) with stride >= 1.
+    """
+    longest = max(h, w)
+    scale = target / float(longest) if longest != target else 1.0
+    sh = max(1, int(round(h * scale)))
+    sw = max(1, int(round(w * scale)))
+    new_h = max(1, nearest_multiple(sh, patch))
+    new_w = max(1, nearest_multiple(sw, patch))
+    stride = longest // (target * 2)
+    if stride < 1:
+        stride = 1
+    return new_h, new_w, stride

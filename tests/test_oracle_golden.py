@@ -1,0 +1,117 @@
+"""CPU: the numpy oracle (oracle/d2s_oracle.py) against the golden vectors captured from the
+reference itself (tests/golden/make_golden.py).  This is what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from desktop2stereo_amd import synth
+from desktop2stereo_amd.config import MODELS
+from desktop2stereo_amd.weights import make_weights
+from oracle import d2s_oracle as O
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    with open(os.path.join(golden_dir, name + ".json")) as f:
+        meta = json.load(f)
+    return z, meta
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = MODELS["tiny"]
+    return cfg, make_weights(cfg, 0)
+
+
+def test_engine_shape_table():
+    # reference depth.py:676-706 integer logic; 16:9 frames all land on 294x518 at T=518
+    assert O.engine_shape(1080, 1920, 518) == (294, 518, 1)
+    assert O.engine_shape(2160, 3840, 518) == (294, 518, 3)
+    assert O.engine_shape(1440, 2560, 518) == (294, 518, 2)
+    assert O.engine_shape(720, 1280, 518) == (294, 518, 1)
+    assert O.engine_shape(1080, 1920, 336) == (196, 336, 2)
+    assert O.engine_shape(90, 160, 84) == (42, 84, 1)
+
+
+def test_tiny_all_taps(golden_dir, tiny):
+    cfg, w = tiny
+    z, meta = _load(golden_dir, "tiny_r84")
+    orc = O.PipelineOracle(cfg, w, 84)
+    for fi in range(len(meta["frames"])):
+        p = f"f{fi}_"
+        img = z[p + "img"]
+        fr = meta["frames"][fi]
+        gen = synth.structured_frame if fr["kind"] == "S2" else synth.noise_frame
+        assert np.array_equal(img, gen(fr["h"], fr["w"], fr["seed"]))      # generators are stable
+        x = orc.model_input(img)
+        np.testing.assert_allclose(x, z[p + "model_input"], atol=2e-5)
+        taps = {}
+        raw = orc.model.forward(z[p + "model_input"], taps)
+        np.testing.assert_allclose(taps["embeddings"], z[p + "embeddings"], atol=2e-5)
+        for li in range(1, cfg.layers + 1):
+            np.testing.assert_allclose(taps[f"layer{li}"], z[p + f"layer{li}"], atol=5e-5)
+        scale = float(z[p + "raw_depth"].max())
+        assert np.abs(raw - z[p + "raw_depth"]).max() <= 2e-5 * scale
+        rawg = z[p + "raw_depth"]
+        nrm = O.normalize_depth(rawg)
+        np.testing.assert_allclose(nrm, z[p + "norm"], atol=1e-6)
+        gam = O.apply_gamma(z[p + "norm"])
+        np.testing.assert_allclose(gam, z[p + "gamma"], atol=1e-6)
+        fg = O.apply_foreground_scale(z[p + "gamma"], 0.05)
+        np.testing.assert_allclose(fg, z[p + "fg"], atol=1e-6)
+        post = O.anti_alias(z[p + "fg"], 4.0)
+        np.testing.assert_allclose(post, z[p + "post_depth"], atol=1e-6)
+        np.testing.assert_allclose(O.post_process_depth(rawg), z[p + "post_depth"], atol=2e-6)
+
+
+def test_tiny_ema_chain(golden_dir, tiny):
+    """predict_depth with use_temporal_smooth=True over 3 frames (reference depth.py:1865-1887)."""
+    cfg, w = tiny
+    z, meta = _load(golden_dir, "tiny_r84")
+    orc = O.PipelineOracle(cfg, w, 84)
+    for fi in range(len(meta["frames"])):
+        d = orc.predict_depth(z[f"f{fi}_img"], use_temporal_smooth=True)
+        np.testing.assert_allclose(orc.stab.prev, z[f"f{fi}_ema_state"], atol=2e-5)
+        np.testing.assert_allclose(d, z[f"f{fi}_depth_ema_full"], atol=2e-5)
+
+
+@pytest.mark.parametrize("name,model,res", [("tiny_r518", "tiny", 518)])
+def test_full_size_model(golden_dir, name, model, res):
+    cfg = MODELS[model]
+    z, meta = _load(golden_dir, name)
+    fr = meta["frames"][0]
+    orc = O.PipelineOracle(cfg, make_weights(cfg, 0), res)
+    taps = {}
+    orc.predict_depth(synth.structured_frame(fr["h"], fr["w"], fr["seed"]), taps=taps)
+    scale = float(z["f0_raw_depth"].max())
+    assert np.abs(taps["raw_depth"] - z["f0_raw_depth"]).max() <= 2e-5 * scale
+    assert np.abs(taps["post_depth"] - z["f0_post_depth"]).max() <= 1e-4
+
+
+def test_warp_all_cases(golden_dir):
+    """make_sbs with a given depth: all display modes x fill_16_9 x convergence, several aspect
+    ratios (pads), 1080p rows.  Values within the reference's own float32 coordinate noise, and
+    within 1 LSB after uint8 rounding (SURVEY.md section 8d parity gate)."""
+    z, meta = _load(golden_dir, "warp")
+    cache = {}
+    for c in meta["cases"]:
+        k = (c["shape"], c["kind"])
+        if k not in cache:
+            gen = synth.structured_frame if c["kind"] == "S2" else synth.noise_frame
+            cache[k] = (gen(c["h"], c["w"], c["seed"]), synth.smooth_depth(c["h"], c["w"], c["seed"]))
+        img, dep = cache[k]
+        if c["shape"] != "hd":
+            assert np.array_equal(img, z[f"{c['shape']}_{c['kind']}_img"])
+            assert np.array_equal(dep, z[f"{c['shape']}_{c['kind']}_depth"])
+        rgb = img.transpose(2, 0, 1).astype(np.float32)
+        out = O.make_sbs_core(rgb, dep, ipd_uv=c["ipd_uv"], depth_ratio=c["depth_ratio"],
+                              display_mode=c["mode"], fill_16_9=c["fill_16_9"],
+                              convergence=c["convergence"]).transpose(1, 2, 0)
+        assert list(out.shape) == c["out_shape"], c
+        ref = z[c["key"]].astype(np.float32) / 256.0
+        got = out[::c["row_stride"]]
+        tol = 0.08 if c["kind"] == "S1" else 0.03
+        assert np.abs(got - ref).max() <= tol, (c["key"], np.abs(got - ref).max())
+        assert np.abs(O.to_u8(got).astype(int) - O.to_u8(ref).astype(int)).max() <= 1
