@@ -1,0 +1,91 @@
+"""ctypes binding of libd2s_hip.so (include/d2s.h).
+
+The library is the product path: if it is missing or a symbol is absent this module raises --
+there is no CPU or PyTorch fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libd2s_hip.so")
+
+OK = 0
+MODE = {"Half-SBS": 0, "Full-SBS": 1, "Half-TAB": 2, "Full-TAB": 3}
+FMT_U8_HWC, FMT_F32_CHW, FMT_F32_HWC, FMT_U8_CHW = 0, 1, 2, 3
+PREC_FP32, PREC_BF16 = 0, 1
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("hidden", C.c_int32), ("heads", C.c_int32), ("layers", C.c_int32),
+                ("out_indices", C.c_int32 * 4), ("neck", C.c_int32 * 4), ("fusion", C.c_int32),
+                ("head_hidden", C.c_int32), ("mlp", C.c_int32), ("patch", C.c_int32),
+                ("pos_grid", C.c_int32), ("ln_eps", C.c_float), ("precision", C.c_int32)]
+
+
+class PostParams(C.Structure):
+    _fields_ = [("percentile", C.c_float), ("subsample_cap", C.c_int32), ("gamma", C.c_float),
+                ("foreground_scale", C.c_float), ("aa_strength", C.c_float), ("ema_alpha", C.c_float)]
+
+
+class SbsParams(C.Structure):
+    _fields_ = [("ipd_uv", C.c_double), ("depth_ratio", C.c_float), ("convergence", C.c_float),
+                ("display_mode", C.c_int32), ("fill_16_9", C.c_int32)]
+
+
+# every symbol include/d2s.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "d2s_last_error": (C.c_char_p, []),
+    "d2s_version": (C.c_int, []),
+    "d2s_engine_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_P)]),
+    "d2s_engine_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),
+    "d2s_engine_finalize": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "d2s_engine_destroy": (C.c_int, [_P]),
+    "d2s_engine_memory": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "d2s_preprocess": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
+    "d2s_model_forward": (C.c_int, [_P, _P, _P, C.c_int, _P]),
+    "d2s_post_process": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(PostParams), _P, C.c_uint64, _P]),
+    "d2s_post_process_workspace": (C.c_uint64, [C.c_int, C.c_int, C.c_int]),
+    "d2s_ema_update": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
+    "d2s_upsample_depth": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
+    "d2s_make_sbs": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.POINTER(SbsParams), _P, C.c_int, _P]),
+    "d2s_sbs_shape": (C.c_int, [C.c_int, C.c_int, C.POINTER(SbsParams), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "d2s_pipeline": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(PostParams),
+                               C.POINTER(SbsParams), C.c_int, _P, C.c_int, _P, _P]),
+    "d2s_engine_reset_stream": (C.c_int, [_P]),
+    "d2s_engine_tap": (C.c_int, [_P, C.c_char_p, _P, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
+    "d2s_gemm_probe": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+}
+
+_lib = None
+
+
+class D2SError(RuntimeError):
+    pass
+
+
+def load(path: str = LIB_PATH):
+    """Load the library and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise D2SError(f"{path} not found: build it with `python -m desktop2stereo_amd.build` "
+                       "(there is no fallback path)")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    if status != OK:
+        msg = load().d2s_last_error()
+        raise D2SError(f"{what or 'libd2s_hip'} failed (status {status}): {msg.decode() if msg else ''}")

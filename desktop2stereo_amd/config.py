@@ -46,7 +46,7 @@ class ModelConfig:
 
 MODELS = {
     # KAT-tiny: known-answer-test size, same structure (SURVEY.md section 8c fixtures (i))
-    "tiny": ModelConfig("tiny", 64, 2, 4, (1, 2, 3, 4), (8, 16, 32, 64), 16),
+    "tiny": ModelConfig("tiny", 128, 2, 4, (1, 2, 3, 4), (16, 32, 64, 128), 32),
     "vits": ModelConfig("vits", 384, 6, 12, (3, 6, 9, 12), (48, 96, 192, 384), 64),
     "vitb": ModelConfig("vitb", 768, 12, 12, (3, 6, 9, 12), (96, 192, 384, 768), 128),
     "vitl": ModelConfig("vitl", 1024, 16, 24, (5, 12, 18, 24), (256, 512, 1024, 1024), 256),

@@ -1,0 +1,250 @@
+// Fused multi-head self-attention (non-causal, head_dim 64) on MFMA, flash-style online softmax.
+// (HF Dinov2SelfAttention.forward: softmax(q k^T * hd^-0.5) v; reference call site depth.py:1778)
+//
+// Inputs:  qkv  [B*N, 3D] T   (q | k | v), written by the QKV GEMM;
+//          vt   [B, heads, 64, Npad] T  = V transposed (written by the same GEMM's epilogue), zero beyond N.
+// Output:  out  [B*N, D] T.
+//
+// One block = 4 waves, one (batch, head, q-tile); each wave owns QF fragments of 16 query rows.
+// Per 64-key tile:
+//   S^T[key, q] = mfma(K rows, Q rows)         lane: 4 keys x 1 query  -> softmax stats are per lane column
+//   P^T feeds the second MFMA straight from the S registers (no LDS round trip): the K rows of a
+//   fragment are loaded in a permuted order so that a lane group's values are 8 (bf16) / 4 (f32)
+//   CONSECUTIVE keys, i.e. exactly one 16-byte chunk of a V^T row;
+//   O^T[d, q] += mfma(V^T rows, P^T)           lane: 4 consecutive d for 1 query -> vector stores.
+// K / V^T tiles: global -> registers -> XOR-swizzled LDS, double buffered, one barrier per tile.
+// Softmax in fp32 (exp2 with the scale folded in).
+#include "vit_ops.h"
+
+namespace d2s {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename T> struct AT;
+template <> struct AT<bf16_t> {
+    static constexpr int CE = 8, CPR = 8, NKS = 2;
+    __device__ static int swzK(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
+    __device__ static int swzV(int r) { return (r >> 1) & 7; }
+    // tile key held by MFMA A-row i of S fragment j
+    __device__ static int key_of(int j, int i) { return (j >> 1) * 32 + (i >> 2) * 8 + (i & 3) + 4 * (j & 1); }
+};
+template <> struct AT<float> {
+    static constexpr int CE = 4, CPR = 16, NKS = 4;
+    __device__ static int swzK(int r) { return r & 15; }
+    __device__ static int swzV(int r) { return r & 15; }
+    __device__ static int key_of(int j, int i) { return j * 16 + i; }
+};
+
+__device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b, bf16_t) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b, float) {
+    const float* af = (const float*)&a;
+    const float* bf = (const float*)&b;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bf[t], acc, 0, 0, 0);
+}
+
+// pack the P values a lane group contributes to one V^T chunk
+__device__ __forceinline__ uint4 pack_p(const f32x4& lo, const f32x4& hi, bf16_t) {
+    uint4 r;
+    r.x = (uint32_t)f2bf(lo[0]) | ((uint32_t)f2bf(lo[1]) << 16);
+    r.y = (uint32_t)f2bf(lo[2]) | ((uint32_t)f2bf(lo[3]) << 16);
+    r.z = (uint32_t)f2bf(hi[0]) | ((uint32_t)f2bf(hi[1]) << 16);
+    r.w = (uint32_t)f2bf(hi[2]) | ((uint32_t)f2bf(hi[3]) << 16);
+    return r;
+}
+__device__ __forceinline__ uint4 pack_p(const f32x4& lo, const f32x4&, float) {
+    uint4 r;
+    r.x = __float_as_uint(lo[0]); r.y = __float_as_uint(lo[1]); r.z = __float_as_uint(lo[2]); r.w = __float_as_uint(lo[3]);
+    return r;
+}
+
+__device__ __forceinline__ void store_o4(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void store_o4(bf16_t* p, const float v[4]) {
+    uint2 t;
+    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *(uint2*)p = t;
+}
+
+template <typename T, int QF>
+__global__ void __launch_bounds__(256)
+attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restrict__ out,
+                 int N, int Npad, int heads, float scale_log2e) {
+    using A = AT<T>;
+    constexpr int CE = A::CE, CPR = A::CPR, NKS = A::NKS;
+    constexpr int TILE_CHUNKS = 64 * CPR;              // chunks in one 64-row tile
+    constexpr int LPT = TILE_CHUNKS / 256;             // chunk loads per thread per tile (2 / 4)
+    constexpr int BQ = 4 * QF * 16;
+    __shared__ __attribute__((aligned(16))) uint4 lds[2][2 * TILE_CHUNKS];   // [buf][K | V^T]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int D = heads * 64;
+    const long row3 = 3L * D;
+    const T* qbase = qkv + (long)b * N * row3 + h * 64;
+    const T* kbase = qbase + D;
+    const T* vbase = vt + ((long)b * heads + h) * 64 * Npad;
+
+    // ---- Q fragments (B operand of S^T): Q[q][chunk ks*4+fg]
+    uint4 qf[QF][NKS];
+    int qrow[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        qrow[f] = qt * BQ + (wid * QF + f) * 16 + fr;
+        bool ok = qrow[f] < N;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            qf[f][ks] = ok ? *(const uint4*)(qbase + (long)qrow[f] * row3 + (ks * 4 + fg) * CE) : make_uint4(0, 0, 0, 0);
+    }
+
+    f32x4 o[QF][4];
+    float m_run[QF], l_run[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        m_run[f] = -1e30f; l_run[f] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[f][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    uint4 rk[LPT], rv[LPT];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            int idx = tid + 256 * i;
+            int r = idx / CPR, c = idx % CPR;
+            int key = t * 64 + r;
+            rk[i] = key < N ? *(const uint4*)(kbase + (long)key * row3 + c * CE) : make_uint4(0, 0, 0, 0);
+            rv[i] = *(const uint4*)(vbase + (long)r * Npad + t * 64 + c * CE);     // r = d row, zero padded in memory
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            int idx = tid + 256 * i;
+            int r = idx / CPR, c = idx % CPR;
+            lds[buf][r * CPR + (c ^ A::swzK(r))] = rk[i];
+            lds[buf][TILE_CHUNKS + r * CPR + (c ^ A::swzV(r))] = rv[i];
+        }
+    };
+
+    const int ntiles = (N + 63) / 64;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) load_tile(t + 1);
+        const uint4* Kl = lds[t & 1];
+        const uint4* Vl = lds[t & 1] + TILE_CHUNKS;
+        // ---- S^T = K Q^T
+        f32x4 s[QF][4];
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int kr = A::key_of(j, fr);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                uint4 kf = Kl[kr * CPR + ((ks * 4 + fg) ^ A::swzK(kr))];
+#pragma unroll
+                for (int f = 0; f < QF; ++f) mma16(s[f][j], kf, qf[f][ks], T());
+            }
+        }
+        // ---- mask the ragged last tile: key of register r in fragment j = key_of(j, fg*4 + r)
+        if (t == ntiles - 1 && (N & 63)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (t * 64 + A::key_of(j, fg * 4 + r) >= N) {
+#pragma unroll
+                        for (int f = 0; f < QF; ++f) s[f][j][r] = -1e30f;
+                    }
+        }
+        // ---- online softmax (per query column = per lane & 15)
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][j][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float m_new = fmaxf(m_run[f], mx);
+            float alpha = exp2f((m_run[f] - m_new) * scale_log2e);
+            m_run[f] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { float p = exp2f((s[f][j][r] - m_new) * scale_log2e); s[f][j][r] = p; ps += p; }
+            l_run[f] = l_run[f] * alpha + ps;          // per-lane partial; groups are summed at the end
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { o[f][d][0] *= alpha; o[f][d][1] *= alpha; o[f][d][2] *= alpha; o[f][d][3] *= alpha; }
+        }
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int pc = 0; pc < NKS; ++pc) {
+            uint4 pf[QF];
+#pragma unroll
+            for (int f = 0; f < QF; ++f)
+            {
+                if constexpr (NKS == 2) pf[f] = pack_p(s[f][2 * pc], s[f][2 * pc + 1], T());
+                else pf[f] = pack_p(s[f][pc], s[f][pc], T());
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                int vr = d * 16 + fr;
+                uint4 vf = Vl[vr * CPR + ((pc * 4 + fg) ^ A::swzV(vr))];
+#pragma unroll
+                for (int f = 0; f < QF; ++f) mma16(o[f][d], vf, pf[f], T());
+            }
+        }
+        if (t + 1 < ntiles) store_tile((t + 1) & 1);
+        __syncthreads();
+    }
+    // ---- normalise and store: lane holds d = dfrag*16 + fg*4 + r for query fr
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        float l = l_run[f];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        float inv = 1.0f / l;
+        if (qrow[f] < N) {
+            T* orow = out + ((long)b * N + qrow[f]) * D + h * 64;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                float v[4] = {o[f][d][0] * inv, o[f][d][1] * inv, o[f][d][2] * inv, o[f][d][3] * inv};
+                store_o4(orow + d * 16 + fg * 4, v);
+            }
+        }
+    }
+}
+
+int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B, int N, int Npad, int heads, hipStream_t st) {
+    const float scale_log2e = 0.125f * 1.4426950408889634f;          // 64^-0.5 * log2(e)
+    // 64-row q tiles (QF=1) when the grid would otherwise leave CUs idle
+    long blocks128 = (long)cdiv(N, 128) * heads * B;
+    if (prec == D2S_PREC_BF16) {
+        if (blocks128 >= 512) {
+            dim3 grid(cdiv(N, 128), heads, B);
+            hipLaunchKernelGGL((attention_kernel<bf16_t, 2>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, N, Npad, heads, scale_log2e);
+        } else {
+            dim3 grid(cdiv(N, 64), heads, B);
+            hipLaunchKernelGGL((attention_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, N, Npad, heads, scale_log2e);
+        }
+    } else {
+        dim3 grid(cdiv(N, 64), heads, B);
+        hipLaunchKernelGGL((attention_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)qkv, (const float*)vt, (float*)out, N, Npad, heads, scale_log2e);
+    }
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+}  // namespace d2s

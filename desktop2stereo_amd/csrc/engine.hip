@@ -1,0 +1,538 @@
+// Depth-Anything-v2 engine: weights, workspaces, forward orchestration, frame pipeline.
+// Replaces DepthModelWrapper + its engine plug-ins (reference depth.py:1539-1781) and the
+// per-frame glue of predict_depth / make_sbs (reference depth.py:1897-2025, 2186-2231).
+#include <map>
+#include <string>
+#include <vector>
+#include <cmath>
+#include <cstring>
+
+#include "gemm.h"
+#include "vit_ops.h"
+
+using namespace d2s;
+
+namespace {
+
+struct HostT { std::vector<float> data; std::vector<int64_t> shape; };
+
+struct PackedW {           // device: W [Npad][Kpad] T, bias [N] f32 (or null)
+    void* w = nullptr;
+    float* bias = nullptr;
+    int N = 0, K = 0, Kpad = 0;
+};
+
+struct Layer {
+    float *ln1g, *ln1b, *ln2g, *ln2b, *ls1, *ls2;
+    PackedW qkv, proj, fc1, fc2;
+};
+
+}  // namespace
+
+struct d2s_engine {
+    d2s_model_desc d;
+    int device = 0;
+    int prec = D2S_PREC_BF16;
+    std::map<std::string, HostT> host;
+    bool finalized = false;
+    int h = 0, w = 0, gh = 0, gw = 0, P = 0, N = 0, Npad = 0, maxB = 0;
+    uint64_t bytes = 0;
+    std::vector<void*> allocs;
+
+    // weights
+    PackedW patch;
+    float *cls = nullptr, *pos = nullptr;          // pos: [N, D] interpolated (row 0 = cls position)
+    std::vector<Layer> L;
+    float *lnfg = nullptr, *lnfb = nullptr;
+    struct { PackedW proj, resize, conv; } re[4];
+    struct { PackedW proj, r1c1, r1c2, r2c1, r2c2; } fu[4];
+    PackedW head1, head2;
+    float* w3 = nullptr;
+    float b3 = 0.f;
+
+    // workspaces
+    float* resid = nullptr;                        // [maxB*N, D] fp32 residual stream
+    void *lnbuf = nullptr, *qkv = nullptr, *vt = nullptr, *attn = nullptr, *mlp = nullptr, *patchA = nullptr;
+    void* tapbuf[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* rproj[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* rres[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* feat[4] = {nullptr, nullptr, nullptr, nullptr};
+    int fH[4], fW[4];
+    void* scr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // pipeline buffers
+    float *pre_x = nullptr, *depth_small = nullptr;
+    void* post_ws = nullptr;
+    uint64_t post_ws_bytes = 0;
+    float* ema_state = nullptr;
+    int ema_init = 0;
+    // debug taps (env D2S_TAPS=1): hidden states of frame 0 after embeddings and each layer
+    bool taps = false;
+    float* tap_hidden = nullptr;                   // [(layers+1), N, D]
+    int last_batch = 0;
+};
+
+namespace {
+
+int dev_alloc(d2s_engine* e, void** p, size_t bytes, bool zero = false) {
+    if (bytes == 0) bytes = 16;
+    D2S_HIP(hipMalloc(p, bytes));
+    e->allocs.push_back(*p);
+    e->bytes += bytes;
+    if (zero) D2S_HIP(hipMemset(*p, 0, bytes));
+    return D2S_OK;
+}
+
+const HostT* find(d2s_engine* e, const std::string& name) {
+    auto it = e->host.find(name);
+    if (it == e->host.end()) { set_error("missing weight tensor: " + name); return nullptr; }
+    return &it->second;
+}
+
+int upload_f32(d2s_engine* e, const std::string& name, size_t n, float** out) {
+    const HostT* t = find(e, name);
+    if (!t) return D2S_E_MISSING;
+    if (t->data.size() != n) { set_error("weight " + name + ": wrong element count"); return D2S_E_MISSING; }
+    int rc = dev_alloc(e, (void**)out, n * sizeof(float));
+    if (rc) return rc;
+    D2S_HIP(hipMemcpy(*out, t->data.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return D2S_OK;
+}
+
+// pack a logical [N][K] float matrix (given by accessor) into device [Npad][Kpad] T
+template <typename F>
+int pack_matrix(d2s_engine* e, int N, int K, F at, const float* bias_host, PackedW& out) {
+    int Kp = gemm_kpad(K, e->prec), Np = gemm_npad(N);
+    size_t es = elem_size(e->prec);
+    std::vector<uint8_t> buf((size_t)Np * Kp * es, 0);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            float v = at(n, k);
+            if (e->prec == D2S_PREC_BF16) ((bf16_t*)buf.data())[(size_t)n * Kp + k] = f2bf(v);
+            else ((float*)buf.data())[(size_t)n * Kp + k] = v;
+        }
+    int rc = dev_alloc(e, &out.w, buf.size());
+    if (rc) return rc;
+    D2S_HIP(hipMemcpy(out.w, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    out.N = N; out.K = K; out.Kpad = Kp;
+    out.bias = nullptr;
+    if (bias_host) {
+        rc = dev_alloc(e, (void**)&out.bias, (size_t)N * sizeof(float));
+        if (rc) return rc;
+        D2S_HIP(hipMemcpy(out.bias, bias_host, (size_t)N * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return D2S_OK;
+}
+
+int pack_linear(d2s_engine* e, const std::string& wname, const std::string& bname, int N, int K, PackedW& out) {
+    const HostT* w = find(e, wname);
+    if (!w) return D2S_E_MISSING;
+    if (w->data.size() != (size_t)N * K) { set_error("weight " + wname + ": wrong shape"); return D2S_E_MISSING; }
+    const float* b = nullptr;
+    if (!bname.empty()) { const HostT* bt = find(e, bname); if (!bt || bt->data.size() != (size_t)N) { set_error("bad bias " + bname); return D2S_E_MISSING; } b = bt->data.data(); }
+    const float* p = w->data.data();
+    return pack_matrix(e, N, K, [&](int n, int k) { return p[(size_t)n * K + k]; }, b, out);
+}
+
+// Conv2d 3x3 weight [Co,Ci,3,3] -> [Co][(ky*3+kx)*Ci + ci]
+int pack_conv3(d2s_engine* e, const std::string& wname, const std::string& bname, int Co, int Ci, PackedW& out) {
+    const HostT* w = find(e, wname);
+    if (!w) return D2S_E_MISSING;
+    if (w->data.size() != (size_t)Co * Ci * 9) { set_error("weight " + wname + ": wrong shape"); return D2S_E_MISSING; }
+    const float* b = nullptr;
+    if (!bname.empty()) { const HostT* bt = find(e, bname); if (!bt || bt->data.size() != (size_t)Co) { set_error("bad bias " + bname); return D2S_E_MISSING; } b = bt->data.data(); }
+    const float* p = w->data.data();
+    return pack_matrix(e, Co, 9 * Ci, [&](int n, int k) { int tap = k / Ci, ci = k % Ci; return p[((size_t)n * Ci + ci) * 9 + tap]; }, b, out);
+}
+
+// ConvTranspose2d k==s weight [Ci,Co,k,k] -> rows n = (ky*k+kx)*Co + co, K = Ci; bias expanded
+int pack_convT(d2s_engine* e, const std::string& wname, const std::string& bname, int C, int ks, PackedW& out) {
+    const HostT* w = find(e, wname);
+    const HostT* bt = find(e, bname);
+    if (!w || !bt) return D2S_E_MISSING;
+    if (w->data.size() != (size_t)C * C * ks * ks || bt->data.size() != (size_t)C) { set_error("weight " + wname + ": wrong shape"); return D2S_E_MISSING; }
+    const float* p = w->data.data();
+    int N = ks * ks * C;
+    std::vector<float> bias(N);
+    for (int n = 0; n < N; ++n) bias[n] = bt->data[n % C];
+    return pack_matrix(e, N, C, [&](int n, int k) { int tap = n / C, co = n % C; return p[((size_t)k * C + co) * ks * ks + tap]; }, bias.data(), out);
+}
+
+// ---- bicubic (align_corners=False, A=-0.75) resample of the position table, float32 like torch ----
+void cubic_coeffs(float t, float c[4]) {
+    const float A = -0.75f;
+    auto c1 = [&](float x) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; };
+    auto c2 = [&](float x) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; };
+    c[0] = c2(t + 1.f); c[1] = c1(t); c[2] = c1(1.f - t); c[3] = c2(2.f - t);
+}
+
+void interp_pos(const float* pos, int grid, int D, int gh, int gw, std::vector<float>& out) {
+    out.assign((size_t)(1 + gh * gw) * D, 0.f);
+    std::memcpy(out.data(), pos, D * sizeof(float));
+    if (gh == grid && gw == grid) { std::memcpy(out.data() + D, pos + D, (size_t)grid * grid * D * sizeof(float)); return; }
+    float sy = (float)grid / (float)gh, sx = (float)grid / (float)gw;
+    for (int oy = 0; oy < gh; ++oy) {
+        float fy = sy * ((float)oy + 0.5f) - 0.5f;
+        float iyf = floorf(fy);
+        float cy[4]; cubic_coeffs(fy - iyf, cy);
+        int iy = (int)iyf;
+        for (int ox = 0; ox < gw; ++ox) {
+            float fx = sx * ((float)ox + 0.5f) - 0.5f;
+            float ixf = floorf(fx);
+            float cx[4]; cubic_coeffs(fx - ixf, cx);
+            int ix = (int)ixf;
+            float* o = out.data() + (size_t)(1 + oy * gw + ox) * D;
+            for (int d = 0; d < D; ++d) {
+                float acc = 0.f;
+                for (int a = 0; a < 4; ++a) {
+                    int yy = std::min(std::max(iy - 1 + a, 0), grid - 1);
+                    float row = 0.f;
+                    for (int b = 0; b < 4; ++b) {
+                        int xx = std::min(std::max(ix - 1 + b, 0), grid - 1);
+                        row += pos[(size_t)(1 + yy * grid + xx) * D + d] * cx[b];
+                    }
+                    acc += row * cy[a];
+                }
+                o[d] = acc;
+            }
+        }
+    }
+}
+
+GemmA plainA(const void* p, long lda) { GemmA a = {}; a.ptr = p; a.mode = A_PLAIN; a.lda = lda; return a; }
+GemmA convA(const void* p, int Hi, int Wi, int C, int Ho, int Wo, int stride, int relu) {
+    GemmA a = {}; a.ptr = p; a.mode = A_CONV3; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.relu = relu; return a;
+}
+GemmEpi rowsE(void* out, int out_type, long ldc, const float* bias) {
+    GemmEpi e = {}; e.out = out; e.out_type = out_type; e.ldc = ldc; e.bias = bias; return e;
+}
+
+int gemm(d2s_engine* e, const GemmA& a, const PackedW& w, int M, const GemmEpi& ep, hipStream_t st) {
+    return launch_gemm(e->prec, 0, a, w.w, M, w.N, w.K, w.Kpad, ep, st);
+}
+
+#define RC(x) do { int _rc = (x); if (_rc != D2S_OK) return _rc; } while (0)
+
+// 3x3 conv (pad 1) as implicit GEMM over NHWC
+int conv3(d2s_engine* e, const void* in, int B, int Hi, int Wi, int C, int stride, int relu_in, const PackedW& w,
+          void* out, int act, const void* res1, const void* res2, hipStream_t st) {
+    int Ho = (Hi + 2 - 3) / stride + 1, Wo = (Wi + 2 - 3) / stride + 1;
+    GemmA a = convA(in, Hi, Wi, C, Ho, Wo, stride, relu_in);
+    GemmEpi ep = rowsE(out, OUT_T, w.N, w.bias);
+    ep.act = act; ep.res1 = res1; ep.res2 = res2;
+    return gemm(e, a, w, B * Ho * Wo, ep, st);
+}
+
+int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) {
+    const d2s_model_desc& d = e->d;
+    const int D = d.hidden, N = e->N, P = e->P, M = B * N, Mp = B * P, prec = e->prec;
+    const int F = d.fusion;
+    // ---- embeddings (HF Dinov2Embeddings)
+    RC(launch_patchify(prec, x, e->patchA, B, e->h, e->w, d.patch, e->patch.Kpad, st));
+    {
+        GemmEpi ep = rowsE(e->resid, OUT_F32, D, e->patch.bias);
+        ep.rows_per_img = P; ep.img_rows = N; ep.row_off = 1;
+        ep.res1 = e->pos; ep.res1_mod = P; ep.res1_off = 1;
+        GemmA a = plainA(e->patchA, e->patch.Kpad);
+        RC(launch_gemm(prec, 0, a, e->patch.w, Mp, D, e->patch.Kpad, e->patch.Kpad, ep, st));
+    }
+    RC(launch_cls_rows(e->cls, e->pos, e->resid, B, N, D, st));
+    if (e->taps) D2S_HIP(hipMemcpyAsync(e->tap_hidden, e->resid, (size_t)N * D * 4, hipMemcpyDeviceToDevice, st));
+    // ---- encoder (HF Dinov2Layer x L)
+    int tap_i = 0;
+    for (int l = 0; l < d.layers; ++l) {
+        const Layer& ly = e->L[l];
+        RC(launch_layernorm(prec, e->resid, ly.ln1g, ly.ln1b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st));
+        {
+            GemmEpi ep = rowsE(e->qkv, OUT_T, 3 * D, ly.qkv.bias);
+            ep.map = MAP_QKV; ep.vt = e->vt; ep.ntok = N; ep.npad = e->Npad; ep.qk_cols = 2 * D; ep.heads = d.heads;
+            RC(gemm(e, plainA(e->lnbuf, D), ly.qkv, M, ep, st));
+        }
+        RC(launch_attention(prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st));
+        {
+            GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.proj.bias);
+            ep.scale = ly.ls1; ep.res1 = e->resid;
+            RC(gemm(e, plainA(e->attn, D), ly.proj, M, ep, st));
+        }
+        RC(launch_layernorm(prec, e->resid, ly.ln2g, ly.ln2b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st));
+        {
+            GemmEpi ep = rowsE(e->mlp, OUT_T, d.mlp, ly.fc1.bias);
+            ep.act = ACT_GELU;
+            RC(gemm(e, plainA(e->lnbuf, D), ly.fc1, M, ep, st));
+        }
+        {
+            GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.fc2.bias);
+            ep.scale = ly.ls2; ep.res1 = e->resid;
+            RC(gemm(e, plainA(e->mlp, d.mlp), ly.fc2, M, ep, st));
+        }
+        if (e->taps) D2S_HIP(hipMemcpyAsync(e->tap_hidden + (size_t)(l + 1) * N * D, e->resid, (size_t)N * D * 4, hipMemcpyDeviceToDevice, st));
+        if (tap_i < 4 && l + 1 == d.out_indices[tap_i]) {     // HF Dinov2Backbone: shared final LN, drop cls
+            RC(launch_layernorm(prec, e->resid, e->lnfg, e->lnfb, e->tapbuf[tap_i], Mp, D, d.ln_eps, P, N, 1, st));
+            ++tap_i;
+        }
+    }
+    // ---- neck: reassemble (HF DepthAnythingReassembleStage) + 3x3 to fusion width
+    const int gh = e->gh, gw = e->gw;
+    for (int i = 0; i < 4; ++i) {
+        int c = d.neck[i];
+        RC(gemm(e, plainA(e->tapbuf[i], D), e->re[i].proj, Mp, rowsE(e->rproj[i], OUT_T, c, e->re[i].proj.bias), st));
+        const void* src = e->rproj[i];
+        int Hs = gh, Ws = gw;
+        if (i < 2) {
+            int ks = i == 0 ? 4 : 2;
+            GemmEpi ep = rowsE(e->rres[i], OUT_T, c, e->re[i].resize.bias);
+            ep.map = MAP_SHUFFLE; ep.gh = gh; ep.gw = gw; ep.ks = ks; ep.cout = c;
+            RC(gemm(e, plainA(e->rproj[i], c), e->re[i].resize, Mp, ep, st));
+            src = e->rres[i]; Hs = gh * ks; Ws = gw * ks;
+        } else if (i == 3) {
+            RC(conv3(e, e->rproj[i], B, gh, gw, c, 2, 0, e->re[i].resize, e->rres[i], ACT_NONE, nullptr, nullptr, st));
+            src = e->rres[i]; Hs = (gh - 1) / 2 + 1; Ws = (gw - 1) / 2 + 1;
+        }
+        RC(conv3(e, src, B, Hs, Ws, c, 1, 0, e->re[i].conv, e->feat[i], ACT_NONE, nullptr, nullptr, st));
+    }
+    // ---- fusion, deep -> shallow (HF DepthAnythingFeatureFusionStage)
+    void *X = e->scr[0], *Y = e->scr[1], *Z = e->scr[2];
+    void* fused = nullptr;
+    int Hc = 0, Wc = 0;
+    for (int idx = 0; idx < 4; ++idx) {
+        int mi = 3 - idx;
+        void* m = e->feat[mi];
+        Hc = e->fH[mi]; Wc = e->fW[mi];
+        const void* hcur = m;
+        if (idx > 0) {       // hidden = fused + RCU1(m)
+            RC(conv3(e, m, B, Hc, Wc, F, 1, 1, e->fu[idx].r1c1, X, ACT_NONE, nullptr, nullptr, st));
+            RC(conv3(e, X, B, Hc, Wc, F, 1, 1, e->fu[idx].r1c2, Y, ACT_NONE, m, fused, st));
+            hcur = Y;
+        }
+        RC(conv3(e, hcur, B, Hc, Wc, F, 1, 1, e->fu[idx].r2c1, X, ACT_NONE, nullptr, nullptr, st));
+        RC(conv3(e, X, B, Hc, Wc, F, 1, 1, e->fu[idx].r2c2, Z, ACT_NONE, hcur, nullptr, st));
+        int Ho, Wo;
+        if (idx < 3) { Ho = e->fH[mi - 1]; Wo = e->fW[mi - 1]; } else { Ho = Hc * 2; Wo = Wc * 2; }
+        RC(launch_bilinear_nhwc(prec, Z, X, B, Hc, Wc, Ho, Wo, F, st));
+        void* pout = e->scr[3 + (idx & 1)];
+        RC(gemm(e, plainA(X, F), e->fu[idx].proj, B * Ho * Wo, rowsE(pout, OUT_T, F, e->fu[idx].proj.bias), st));
+        fused = pout; Hc = Ho; Wc = Wo;
+    }
+    // ---- head (HF DepthAnythingDepthEstimationHead)
+    RC(conv3(e, fused, B, Hc, Wc, F, 1, 0, e->head1, X, ACT_NONE, nullptr, nullptr, st));
+    RC(launch_bilinear_nhwc(prec, X, Y, B, Hc, Wc, e->h, e->w, F / 2, st));
+    RC(conv3(e, Y, B, e->h, e->w, F / 2, 1, 0, e->head2, Z, ACT_RELU, nullptr, nullptr, st));
+    RC(launch_head_final(prec, Z, e->w3, e->b3, depth, (long)B * e->h * e->w, d.head_hidden, st));
+    e->last_batch = B;
+    return D2S_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" int d2s_engine_create(const d2s_model_desc* desc, int device_id, d2s_engine** out) {
+    D2S_REQUIRE(desc && out, "null pointer");
+    D2S_REQUIRE(desc->hidden > 0 && desc->heads > 0 && desc->hidden == desc->heads * 64, "head_dim must be 64");
+    D2S_REQUIRE(desc->layers > 0 && desc->patch > 0 && desc->pos_grid > 0 && desc->fusion % 8 == 0, "bad model desc");
+    D2S_REQUIRE(desc->precision == D2S_PREC_FP32 || desc->precision == D2S_PREC_BF16, "bad precision");
+    for (int i = 0; i < 4; ++i) D2S_REQUIRE(desc->neck[i] % 8 == 0 && desc->out_indices[i] >= 1 && desc->out_indices[i] <= desc->layers, "bad neck / out_indices");
+    D2S_REQUIRE(desc->head_hidden % 4 == 0 && desc->mlp % 8 == 0, "bad head_hidden / mlp");
+    D2S_HIP(hipSetDevice(device_id));
+    d2s_engine* e = new d2s_engine();
+    e->d = *desc; e->device = device_id; e->prec = desc->precision;
+    const char* t = getenv("D2S_TAPS");
+    e->taps = t && atoi(t) != 0;
+    *out = e;
+    return D2S_OK;
+}
+
+extern "C" int d2s_engine_set_weight(d2s_engine* e, const char* name, const float* host, const int64_t* shape, int ndim) {
+    D2S_REQUIRE(e && name && host && shape && ndim >= 1 && ndim <= 4, "bad argument");
+    if (e->finalized) { set_error("d2s_engine_set_weight after finalize"); return D2S_E_STATE; }
+    HostT t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { D2S_REQUIRE(shape[i] > 0, "bad shape"); n *= (size_t)shape[i]; t.shape.push_back(shape[i]); }
+    t.data.assign(host, host + n);
+    e->host[name] = std::move(t);
+    return D2S_OK;
+}
+
+extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
+    D2S_REQUIRE(e, "null engine");
+    if (e->finalized) { set_error("engine already finalized"); return D2S_E_STATE; }
+    const d2s_model_desc& d = e->d;
+    D2S_REQUIRE(h > 0 && w > 0 && h % d.patch == 0 && w % d.patch == 0 && max_batch >= 1, "h, w must be patch multiples");
+    D2S_HIP(hipSetDevice(e->device));
+    const int D = d.hidden, F = d.fusion;
+    e->h = h; e->w = w; e->gh = h / d.patch; e->gw = w / d.patch; e->P = e->gh * e->gw; e->N = e->P + 1;
+    e->Npad = (e->N + 63) / 64 * 64; e->maxB = max_batch;
+    const int N = e->N, P = e->P, B = max_batch;
+    const size_t es = elem_size(e->prec);
+    std::string pe = "backbone.embeddings.";
+    // ---- weights
+    RC(pack_linear(e, pe + "patch_embeddings.projection.weight", pe + "patch_embeddings.projection.bias", D, 3 * d.patch * d.patch, e->patch));
+    RC(upload_f32(e, pe + "cls_token", D, &e->cls));
+    {
+        const HostT* pt = find(e, pe + "position_embeddings");
+        if (!pt) return D2S_E_MISSING;
+        if (pt->data.size() != (size_t)(d.pos_grid * d.pos_grid + 1) * D) { set_error("position_embeddings: wrong shape"); return D2S_E_MISSING; }
+        std::vector<float> pos;
+        interp_pos(pt->data.data(), d.pos_grid, D, e->gh, e->gw, pos);
+        RC(dev_alloc(e, (void**)&e->pos, pos.size() * 4));
+        D2S_HIP(hipMemcpy(e->pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+    }
+    e->L.resize(d.layers);
+    for (int l = 0; l < d.layers; ++l) {
+        std::string p = "backbone.encoder.layer." + std::to_string(l) + ".";
+        Layer& ly = e->L[l];
+        RC(upload_f32(e, p + "norm1.weight", D, &ly.ln1g)); RC(upload_f32(e, p + "norm1.bias", D, &ly.ln1b));
+        RC(upload_f32(e, p + "norm2.weight", D, &ly.ln2g)); RC(upload_f32(e, p + "norm2.bias", D, &ly.ln2b));
+        RC(upload_f32(e, p + "layer_scale1.lambda1", D, &ly.ls1)); RC(upload_f32(e, p + "layer_scale2.lambda1", D, &ly.ls2));
+        // fused QKV: rows q | k | v
+        const HostT *wq = find(e, p + "attention.attention.query.weight"), *wk = find(e, p + "attention.attention.key.weight"),
+                    *wv = find(e, p + "attention.attention.value.weight"), *bq = find(e, p + "attention.attention.query.bias"),
+                    *bk = find(e, p + "attention.attention.key.bias"), *bv = find(e, p + "attention.attention.value.bias");
+        if (!wq || !wk || !wv || !bq || !bk || !bv) return D2S_E_MISSING;
+        for (const HostT* t : {wq, wk, wv}) if (t->data.size() != (size_t)D * D) { set_error("qkv weight: wrong shape"); return D2S_E_MISSING; }
+        std::vector<float> bias(3 * D);
+        for (int i = 0; i < D; ++i) { bias[i] = bq->data[i]; bias[D + i] = bk->data[i]; bias[2 * D + i] = bv->data[i]; }
+        const float* ws[3] = {wq->data.data(), wk->data.data(), wv->data.data()};
+        RC(pack_matrix(e, 3 * D, D, [&](int n, int k) { return ws[n / D][(size_t)(n % D) * D + k]; }, bias.data(), ly.qkv));
+        RC(pack_linear(e, p + "attention.output.dense.weight", p + "attention.output.dense.bias", D, D, ly.proj));
+        RC(pack_linear(e, p + "mlp.fc1.weight", p + "mlp.fc1.bias", d.mlp, D, ly.fc1));
+        RC(pack_linear(e, p + "mlp.fc2.weight", p + "mlp.fc2.bias", D, d.mlp, ly.fc2));
+    }
+    RC(upload_f32(e, "backbone.layernorm.weight", D, &e->lnfg));
+    RC(upload_f32(e, "backbone.layernorm.bias", D, &e->lnfb));
+    for (int i = 0; i < 4; ++i) {
+        std::string p = "neck.reassemble_stage.layers." + std::to_string(i) + ".";
+        int c = d.neck[i];
+        RC(pack_linear(e, p + "projection.weight", p + "projection.bias", c, D, e->re[i].proj));
+        if (i == 0) RC(pack_convT(e, p + "resize.weight", p + "resize.bias", c, 4, e->re[i].resize));
+        if (i == 1) RC(pack_convT(e, p + "resize.weight", p + "resize.bias", c, 2, e->re[i].resize));
+        if (i == 3) RC(pack_conv3(e, p + "resize.weight", p + "resize.bias", c, c, e->re[i].resize));
+        RC(pack_conv3(e, "neck.convs." + std::to_string(i) + ".weight", "", F, c, e->re[i].conv));
+    }
+    for (int i = 0; i < 4; ++i) {
+        std::string p = "neck.fusion_stage.layers." + std::to_string(i) + ".";
+        RC(pack_linear(e, p + "projection.weight", p + "projection.bias", F, F, e->fu[i].proj));
+        RC(pack_conv3(e, p + "residual_layer1.convolution1.weight", p + "residual_layer1.convolution1.bias", F, F, e->fu[i].r1c1));
+        RC(pack_conv3(e, p + "residual_layer1.convolution2.weight", p + "residual_layer1.convolution2.bias", F, F, e->fu[i].r1c2));
+        RC(pack_conv3(e, p + "residual_layer2.convolution1.weight", p + "residual_layer2.convolution1.bias", F, F, e->fu[i].r2c1));
+        RC(pack_conv3(e, p + "residual_layer2.convolution2.weight", p + "residual_layer2.convolution2.bias", F, F, e->fu[i].r2c2));
+    }
+    RC(pack_conv3(e, "head.conv1.weight", "head.conv1.bias", F / 2, F, e->head1));
+    RC(pack_conv3(e, "head.conv2.weight", "head.conv2.bias", d.head_hidden, F / 2, e->head2));
+    RC(upload_f32(e, "head.conv3.weight", d.head_hidden, &e->w3));
+    { const HostT* b3 = find(e, "head.conv3.bias"); if (!b3) return D2S_E_MISSING; e->b3 = b3->data[0]; }
+    e->host.clear();
+
+    // ---- workspaces
+    const size_t M = (size_t)B * N, Mp = (size_t)B * P;
+    RC(dev_alloc(e, (void**)&e->resid, M * D * 4));
+    RC(dev_alloc(e, &e->lnbuf, M * D * es));
+    RC(dev_alloc(e, &e->qkv, M * 3 * D * es));
+    RC(dev_alloc(e, &e->vt, (size_t)B * D * e->Npad * es, true));     // zero beyond N, never written there
+    RC(dev_alloc(e, &e->attn, M * D * es));
+    RC(dev_alloc(e, &e->mlp, M * d.mlp * es));
+    RC(dev_alloc(e, &e->patchA, Mp * e->patch.Kpad * es));
+    const int gh = e->gh, gw = e->gw;
+    e->fH[0] = gh * 4; e->fW[0] = gw * 4; e->fH[1] = gh * 2; e->fW[1] = gw * 2; e->fH[2] = gh; e->fW[2] = gw;
+    e->fH[3] = (gh - 1) / 2 + 1; e->fW[3] = (gw - 1) / 2 + 1;
+    for (int i = 0; i < 4; ++i) {
+        RC(dev_alloc(e, &e->tapbuf[i], Mp * D * es));
+        RC(dev_alloc(e, &e->rproj[i], Mp * d.neck[i] * es));
+        RC(dev_alloc(e, &e->rres[i], (size_t)B * e->fH[i] * e->fW[i] * d.neck[i] * es));
+        RC(dev_alloc(e, &e->feat[i], (size_t)B * e->fH[i] * e->fW[i] * F * es));
+    }
+    size_t scr_elems = std::max({(size_t)64 * gh * gw * F, (size_t)h * w * (F / 2), (size_t)h * w * d.head_hidden}) * B;
+    for (int i = 0; i < 5; ++i) RC(dev_alloc(e, &e->scr[i], scr_elems * es));
+    RC(dev_alloc(e, (void**)&e->pre_x, (size_t)B * 3 * h * w * 4));
+    RC(dev_alloc(e, (void**)&e->depth_small, (size_t)B * h * w * 4));
+    e->post_ws_bytes = d2s_post_process_workspace(B, h, w);
+    RC(dev_alloc(e, &e->post_ws, e->post_ws_bytes));
+    RC(dev_alloc(e, (void**)&e->ema_state, (size_t)h * w * 4));
+    if (e->taps) RC(dev_alloc(e, (void**)&e->tap_hidden, (size_t)(d.layers + 1) * N * D * 4));
+    D2S_HIP(hipDeviceSynchronize());
+    e->finalized = true;
+    return D2S_OK;
+}
+
+extern "C" int d2s_engine_destroy(d2s_engine* e) {
+    if (!e) return D2S_OK;
+    for (void* p : e->allocs) (void)hipFree(p);
+    delete e;
+    return D2S_OK;
+}
+
+extern "C" int d2s_engine_memory(const d2s_engine* e, uint64_t* bytes) {
+    D2S_REQUIRE(e && bytes, "null pointer");
+    *bytes = e->bytes;
+    return D2S_OK;
+}
+
+extern "C" int d2s_model_forward(d2s_engine* e, const float* x, float* depth, int batch, void* stream) {
+    D2S_REQUIRE(e && x && depth, "null pointer");
+    if (!e->finalized) { set_error("d2s_model_forward before d2s_engine_finalize"); return D2S_E_STATE; }
+    D2S_REQUIRE(batch >= 1 && batch <= e->maxB, "batch exceeds max_batch");
+    return forward(e, x, depth, batch, (hipStream_t)stream);
+}
+
+extern "C" int d2s_engine_reset_stream(d2s_engine* e) {
+    D2S_REQUIRE(e, "null engine");
+    e->ema_init = 0;
+    return D2S_OK;
+}
+
+extern "C" int d2s_pipeline(d2s_engine* e, const uint8_t* frames, int batch, int H, int W, int depth_resolution,
+                            const d2s_post_params* pp, const d2s_sbs_params* sp, int use_ema, void* out, int out_fmt,
+                            float* depth_full, void* stream) {
+    D2S_REQUIRE(e && frames && pp && sp && out, "null pointer");
+    if (!e->finalized) { set_error("d2s_pipeline before d2s_engine_finalize"); return D2S_E_STATE; }
+    D2S_REQUIRE(batch >= 1 && batch <= e->maxB, "batch exceeds max_batch");
+    // model-input shape of this frame size must be the engine's (reference: fixed at first frame, depth.py:1951-1953)
+    D2S_REQUIRE(H > 0 && W > 0 && depth_resolution > 0, "bad frame shape");
+    int longest = H > W ? H : W;
+    {   // _resize_patch_aligned_t integer logic (reference depth.py:677-689); Python round() = half-to-even
+        double scale = longest != depth_resolution ? (double)depth_resolution / (double)longest : 1.0;
+        int sh = std::max(1, (int)nearbyint(H * scale)), sw = std::max(1, (int)nearbyint(W * scale));
+        auto nm = [&](int x) { int p = e->d.patch, down = (x / p) * p, up = down + p; return (std::abs(up - x) <= std::abs(x - down)) ? up : down; };
+        if (std::max(1, nm(sh)) != e->h || std::max(1, nm(sw)) != e->w) {
+            set_error("d2s_pipeline: frame maps to a model-input shape different from the engine's"); return D2S_E_INVALID;
+        }
+    }
+    int stride = longest / (depth_resolution * 2);
+    if (stride < 1) stride = 1;
+    hipStream_t st = (hipStream_t)stream;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};   // depth.py:1798-1799
+    RC(d2s_preprocess(frames, D2S_FMT_U8_HWC, batch, H, W, e->pre_x, e->h, e->w, stride, mean, stdv, stream));
+    RC(forward(e, e->pre_x, e->depth_small, batch, st));
+    RC(d2s_post_process(e->depth_small, batch, e->h, e->w, pp, e->post_ws, e->post_ws_bytes, stream));
+    if (use_ema) {
+        RC(ema_batch(e->depth_small, e->ema_state, e->ema_init, batch, e->h * e->w, pp->ema_alpha, st));
+        e->ema_init = 1;
+    }
+    if (depth_full) RC(d2s_upsample_depth(e->depth_small, batch, e->h, e->w, depth_full, H, W, stream));
+    RC(d2s_make_sbs(frames, D2S_FMT_U8_HWC, e->depth_small, e->h, e->w, batch, H, W, sp, out, out_fmt, stream));
+    return D2S_OK;
+}
+
+extern "C" int d2s_engine_tap(d2s_engine* e, const char* name, float* out, uint64_t out_elems, int* rows, int* cols, void* stream) {
+    D2S_REQUIRE(e && name && out && rows && cols, "null pointer");
+    if (!e->finalized || e->last_batch == 0) { set_error("d2s_engine_tap: no forward pass yet"); return D2S_E_STATE; }
+    hipStream_t st = (hipStream_t)stream;
+    std::string n(name);
+    const int D = e->d.hidden, F = e->d.fusion;
+    if (n == "embeddings" || n.rfind("layer", 0) == 0) {
+        if (!e->taps) { set_error("hidden-state taps need D2S_TAPS=1 at engine creation"); return D2S_E_STATE; }
+        int l = n == "embeddings" ? 0 : atoi(n.c_str() + 5);
+        D2S_REQUIRE(l >= 0 && l <= e->d.layers, "bad layer index");
+        *rows = e->N; *cols = D;
+        D2S_REQUIRE(out_elems >= (uint64_t)e->N * D, "tap buffer too small");
+        D2S_HIP(hipMemcpyAsync(out, e->tap_hidden + (size_t)l * e->N * D, (size_t)e->N * D * 4, hipMemcpyDeviceToDevice, st));
+        return D2S_OK;
+    }
+    if (n.rfind("neck_feat", 0) == 0) {
+        int i = atoi(n.c_str() + 9);
+        D2S_REQUIRE(i >= 0 && i < 4, "bad neck index");
+        *rows = e->fH[i] * e->fW[i]; *cols = F;
+        D2S_REQUIRE(out_elems >= (uint64_t)(*rows) * F, "tap buffer too small");
+        return launch_to_f32(e->prec, e->feat[i], out, (long)(*rows) * F, st);
+    }
+    set_error("unknown tap: " + n);
+    return D2S_E_INVALID;
+}

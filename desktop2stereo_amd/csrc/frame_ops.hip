@@ -1,0 +1,498 @@
+// Frame-side kernels of the hot path (HBM-bound, no matrix work):
+//   preprocess      A2-A4  (reference depth.py:676-706, 1916-1948)
+//   upsample_depth  A13    (reference depth.py:1999-2004)
+//   stereo_warp     A14    (reference depth.py:2122-2184), with A13 fused when depth comes at model res
+#include "common.h"
+
+namespace d2s {
+
+// ------------------------------------------------------------------------------------------------
+// pixel fetch in the boundary formats; returns 0..255 float
+// ------------------------------------------------------------------------------------------------
+template <int FMT>
+__device__ __forceinline__ void load_px(const void* base, long frame_off_px, int H, int W, int y, int x,
+                                        float& r, float& g, float& b) {
+    if (FMT == D2S_FMT_U8_HWC) {
+        const uint8_t* p = (const uint8_t*)base + (frame_off_px + (long)y * W + x) * 3;
+        r = (float)p[0]; g = (float)p[1]; b = (float)p[2];
+    } else if (FMT == D2S_FMT_U8_CHW) {
+        const uint8_t* p = (const uint8_t*)base + frame_off_px * 3 + (long)y * W + x;
+        long pl = (long)H * W;
+        r = (float)p[0]; g = (float)p[pl]; b = (float)p[2 * pl];
+    } else {  // F32_CHW
+        const float* p = (const float*)base + frame_off_px * 3 + (long)y * W + x;
+        long pl = (long)H * W;
+        r = p[0]; g = p[pl]; b = p[2 * pl];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A2-A4 preprocess: (optional ::stride decimation) -> bilinear(align_corners=False) -> /255 -> norm
+// one thread per output pixel, all three channels; output planes [B,3,h,w] float
+// ------------------------------------------------------------------------------------------------
+template <int FMT>
+__global__ void __launch_bounds__(256)
+preprocess_kernel(const void* __restrict__ frames, int B, int H, int W, int stride,
+                  float* __restrict__ out, int h, int w, float sy, float sx,
+                  float m0, float m1, float m2, float is0, float is1, float is2) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * h * w;
+    if (idx >= total) return;
+    int ox = (int)(idx % w);
+    int oy = (int)((idx / w) % h);
+    int b = (int)(idx / ((long)w * h));
+    int Hs = (H + stride - 1) / stride, Ws = (W + stride - 1) / stride;
+    Tap ty = linear_tap(oy, sy, Hs, false);
+    Tap tx = linear_tap(ox, sx, Ws, false);
+    long fo = (long)b * H * W;
+    float a[3], c[3], d[3], e[3];
+    load_px<FMT>(frames, fo, H, W, ty.i0 * stride, tx.i0 * stride, a[0], a[1], a[2]);
+    load_px<FMT>(frames, fo, H, W, ty.i0 * stride, tx.i1 * stride, c[0], c[1], c[2]);
+    load_px<FMT>(frames, fo, H, W, ty.i1 * stride, tx.i0 * stride, d[0], d[1], d[2]);
+    load_px<FMT>(frames, fo, H, W, ty.i1 * stride, tx.i1 * stride, e[0], e[1], e[2]);
+    const float mean[3] = {m0, m1, m2};
+    const float istd[3] = {is0, is1, is2};
+    long plane = (long)h * w;
+    float* o = out + (long)b * 3 * plane + (long)oy * w + ox;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        // ATen order: wy0*(wx0*a + wx1*b) + wy1*(wx0*c + wx1*d)
+        float top = tx.w0 * a[ch] + tx.w1 * c[ch];
+        float bot = tx.w0 * d[ch] + tx.w1 * e[ch];
+        float v = ty.w0 * top + ty.w1 * bot;
+        v = v / 255.0f;
+        o[ch * plane] = (v - mean[ch]) / istd[ch];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A13: depth up-sample, bilinear align_corners=False
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+upsample_depth_kernel(const float* __restrict__ in, int B, int h, int w, float* __restrict__ out,
+                      int H, int W, float sy, float sx) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * H * W;
+    if (idx >= total) return;
+    int x = (int)(idx % W);
+    int y = (int)((idx / W) % H);
+    int b = (int)(idx / ((long)W * H));
+    Tap ty = linear_tap(y, sy, h, false);
+    Tap tx = linear_tap(x, sx, w, false);
+    const float* p = in + (long)b * h * w;
+    float top = tx.w0 * p[ty.i0 * w + tx.i0] + tx.w1 * p[ty.i0 * w + tx.i1];
+    float bot = tx.w0 * p[ty.i1 * w + tx.i0] + tx.w1 * p[ty.i1 * w + tx.i1];
+    out[idx] = ty.w0 * top + ty.w1 * bot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A14 stereo warp
+// ------------------------------------------------------------------------------------------------
+struct WarpGeom {
+    int H, W;            // source frame
+    int dh, dw;          // depth grid
+    float dsy, dsx;      // depth grid scales (in/out)
+    int Hp, Wp;          // eye frame after pad_to_aspect
+    int pad_top, pad_left;
+    int out_h, out_w;    // packed output
+    int mode;
+    float conv, ratio, max_px;
+};
+
+__device__ __forceinline__ float depth_at(const float* __restrict__ dep, const WarpGeom& g, int y, int x) {
+    Tap ty = linear_tap(y, g.dsy, g.dh, false);
+    Tap tx = linear_tap(x, g.dsx, g.dw, false);
+    float top = tx.w0 * dep[ty.i0 * g.dw + tx.i0] + tx.w1 * dep[ty.i0 * g.dw + tx.i1];
+    float bot = tx.w0 * dep[ty.i1 * g.dw + tx.i0] + tx.w1 * dep[ty.i1 * g.dw + tx.i1];
+    return ty.w0 * top + ty.w1 * bot;
+}
+
+// reflect about [0, span] then clip (ATen grid_sampler reflect_coordinates, align_corners=True)
+__device__ __forceinline__ float reflect_clip(float x, float span) {
+    if (span <= 0.f) return 0.f;
+    x = fabsf(x);
+    if (x <= span) return x;                                   // common case: at most one reflection at 0
+    float extra = fmodf(x, span);
+    int flips = (int)floorf(x / span);
+    float r = (flips & 1) ? span - extra : extra;
+    return fminf(fmaxf(r, 0.f), span);
+}
+
+// one eye-plane sample: E(eye, y, x) for in-frame (y, x); sign = +1 left eye, -1 right eye
+template <int IN_FMT>
+__device__ __forceinline__ void eye_sample(const void* __restrict__ rgb, long frame_off_px,
+                                           const float* __restrict__ dep, const WarpGeom& g,
+                                           int y, int x, float sign, float& r, float& gg, float& b) {
+    float d = depth_at(dep, g, y, x) - g.conv;
+    float shift = ((-d * g.ratio) * g.max_px) * 0.05f;       // reference depth.py:2144-2147
+    float sx = reflect_clip((float)x + sign * shift, (float)(g.W - 1));
+    int x0 = (int)sx;
+    float w1 = sx - (float)x0;
+    float w0 = 1.0f - w1;
+    int x1 = x0 + 1 < g.W ? x0 + 1 : x0;                     // out-of-range tap has weight 0 anyway
+    float r0, g0, b0, r1, g1, b1;
+    load_px<IN_FMT>(rgb, frame_off_px, g.H, g.W, y, x0, r0, g0, b0);
+    load_px<IN_FMT>(rgb, frame_off_px, g.H, g.W, y, x1, r1, g1, b1);
+    if (IN_FMT == D2S_FMT_F32_CHW) {                          // img.clamp(0,255), depth.py:2142
+        r0 = fminf(fmaxf(r0, 0.f), 255.f); g0 = fminf(fmaxf(g0, 0.f), 255.f); b0 = fminf(fmaxf(b0, 0.f), 255.f);
+        r1 = fminf(fmaxf(r1, 0.f), 255.f); g1 = fminf(fmaxf(g1, 0.f), 255.f); b1 = fminf(fmaxf(b1, 0.f), 255.f);
+    }
+    r = w0 * r0 + w1 * r1; gg = w0 * g0 + w1 * g1; b = w0 * b0 + w1 * b1;
+}
+
+// value of the concatenated (padded) stereo frame at cat coordinates
+template <int IN_FMT>
+__device__ __forceinline__ void cat_sample(const void* __restrict__ rgb, long fo, const float* __restrict__ dep,
+                                           const WarpGeom& g, int cy, int cx, bool tab,
+                                           float& r, float& gg, float& b) {
+    int eye, yp, xp;
+    if (tab) { eye = cy >= g.Hp; yp = cy - eye * g.Hp; xp = cx; }
+    else     { eye = cx >= g.Wp; xp = cx - eye * g.Wp; yp = cy; }
+    int y = yp - g.pad_top, x = xp - g.pad_left;
+    if (y < 0 || y >= g.H || x < 0 || x >= g.W) { r = gg = b = 0.f; return; }
+    eye_sample<IN_FMT>(rgb, fo, dep, g, y, x, eye ? -1.0f : 1.0f, r, gg, b);
+}
+
+__device__ __forceinline__ uint8_t to_u8(float v) {
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    return (uint8_t)__float2int_rn(v);                         // round-half-even, saturate
+}
+
+// Generic kernel: one thread per output pixel, any alignment / padding / mode.
+template <int IN_FMT, int OUT_FMT>
+__global__ void __launch_bounds__(256)
+stereo_warp_generic(const void* __restrict__ rgb, const float* __restrict__ depth, void* __restrict__ out,
+                    int B, WarpGeom g) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long per = (long)g.out_h * g.out_w;
+    if (idx >= per * B) return;
+    int ox = (int)(idx % g.out_w);
+    int oy = (int)((idx / g.out_w) % g.out_h);
+    int b = (int)(idx / per);
+    long fo = (long)b * g.H * g.W;
+    const float* dep = depth + (long)b * g.dh * g.dw;
+    bool tab = (g.mode == D2S_MODE_HALF_TAB || g.mode == D2S_MODE_FULL_TAB);
+    float r, gg, bl;
+    if (g.mode == D2S_MODE_FULL_SBS || g.mode == D2S_MODE_FULL_TAB) {
+        cat_sample<IN_FMT>(rgb, fo, dep, g, oy, ox, tab, r, gg, bl);
+    } else {
+        float r2, g2, b2;
+        if (tab) { cat_sample<IN_FMT>(rgb, fo, dep, g, 2 * oy, ox, true, r, gg, bl);
+                   cat_sample<IN_FMT>(rgb, fo, dep, g, 2 * oy + 1, ox, true, r2, g2, b2); }
+        else     { cat_sample<IN_FMT>(rgb, fo, dep, g, oy, 2 * ox, false, r, gg, bl);
+                   cat_sample<IN_FMT>(rgb, fo, dep, g, oy, 2 * ox + 1, false, r2, g2, b2); }
+        r = (r + r2) * 0.5f; gg = (gg + g2) * 0.5f; bl = (bl + b2) * 0.5f;   // F.interpolate(mode='area')
+    }
+    r = fminf(fmaxf(r, 0.f), 255.f); gg = fminf(fmaxf(gg, 0.f), 255.f); bl = fminf(fmaxf(bl, 0.f), 255.f);
+    if (OUT_FMT == D2S_FMT_U8_HWC) {
+        uint8_t* o = (uint8_t*)out + (b * per + (long)oy * g.out_w + ox) * 3;
+        o[0] = to_u8(r); o[1] = to_u8(gg); o[2] = to_u8(bl);
+    } else if (OUT_FMT == D2S_FMT_F32_HWC) {
+        float* o = (float*)out + (b * per + (long)oy * g.out_w + ox) * 3;
+        o[0] = r; o[1] = gg; o[2] = bl;
+    } else {  // F32_CHW
+        float* o = (float*)out + b * per * 3 + (long)oy * g.out_w + ox;
+        o[0] = r; o[per] = gg; o[2 * per] = bl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path (the bench configuration): u8 HWC in, u8 HWC out, no padding, even W.
+// One thread per 4 consecutive SOURCE pixels of one row: the depth sample / shift is computed once
+// and shared by both eyes; the source row window is staged through LDS with coalesced dword reads;
+// each eye's 4 (Full) or 2 (Half-SBS) output pixels leave as one 12-/6-byte store.
+// Block = 256 threads = 1024 source pixels of one row.
+// ------------------------------------------------------------------------------------------------
+constexpr int FP_PX = 4;                    // source pixels per thread
+constexpr int FP_TW = 256 * FP_PX;          // tile width in source pixels
+constexpr int FP_MARGIN = 64;               // staged halo each side (pixels); beyond it -> global fallback
+constexpr int FP_LDS_PX = FP_TW + 2 * FP_MARGIN;
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+stereo_warp_fast(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
+                 int B, WarpGeom g) {
+    __shared__ __attribute__((aligned(16))) uint8_t srow[FP_LDS_PX * 3 + 16];
+    __shared__ float drow[FP_TW + 8];       // vertically interpolated depth row segment (dw <= W: dispatcher)
+    const int tiles_x = (g.W + FP_TW - 1) / FP_TW;
+    int bid = blockIdx.x;
+    int tx = bid % tiles_x;
+    int y = (bid / tiles_x) % g.H;
+    int b = bid / (tiles_x * g.H);
+    const int xa = tx * FP_TW;
+    const uint8_t* src_row = rgb + ((long)b * g.H + y) * (long)g.W * 3;
+    // ---- stage source window [xa - M, xa + TW + M) clipped to [0, W) : coalesced 4-byte reads
+    int wx0 = xa - FP_MARGIN; if (wx0 < 0) wx0 = 0;
+    int wx1 = xa + FP_TW + FP_MARGIN; if (wx1 > g.W) wx1 = g.W;
+    {
+        long byte0 = (long)wx0 * 3;
+        long byte1 = (long)wx1 * 3;
+        long a0 = byte0 & ~3L;                                  // row base is 4-aligned when W*3 % 4 == 0 (dispatcher)
+        int nwords = (int)((byte1 - a0 + 3) >> 2);
+        const uint32_t* gp = (const uint32_t*)(src_row + a0);
+        uint32_t* lp = (uint32_t*)srow;
+        long row_bytes = (long)g.W * 3;
+        for (int i = threadIdx.x; i < nwords; i += 256) {
+            uint32_t v;
+            if (a0 + 4L * i + 4 <= row_bytes) v = gp[i];
+            else { v = 0; for (int k = 0; k < 4; ++k) if (a0 + 4L * i + k < row_bytes) v |= (uint32_t)src_row[a0 + 4L * i + k] << (8 * k); }
+            lp[i] = v;
+        }
+    }
+    const int lds_byte0 = (int)(((long)wx0 * 3) & 3L) - wx0 * 3;   // srow index of pixel x byte c = x*3 + c + lds_byte0
+    // ---- stage depth: vertical lerp of the two depth rows over the needed column span
+    const float* dep = depth + (long)b * g.dh * g.dw;
+    Tap ty = linear_tap(y, g.dsy, g.dh, false);
+    int xe = xa + FP_TW - 1; if (xe > g.W - 1) xe = g.W - 1;
+    int dxa = linear_tap(xa, g.dsx, g.dw, false).i0;
+    int dxb = linear_tap(xe, g.dsx, g.dw, false).i1;
+    int dn = dxb - dxa + 1;
+    for (int i = threadIdx.x; i < dn; i += 256)
+        drow[i] = ty.w0 * dep[ty.i0 * g.dw + dxa + i] + ty.w1 * dep[ty.i1 * g.dw + dxa + i];
+    __syncthreads();
+
+    const int x_base = xa + threadIdx.x * FP_PX;
+    if (x_base >= g.W) return;
+    float shift[FP_PX];
+#pragma unroll
+    for (int k = 0; k < FP_PX; ++k) {
+        int x = x_base + k; if (x > g.W - 1) x = g.W - 1;
+        Tap t = linear_tap(x, g.dsx, g.dw, false);
+        float d = t.w0 * drow[t.i0 - dxa] + t.w1 * drow[t.i1 - dxa] - g.conv;
+        shift[k] = ((-d * g.ratio) * g.max_px) * 0.05f;
+    }
+    const float span = (float)(g.W - 1);
+    const long per = (long)g.out_h * g.out_w;
+#pragma unroll
+    for (int eye = 0; eye < 2; ++eye) {
+        float px[FP_PX][3];
+#pragma unroll
+        for (int k = 0; k < FP_PX; ++k) {
+            int x = x_base + k;
+            float sx = reflect_clip((float)x + (eye ? -shift[k] : shift[k]), span);
+            int x0 = (int)sx;
+            float w1 = sx - (float)x0, w0 = 1.0f - w1;
+            int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
+            const uint8_t *p0, *p1;
+            if (x0 >= wx0 && x1 < wx1) { p0 = srow + x0 * 3 + lds_byte0; p1 = srow + x1 * 3 + lds_byte0; }
+            else { p0 = src_row + (long)x0 * 3; p1 = src_row + (long)x1 * 3; }      // rare: shift beyond halo
+#pragma unroll
+            for (int c = 0; c < 3; ++c) px[k][c] = w0 * (float)p0[c] + w1 * (float)p1[c];
+        }
+        if (x_base + FP_PX <= g.W) {
+            if (MODE == D2S_MODE_FULL_SBS || MODE == D2S_MODE_FULL_TAB) {
+                long row = (MODE == D2S_MODE_FULL_SBS) ? y : (long)eye * g.H + y;
+                long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + x_base : x_base;
+                uint32_t w[3];
+                uint8_t bytes[12];
+#pragma unroll
+                for (int k = 0; k < FP_PX; ++k)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) bytes[k * 3 + c] = to_u8(px[k][c]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    w[i] = bytes[4 * i] | (bytes[4 * i + 1] << 8) | (bytes[4 * i + 2] << 16) | ((uint32_t)bytes[4 * i + 3] << 24);
+                uint32_t* o = (uint32_t*)(out + (b * per + row * g.out_w + col) * 3);
+                o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+            } else {  // HALF_SBS: cat columns (eye*W + x) pair up; W even and x_base % 4 == 0
+                long col = ((long)eye * g.W + x_base) >> 1;
+                uint8_t* o = out + (b * per + (long)y * g.out_w + col) * 3;
+                uint8_t bytes[6];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    bytes[c] = to_u8((px[0][c] + px[1][c]) * 0.5f);
+                    bytes[3 + c] = to_u8((px[2][c] + px[3][c]) * 0.5f);
+                }
+                uint16_t* o16 = (uint16_t*)o;                       // 6-byte aligned to 2
+                o16[0] = bytes[0] | (bytes[1] << 8); o16[1] = bytes[2] | (bytes[3] << 8); o16[2] = bytes[4] | (bytes[5] << 8);
+            }
+        } else {  // ragged tail of the row: per-pixel stores
+            for (int k = 0; k < FP_PX && x_base + k < g.W; ++k) {
+                if (MODE == D2S_MODE_FULL_SBS || MODE == D2S_MODE_FULL_TAB) {
+                    long row = (MODE == D2S_MODE_FULL_SBS) ? y : (long)eye * g.H + y;
+                    long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + x_base + k : x_base + k;
+                    uint8_t* o = out + (b * per + row * g.out_w + col) * 3;
+                    for (int c = 0; c < 3; ++c) o[c] = to_u8(px[k][c]);
+                } else if ((k & 1) == 0 && x_base + k + 1 < g.W) {
+                    long col = ((long)eye * g.W + x_base + k) >> 1;
+                    uint8_t* o = out + (b * per + (long)y * g.out_w + col) * 3;
+                    for (int c = 0; c < 3; ++c) o[c] = to_u8((px[k][c] + px[k + 1][c]) * 0.5f);
+                }
+            }
+        }
+    }
+}
+
+// Half-TAB fast path: thread = 4 source pixels x 2 rows (y, y+1 with even y); H even.
+__global__ void __launch_bounds__(256)
+stereo_warp_fast_halftab(const uint8_t* __restrict__ rgb, const float* __restrict__ depth,
+                         uint8_t* __restrict__ out, int B, WarpGeom g) {
+    // Direct (L2-cached) reads; the two rows share the thread's column window.
+    const int tiles_x = (g.W + FP_TW - 1) / FP_TW;
+    int bid = blockIdx.x;
+    int tx = bid % tiles_x;
+    int yp = (bid / tiles_x) % (g.H / 2);
+    int b = bid / (tiles_x * (g.H / 2));
+    const int x_base = tx * FP_TW + threadIdx.x * FP_PX;
+    if (x_base >= g.W) return;
+    const float* dep = depth + (long)b * g.dh * g.dw;
+    const float span = (float)(g.W - 1);
+    const long per = (long)g.out_h * g.out_w;
+    float acc[2][FP_PX][3];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int k = 0; k < FP_PX; ++k) acc[e][k][0] = acc[e][k][1] = acc[e][k][2] = 0.f;
+#pragma unroll
+    for (int ry = 0; ry < 2; ++ry) {
+        int y = 2 * yp + ry;
+        const uint8_t* src_row = rgb + ((long)b * g.H + y) * (long)g.W * 3;
+#pragma unroll
+        for (int k = 0; k < FP_PX; ++k) {
+            int x = x_base + k; if (x > g.W - 1) x = g.W - 1;
+            float d = depth_at(dep, g, y, x) - g.conv;
+            float shift = ((-d * g.ratio) * g.max_px) * 0.05f;
+#pragma unroll
+            for (int eye = 0; eye < 2; ++eye) {
+                float sx = reflect_clip((float)x + (eye ? -shift : shift), span);
+                int x0 = (int)sx;
+                float w1 = sx - (float)x0, w0 = 1.0f - w1;
+                int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
+                const uint8_t* p0 = src_row + (long)x0 * 3;
+                const uint8_t* p1 = src_row + (long)x1 * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float v = w0 * (float)p0[c] + w1 * (float)p1[c];
+                    acc[eye][k][c] = ry == 0 ? v : (acc[eye][k][c] + v) * 0.5f;
+                }
+            }
+        }
+    }
+    // cat rows: eye*H + y ; out row = (eye*H + 2*yp) / 2 = eye*H/2 + yp
+#pragma unroll
+    for (int eye = 0; eye < 2; ++eye) {
+        long row = (long)eye * (g.H / 2) + yp;
+        uint8_t* o = out + (b * per + row * g.out_w + x_base) * 3;
+        for (int k = 0; k < FP_PX && x_base + k < g.W; ++k)
+            for (int c = 0; c < 3; ++c) o[k * 3 + c] = to_u8(acc[eye][k][c]);
+    }
+}
+
+}  // namespace d2s
+
+using namespace d2s;
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+extern "C" int d2s_preprocess(const void* frames, int fmt, int batch, int H, int W, float* out, int h, int w,
+                              int decim_stride, const float mean[3], const float stdv[3], void* stream) {
+    D2S_REQUIRE(frames && out && mean && stdv, "null pointer");
+    D2S_REQUIRE(batch > 0 && H > 0 && W > 0 && h > 0 && w > 0 && decim_stride >= 1, "bad shape");
+    int Hs = (H + decim_stride - 1) / decim_stride, Ws = (W + decim_stride - 1) / decim_stride;
+    float sy = linear_scale(Hs, h, false), sx = linear_scale(Ws, w, false);
+    long total = (long)batch * h * w;
+    dim3 grid(cdiv(total, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_PRE(F) hipLaunchKernelGGL(preprocess_kernel<F>, grid, block, 0, st, frames, batch, H, W, decim_stride, \
+        out, h, w, sy, sx, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2])
+    if (fmt == D2S_FMT_U8_HWC) LAUNCH_PRE(D2S_FMT_U8_HWC);
+    else if (fmt == D2S_FMT_U8_CHW) LAUNCH_PRE(D2S_FMT_U8_CHW);
+    else if (fmt == D2S_FMT_F32_CHW) LAUNCH_PRE(D2S_FMT_F32_CHW);
+    else { set_error("d2s_preprocess: unsupported frame format"); return D2S_E_UNSUPPORTED; }
+#undef LAUNCH_PRE
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+extern "C" int d2s_upsample_depth(const float* in, int batch, int h, int w, float* out, int H, int W, void* stream) {
+    D2S_REQUIRE(in && out && batch > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bad argument");
+    long total = (long)batch * H * W;
+    hipLaunchKernelGGL(upsample_depth_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       in, batch, h, w, out, H, W, linear_scale(h, H, false), linear_scale(w, W, false));
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+static int make_geom(int H, int W, int dh, int dw, const d2s_sbs_params* p, WarpGeom& g) {
+    if (!p) return D2S_E_INVALID;
+    if (p->display_mode < 0 || p->display_mode > 3) return D2S_E_INVALID;
+    g.H = H; g.W = W; g.dh = dh; g.dw = dw;
+    g.dsy = linear_scale(dh, H, false); g.dsx = linear_scale(dw, W, false);
+    g.Hp = H; g.Wp = W; g.pad_top = 0; g.pad_left = 0;
+    if (p->fill_16_9) {                                          // pad_to_aspect_tensor, depth.py:2106-2119
+        double r_img = (double)W / (double)H, r_t = 16.0 / 9.0;
+        if (!(fabs(r_img - r_t) < 1e-3)) {
+            if (r_img > r_t) { int nh = (int)nearbyint((double)W / r_t); g.pad_top = (nh - H) / 2; g.Hp = nh; }
+            else             { int nw = (int)nearbyint((double)H * r_t); g.pad_left = (nw - W) / 2; g.Wp = nw; }
+        }
+    }
+    g.mode = p->display_mode;
+    bool tab = (g.mode == D2S_MODE_HALF_TAB || g.mode == D2S_MODE_FULL_TAB);
+    bool full = (g.mode == D2S_MODE_FULL_SBS || g.mode == D2S_MODE_FULL_TAB);
+    g.out_h = full && tab ? 2 * g.Hp : g.Hp;
+    g.out_w = full && !tab ? 2 * g.Wp : g.Wp;
+    g.conv = p->convergence; g.ratio = p->depth_ratio;
+    g.max_px = (float)(p->ipd_uv * (double)W);                   // python double product, cast at the multiply
+    return D2S_OK;
+}
+
+extern "C" int d2s_sbs_shape(int H, int W, const d2s_sbs_params* p, int* out_h, int* out_w) {
+    WarpGeom g;
+    D2S_REQUIRE(H > 0 && W > 0 && out_h && out_w, "bad argument");
+    if (make_geom(H, W, H, W, p, g) != D2S_OK) { set_error("d2s_sbs_shape: bad params"); return D2S_E_INVALID; }
+    *out_h = g.out_h; *out_w = g.out_w;
+    return D2S_OK;
+}
+
+template <int IN_FMT>
+static void launch_generic(const void* rgb, const float* depth, void* out, int out_fmt, int batch,
+                           const WarpGeom& g, hipStream_t st) {
+    long total = (long)batch * g.out_h * g.out_w;
+    dim3 grid(cdiv(total, 256)), block(256);
+    if (out_fmt == D2S_FMT_U8_HWC)
+        hipLaunchKernelGGL((stereo_warp_generic<IN_FMT, D2S_FMT_U8_HWC>), grid, block, 0, st, rgb, depth, out, batch, g);
+    else if (out_fmt == D2S_FMT_F32_HWC)
+        hipLaunchKernelGGL((stereo_warp_generic<IN_FMT, D2S_FMT_F32_HWC>), grid, block, 0, st, rgb, depth, out, batch, g);
+    else
+        hipLaunchKernelGGL((stereo_warp_generic<IN_FMT, D2S_FMT_F32_CHW>), grid, block, 0, st, rgb, depth, out, batch, g);
+}
+
+// `force_generic` (env D2S_WARP_GENERIC=1) lets tests compare the two paths.
+extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, int dh, int dw, int batch, int H, int W,
+                            const d2s_sbs_params* p, void* out, int out_fmt, void* stream) {
+    D2S_REQUIRE(rgb && depth && out && p, "null pointer");
+    D2S_REQUIRE(batch > 0 && H > 0 && W > 0 && dh > 0 && dw > 0, "bad shape");
+    D2S_REQUIRE(out_fmt == D2S_FMT_U8_HWC || out_fmt == D2S_FMT_F32_HWC || out_fmt == D2S_FMT_F32_CHW, "bad out_fmt");
+    WarpGeom g;
+    if (make_geom(H, W, dh, dw, p, g) != D2S_OK) { set_error("d2s_make_sbs: bad display_mode"); return D2S_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    static const bool force_generic = getenv("D2S_WARP_GENERIC") && atoi(getenv("D2S_WARP_GENERIC")) != 0;
+    bool nopad = (g.Hp == H && g.Wp == W);
+    bool fast_ok = !force_generic && rgb_fmt == D2S_FMT_U8_HWC && out_fmt == D2S_FMT_U8_HWC && nopad &&
+                   (W % 4 == 0) && dw <= W && dh <= H && ((uintptr_t)rgb % 4 == 0) && ((uintptr_t)out % 4 == 0) &&
+                   ((long)H * W * 3 % 4 == 0);
+    if (fast_ok && g.mode == D2S_MODE_HALF_TAB && (H % 2 != 0)) fast_ok = false;
+    if (fast_ok) {
+        int tiles_x = cdiv(W, FP_TW);
+        if (g.mode == D2S_MODE_HALF_TAB) {
+            dim3 grid((unsigned)((long)tiles_x * (H / 2) * batch));
+            hipLaunchKernelGGL(stereo_warp_fast_halftab, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+        } else {
+            dim3 grid((unsigned)((long)tiles_x * H * batch));
+            if (g.mode == D2S_MODE_FULL_SBS)
+                hipLaunchKernelGGL(stereo_warp_fast<D2S_MODE_FULL_SBS>, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+            else if (g.mode == D2S_MODE_FULL_TAB)
+                hipLaunchKernelGGL(stereo_warp_fast<D2S_MODE_FULL_TAB>, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+            else
+                hipLaunchKernelGGL(stereo_warp_fast<D2S_MODE_HALF_SBS>, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+        }
+    } else {
+        if (rgb_fmt == D2S_FMT_U8_HWC) launch_generic<D2S_FMT_U8_HWC>(rgb, depth, out, out_fmt, batch, g, st);
+        else if (rgb_fmt == D2S_FMT_U8_CHW) launch_generic<D2S_FMT_U8_CHW>(rgb, depth, out, out_fmt, batch, g, st);
+        else if (rgb_fmt == D2S_FMT_F32_CHW) launch_generic<D2S_FMT_F32_CHW>(rgb, depth, out, out_fmt, batch, g, st);
+        else { set_error("d2s_make_sbs: unsupported rgb_fmt"); return D2S_E_UNSUPPORTED; }
+    }
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}

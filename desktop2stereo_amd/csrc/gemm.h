@@ -1,0 +1,51 @@
+// MFMA GEMM with implicit-conv A loader and fused epilogues (gemm.hip).
+//   C[m, n] = epilogue( sum_k A[m, k] * W[n, k] )          W packed [Npad][Kpad], K contiguous
+#pragma once
+#include "common.h"
+
+namespace d2s {
+
+enum { A_PLAIN = 0, A_CONV3 = 1 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+enum { MAP_ROWS = 0, MAP_SHUFFLE = 1, MAP_QKV = 2 };
+enum { OUT_T = 0, OUT_F32 = 1 };
+
+struct GemmA {
+    const void* ptr;      // T*
+    int mode;             // A_PLAIN / A_CONV3
+    long lda;             // A_PLAIN: row stride (elements)
+    int Hi, Wi, C;        // A_CONV3: input NHWC [B,Hi,Wi,C], 3x3, pad 1
+    int Ho, Wo, stride;   //          output grid, conv stride
+    int relu;             // max(x,0) on load (pre-activation)
+};
+
+struct GemmEpi {
+    void* out;
+    int out_type;         // OUT_T: same type as the operands; OUT_F32
+    long ldc;             // MAP_ROWS: row stride of out (elements)
+    const float* bias;    // [N] or null
+    const float* scale;   // [N] LayerScale or null: v = scale * (acc + bias)
+    int act;
+    const void* res1;     // residual(s), type = out type, added after scale/act
+    const void* res2;
+    // row mapping (MAP_ROWS): out_row = (m / rows_per_img) * img_rows + (m % rows_per_img) + row_off
+    int rows_per_img, img_rows, row_off;   // rows_per_img == 0 -> out_row = m
+    int res1_mod, res1_off;                // res1 row = res1_mod ? (m % res1_mod) + res1_off : out_row; ld = ldc
+    // MAP_SHUFFLE (ConvTranspose k == s): m -> (b, y, x) over [B, gh, gw]; n -> (ky, kx, co)
+    int map, gh, gw, ks, cout;
+    // MAP_QKV: row-major [M, 3D] for q | k; the v third goes TRANSPOSED to vt[B, heads, 64, npad]
+    // (m = b*ntok + t, n - 2D = h*64 + d) so the attention kernel reads V^T rows with 16-byte chunks.
+    void* vt; int ntok, npad, qk_cols, heads;
+};
+
+// precision: D2S_PREC_FP32 (T = float) / D2S_PREC_BF16 (T = bf16).  tile: 0 = auto, 64, 128.
+int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad,
+                const GemmEpi& e, hipStream_t st);
+
+// packed-weight geometry
+static inline int gemm_bk(int precision) { return precision == D2S_PREC_BF16 ? 64 : 32; }   // 128-byte K tile
+static inline int gemm_kpad(int K, int precision) { int bk = gemm_bk(precision); return (K + bk - 1) / bk * bk; }
+static inline int gemm_npad(int N) { return (N + 127) / 128 * 128; }
+static inline size_t elem_size(int precision) { return precision == D2S_PREC_BF16 ? 2 : 4; }
+
+}  // namespace d2s

@@ -1,0 +1,279 @@
+// MFMA GEMM for gfx950: C[m,n] = epi(sum_k A[m,k] W[n,k]).
+//
+//  * operands bf16 (v_mfma_f32_16x16x32_bf16) or f32 (v_mfma_f32_16x16x4_f32, exact fp32), fp32 accumulate;
+//  * tile BM x BN x 128 bytes of K, 256 threads = 4 waves (2 x 2), wave tile (BM/2) x (BN/2);
+//  * both operands are K-contiguous; a 16-byte chunk per lane is the unit everywhere:
+//      global -> registers (16 B/lane, 8 lanes cover one 128-B row = full cache lines)
+//      registers -> LDS with the chunk XOR-swizzle  phys = chunk ^ ((row >> 1) & 7)
+//      LDS -> fragments with ds_read_b128 at (row = lane & 15, chunk = kstep*4 + (lane >> 4)),
+//    conflict-free for 128-byte rows.  One chunk feeds one bf16 MFMA (K=32 across the 4 lane groups)
+//    or four f32 MFMAs (the k permutation is the same for both operands, so the sum is unchanged);
+//  * operands are swapped (first = W rows, second = A rows) so each lane ends up with 4 consecutive
+//    n for one m: bias / LayerScale / residual / output move as 8- or 16-byte vectors;
+//  * the A loader is either a plain row-major matrix or an implicit 3x3 (pad 1, stride 1|2)
+//    convolution over an NHWC activation, with optional ReLU-on-load (pre-activation units);
+//  * double-buffered LDS, register-staged prefetch of the next K tile, one barrier per tile.
+#include "gemm.h"
+
+namespace d2s {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename T> struct Prec;
+template <> struct Prec<bf16_t> { static constexpr int CE = 8; };   // elements per 16-byte chunk
+template <> struct Prec<float>  { static constexpr int CE = 4; };
+
+__device__ __forceinline__ uint4 relu_chunk(uint4 v, bf16_t) {
+    uint32_t* p = (uint32_t*)&v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { uint32_t m = ((p[i] >> 15) & 0x00010001u) * 0xffffu; p[i] &= ~m; }
+    return v;
+}
+__device__ __forceinline__ uint4 relu_chunk(uint4 v, float) {
+    float* p = (float*)&v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = fmaxf(p[i], 0.f);
+    return v;
+}
+
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& w, const uint4& a, bf16_t) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w, *(const bf16x8*)&a, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& w, const uint4& a, float) {
+    const float* wf = (const float*)&w;
+    const float* af = (const float*)&a;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], af[t], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ void load4(const float* p, float v[4]) { float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+__device__ __forceinline__ void load4(const bf16_t* p, float v[4]) {
+    uint2 t = *(const uint2*)p;
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ void store4(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
+    uint2 t;
+    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *(uint2*)p = t;
+}
+
+template <typename OT> __device__ __forceinline__ OT cvt_out(float v);
+template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float v) { return f2bf(v); }
+
+template <typename OT>
+__device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float v[4]) {
+    if (e.bias) { float b[4]; load4(e.bias + n0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+    if (e.act == ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+    else if (e.act == ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    if (e.scale) { float s[4]; load4(e.scale + n0, s); v[0] *= s[0]; v[1] *= s[1]; v[2] *= s[2]; v[3] *= s[3]; }
+    long off;
+    if (e.map == MAP_QKV && n0 >= e.qk_cols) {
+        int b = m / e.ntok, t = m - b * e.ntok;
+        int c = n0 - e.qk_cols;                       // h*64 + d, 4 consecutive d
+        OT* p = (OT*)e.vt + ((long)b * e.heads * 64 + c) * e.npad + t;
+        p[0] = cvt_out<OT>(v[0]); p[e.npad] = cvt_out<OT>(v[1]); p[2L * e.npad] = cvt_out<OT>(v[2]); p[3L * e.npad] = cvt_out<OT>(v[3]);
+        return;
+    }
+    if (e.map == MAP_SHUFFLE) {
+        int x = m % e.gw, y = (m / e.gw) % e.gh, b = m / (e.gw * e.gh);
+        int tap = n0 / e.cout, co = n0 - tap * e.cout;
+        int ky = tap / e.ks, kx = tap - ky * e.ks;
+        off = (((long)b * e.gh * e.ks + (long)y * e.ks + ky) * ((long)e.gw * e.ks) + (long)x * e.ks + kx) * e.cout + co;
+    } else {
+        long row = m;
+        if (e.rows_per_img) row = (long)(m / e.rows_per_img) * e.img_rows + (m % e.rows_per_img) + e.row_off;
+        off = row * e.ldc + n0;
+    }
+    if (e.res1) {
+        long roff = e.res1_mod ? ((long)(m % e.res1_mod) + e.res1_off) * e.ldc + n0 : off;
+        float r[4]; load4((const OT*)e.res1 + roff, r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+    }
+    if (e.res2) { float r[4]; load4((const OT*)e.res2 + off, r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+    store4((OT*)e.out + off, v);
+}
+
+template <typename T, int BM, int BN>
+__global__ void __launch_bounds__(256)
+gemm_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e) {
+    constexpr int CE = Prec<T>::CE;
+    constexpr int BK = 8 * CE;                 // 128-byte K tile
+    constexpr int AI = BM / 32, BI = BN / 32;  // chunks per thread per tile
+    constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave
+    __shared__ __attribute__((aligned(16))) uint4 lds[2][(BM + BN) * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wave_m = wid >> 1, wave_n = wid & 1;
+    const int tiles_n = (N + BN - 1) / BN;
+    const int bm0 = (blockIdx.x / tiles_n) * BM, bn0 = (blockIdx.x % tiles_n) * BN;
+    const int lrow = tid >> 3, lchunk = tid & 7;
+
+    // ---- per-thread A row descriptors (fixed across K tiles)
+    const T* arow[AI];
+    int aiy[AI], aix[AI];
+    bool aok[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        int m = bm0 + lrow + 32 * i;
+        aok[i] = m < M;
+        int mm = aok[i] ? m : 0;
+        if (a.mode == A_PLAIN) { arow[i] = (const T*)a.ptr + (long)mm * a.lda; aiy[i] = aix[i] = 0; }
+        else {
+            int ox = mm % a.Wo, oy = (mm / a.Wo) % a.Ho, b = mm / (a.Wo * a.Ho);
+            aiy[i] = oy * a.stride - 1; aix[i] = ox * a.stride - 1;
+            arow[i] = (const T*)a.ptr + (long)b * a.Hi * a.Wi * a.C;
+        }
+    }
+    const T* wrow = W + (long)(bn0 + lrow) * Kpad + lchunk * CE;
+
+    uint4 ra[AI], rb[BI];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + lchunk * CE;
+        if (a.mode == A_PLAIN) {
+#pragma unroll
+            for (int i = 0; i < AI; ++i)
+                ra[i] = (aok[i] && k < K) ? *(const uint4*)(arow[i] + k) : make_uint4(0, 0, 0, 0);
+        } else {
+            int tap = k / a.C, c0 = k - tap * a.C;
+            int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                int iy = aiy[i] + ky, ix = aix[i] + kx;
+                bool ok = aok[i] && k < K && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+                ra[i] = ok ? *(const uint4*)(arow[i] + ((long)iy * a.Wi + ix) * a.C + c0) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int i = 0; i < AI; ++i) ra[i] = relu_chunk(ra[i], T());
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) rb[i] = *(const uint4*)(wrow + (long)(32 * i) * Kpad + kt * BK);
+    };
+    auto store_tile = [&](int buf) {
+        uint4* A_l = lds[buf];
+        uint4* B_l = lds[buf] + BM * 8;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) { int r = lrow + 32 * i; A_l[r * 8 + (lchunk ^ ((r >> 1) & 7))] = ra[i]; }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) { int r = lrow + 32 * i; B_l[r * 8 + (lchunk ^ ((r >> 1) & 7))] = rb[i]; }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = Kpad / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const uint4* A_l = lds[kt & 1] + (wave_m * (BM / 2)) * 8;
+        const uint4* B_l = lds[kt & 1] + BM * 8 + (wave_n * (BN / 2)) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 fa[FM], fb[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) { int r = i * 16 + fr; fa[i] = A_l[r * 8 + ((ks * 4 + fg) ^ ((r >> 1) & 7))]; }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) { int r = j * 16 + fr; fb[j] = B_l[r * 8 + ((ks * 4 + fg) ^ ((r >> 1) & 7))]; }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma_chunk(acc[i][j], fb[j], fa[i], T());
+        }
+        if (kt + 1 < nkt) store_tile((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds n = n0..n0+3 for m
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        int m = bm0 + wave_m * (BM / 2) + i * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            int n0 = bn0 + wave_n * (BN / 2) + j * 16 + fg * 4;
+            if (n0 >= N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v);
+            else epilogue4<T>(e, m, n0, v);
+        }
+    }
+}
+
+template <typename T>
+static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
+    if (tile == 0) tile = ((long)cdiv(M, 128) * cdiv(N, 128) >= 192) ? 128 : 64;
+    if (tile == 128) {
+        dim3 grid((unsigned)((long)cdiv(M, 128) * cdiv(N, 128)));
+        hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e);
+    } else if (tile == 64) {
+        dim3 grid((unsigned)((long)cdiv(M, 64) * cdiv(N, 64)));
+        hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), grid, dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e);
+    } else { set_error("launch_gemm: tile must be 0, 64 or 128"); return D2S_E_INVALID; }
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad,
+                const GemmEpi& e, hipStream_t st) {
+    const int ce = precision == D2S_PREC_BF16 ? 8 : 4;
+    if (M <= 0 || N <= 0 || K <= 0 || (N & 3) || (K % ce) || Kpad % gemm_bk(precision)) {
+        set_error("launch_gemm: bad dims (N % 4, K % chunk, Kpad % BK)"); return D2S_E_INVALID;
+    }
+    if (a.mode == A_PLAIN && (a.lda % ce)) { set_error("launch_gemm: lda not chunk aligned"); return D2S_E_INVALID; }
+    if (a.mode == A_CONV3 && (a.C % ce)) { set_error("launch_gemm: conv channels not chunk aligned"); return D2S_E_INVALID; }
+    if (precision == D2S_PREC_BF16) return launch_t<bf16_t>(tile, a, W, M, N, K, Kpad, e, st);
+    return launch_t<float>(tile, a, W, M, N, K, Kpad, e, st);
+}
+
+// ---- test / micro-benchmark probe -----------------------------------------------------------------
+__global__ void cast_pad_kernel(const float* __restrict__ src, void* __restrict__ dst, int rows, int cols,
+                                int rows_pad, int cols_pad, int bf16) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)rows_pad * cols_pad) return;
+    int c = (int)(idx % cols_pad), r = (int)(idx / cols_pad);
+    float v = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+    if (bf16) ((bf16_t*)dst)[idx] = f2bf(v); else ((float*)dst)[idx] = v;
+}
+
+}  // namespace d2s
+
+using namespace d2s;
+
+extern "C" int d2s_gemm_probe(const float* A, const float* Wt, const float* bias, float* Cout, int M, int N, int K,
+                              int precision, int tile, int iters, void* stream) {
+    D2S_REQUIRE(A && Wt && Cout && M > 0 && N > 0 && K > 0 && (N % 4 == 0) && iters >= 1, "bad argument");
+    D2S_REQUIRE(precision == D2S_PREC_BF16 || precision == D2S_PREC_FP32, "bad precision");
+    hipStream_t st = (hipStream_t)stream;
+    int bf = precision == D2S_PREC_BF16;
+    int Kp = gemm_kpad(K, precision), Np = gemm_npad(N);
+    size_t es = elem_size(precision);
+    void *dA = nullptr, *dW = nullptr;
+    D2S_HIP(hipMalloc(&dA, (size_t)M * Kp * es));
+    D2S_HIP(hipMalloc(&dW, (size_t)Np * Kp * es));
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(cdiv((long)M * Kp, 256)), dim3(256), 0, st, A, dA, M, K, M, Kp, bf);
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(cdiv((long)Np * Kp, 256)), dim3(256), 0, st, Wt, dW, N, K, Np, Kp, bf);
+    GemmA a = {};
+    a.ptr = dA; a.mode = A_PLAIN; a.lda = Kp;
+    GemmEpi e = {};
+    e.out = Cout; e.out_type = OUT_F32; e.ldc = N; e.bias = bias;
+    int rc = D2S_OK;
+    for (int i = 0; i < iters && rc == D2S_OK; ++i) rc = launch_gemm(precision, tile, a, dW, M, N, Kp, Kp, e, st);
+    hipError_t err = hipStreamSynchronize(st);
+    (void)hipFree(dA); (void)hipFree(dW);
+    if (rc != D2S_OK) return rc;
+    D2S_HIP(err);
+    return D2S_OK;
+}

@@ -1,0 +1,187 @@
+// Depth post-process at model resolution (latency-bound, tiny):
+//   A10  normalize (subsample + order statistic, no lerp) -> gamma -> foreground scale
+//        reference depth.py:816-867, 784-794, 775-776, 709-736
+//   A11  anti_alias: separable Gaussian, zero padding, H then V     reference depth.py:740-765
+//   A12  DepthStabilizer (EMA)                                      reference depth.py:1865-1887
+#include "common.h"
+#include <math.h>
+
+namespace d2s {
+
+constexpr int SORT_N = 8192;       // >= subsample_cap (6144), power of two
+constexpr int SORT_THREADS = 1024;
+
+__device__ __forceinline__ uint32_t f2key(float f) {          // order-preserving float -> uint
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// One block per frame: v = depth.flatten()[::step] (m <= cap values), bitonic sort in LDS,
+// bounds[b] = { s[tail-1], s[m-tail] }  (the tail-th smallest / largest).
+__global__ void __launch_bounds__(SORT_THREADS)
+percentile_bounds_kernel(const float* __restrict__ depth, int n, int step, int m, int tail,
+                         float* __restrict__ bounds) {
+    __shared__ uint32_t keys[SORT_N];
+    const float* d = depth + (long)blockIdx.x * n;
+    for (int i = threadIdx.x; i < SORT_N; i += SORT_THREADS)
+        keys[i] = i < m ? f2key(d[(long)i * step]) : 0xffffffffu;
+    __syncthreads();
+    for (int k = 2; k <= SORT_N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < SORT_N / 2; t += SORT_THREADS) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j cleared
+                int l = i | j;
+                bool up = ((i & k) == 0);
+                uint32_t a = keys[i], b = keys[l];
+                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        float lo, hi;
+        if (n <= 10) { lo = 0.f; hi = 0.f; }                                     // depth.py:852-854
+        else if (tail >= m) { lo = key2f(keys[0]); hi = key2f(keys[m - 1]); }    // depth.py:790-791
+        else { lo = key2f(keys[tail - 1]); hi = key2f(keys[m - tail]); }
+        bounds[2 * blockIdx.x] = lo;
+        bounds[2 * blockIdx.x + 1] = hi;
+    }
+}
+
+__device__ __forceinline__ float shape_depth(float d, float dmin, float dmax, float gamma, float fg_exp, bool fg_on) {
+    float denom = fmaxf(dmax - dmin, 1e-6f);                                      // depth.py:865
+    float nrm = fminf(fmaxf((d - dmin) / denom, 0.f), 1.f);
+    float g = powf(nrm, gamma);                                                   // depth.py:775-776
+    g = fminf(fmaxf(g, 0.f), 1.f);                                                // depth.py:729
+    if (!fg_on) return g;
+    float dist = g - 0.5f;
+    float sgn = dist > 0.f ? 1.f : (dist < 0.f ? -1.f : 0.f);
+    float o = 0.5f + sgn * powf(fabsf(dist), fg_exp);                             // depth.py:733-735
+    return fminf(fmaxf(o, 0.f), 1.f);
+}
+
+constexpr int MAX_TAPS = 63;
+struct GaussTaps { int k; float w[MAX_TAPS]; };
+
+// normalise + gamma + foreground-scale fused with the horizontal Gaussian pass: one block per row,
+// shaped row staged in LDS (zero padded), k taps out of LDS.
+__global__ void __launch_bounds__(256)
+shape_hblur_kernel(const float* __restrict__ depth, const float* __restrict__ bounds, float* __restrict__ tmp,
+                   int h, int w, float gamma, float fg_exp, int fg_on, GaussTaps taps) {
+    extern __shared__ float row[];                       // w + 2r
+    int y = blockIdx.x % h, b = blockIdx.x / h;
+    int r = taps.k / 2;
+    float dmin = bounds[2 * b], dmax = bounds[2 * b + 1];
+    const float* src = depth + ((long)b * h + y) * w;
+    for (int i = threadIdx.x; i < w + 2 * r; i += 256) {
+        int x = i - r;
+        row[i] = (x >= 0 && x < w) ? shape_depth(src[x], dmin, dmax, gamma, fg_exp, fg_on != 0) : 0.f;
+    }
+    __syncthreads();
+    float* dst = tmp + ((long)b * h + y) * w;
+    for (int x = threadIdx.x; x < w; x += 256) {
+        float acc = 0.f;
+        if (taps.k >= 3) { for (int t = 0; t < taps.k; ++t) acc += taps.w[t] * row[x + t]; }
+        else acc = row[x + r];
+        dst[x] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+vblur_kernel(const float* __restrict__ tmp, float* __restrict__ out, int B, int h, int w, GaussTaps taps) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * h * w) return;
+    int x = (int)(idx % w);
+    int y = (int)((idx / w) % h);
+    int b = (int)(idx / ((long)w * h));
+    const float* p = tmp + (long)b * h * w + x;
+    int r = taps.k / 2;
+    float acc = 0.f;
+    for (int t = 0; t < taps.k; ++t) {
+        int yy = y + t - r;
+        if (yy >= 0 && yy < h) acc += taps.w[t] * p[(long)yy * w];
+    }
+    out[idx] = acc;
+}
+
+// EMA over `nframes` consecutive frames (recurrence in frame order); thread per pixel.
+__global__ void __launch_bounds__(256)
+ema_kernel(float* __restrict__ depth, float* __restrict__ state, int initialised, int nframes, int hw, float wgt) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hw) return;
+    float prev = initialised ? state[i] : 0.f;
+    for (int f = 0; f < nframes; ++f) {
+        float d = depth[(long)f * hw + i];
+        if (!initialised && f == 0) prev = d;
+        else prev = prev + wgt * (d - prev);                 // torch lerp_, weight < 0.5
+        depth[(long)f * hw + i] = prev;
+    }
+    state[i] = prev;
+}
+
+}  // namespace d2s
+
+using namespace d2s;
+
+extern "C" uint64_t d2s_post_process_workspace(int batch, int h, int w) {
+    return (uint64_t)batch * h * w * sizeof(float) + (uint64_t)batch * 2 * sizeof(float) + 256;
+}
+
+extern "C" int d2s_post_process(float* depth, int batch, int h, int w, const d2s_post_params* p,
+                                void* workspace, uint64_t workspace_bytes, void* stream) {
+    D2S_REQUIRE(depth && p && workspace, "null pointer");
+    D2S_REQUIRE(batch > 0 && h > 0 && w > 0, "bad shape");
+    D2S_REQUIRE(workspace_bytes >= d2s_post_process_workspace(batch, h, w), "workspace too small");
+    D2S_REQUIRE(p->subsample_cap > 0 && p->subsample_cap <= SORT_N, "subsample_cap must be <= 8192");
+    D2S_REQUIRE(p->foreground_scale > -1.0f + 1e-12f, "scale must be greater than -1.0");   // depth.py:726-727
+    hipStream_t st = (hipStream_t)stream;
+    float* tmp = (float*)workspace;
+    float* bounds = (float*)((char*)workspace + (((uint64_t)batch * h * w * sizeof(float) + 255) & ~255ull));
+    int n = h * w;
+    int step = 1, m = n;
+    if (n > p->subsample_cap) { step = (n + p->subsample_cap - 1) / p->subsample_cap; m = (n + step - 1) / step; }
+    double lo_q = fmax(0.0, fmin(1.0, (double)p->percentile / 100.0));
+    int tail = (int)nearbyint(lo_q * (m - 1)) + 1;
+    if (tail < 1) tail = 1;
+    if (tail > m) tail = m;
+    hipLaunchKernelGGL(percentile_bounds_kernel, dim3(batch), dim3(SORT_THREADS), 0, st, depth, n, step, m, tail, bounds);
+    // Gaussian taps: k = int(3 s) | 1, sigma = 0.5 s, float32 like the reference (depth.py:746-758)
+    GaussTaps taps;
+    int k = ((int)(3.0f * p->aa_strength)) | 1;
+    D2S_REQUIRE(k <= MAX_TAPS, "aa_strength too large");
+    taps.k = k >= 3 ? k : 1;
+    if (k >= 3) {
+        float sigma = 0.5f * p->aa_strength, sum = 0.f;
+        for (int i = 0; i < k; ++i) { float c = (float)(i - k / 2); taps.w[i] = expf(-(c * c) / (2.f * sigma * sigma)); sum += taps.w[i]; }
+        for (int i = 0; i < k; ++i) taps.w[i] /= sum;
+    } else taps.w[0] = 1.f;
+    int fg_on = fabsf(p->foreground_scale) >= 1e-6f;
+    float fg_exp = 1.0f / (1.0f + p->foreground_scale);
+    int r = taps.k / 2;
+    hipLaunchKernelGGL(shape_hblur_kernel, dim3(batch * h), dim3(256), (w + 2 * r) * sizeof(float), st,
+                       depth, bounds, tmp, h, w, p->gamma, fg_exp, fg_on, taps);
+    hipLaunchKernelGGL(vblur_kernel, dim3(cdiv((long)batch * h * w, 256)), dim3(256), 0, st, tmp, depth, batch, h, w, taps);
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+extern "C" int d2s_ema_update(float* depth, float* state, int initialised, int h, int w, float alpha, void* stream) {
+    D2S_REQUIRE(depth && state && h > 0 && w > 0, "bad argument");
+    hipLaunchKernelGGL(ema_kernel, dim3(cdiv((long)h * w, 256)), dim3(256), 0, (hipStream_t)stream,
+                       depth, state, initialised, 1, h * w, 1.0f - alpha);
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+namespace d2s {
+// engine-internal: EMA over a batch of frames in order
+int ema_batch(float* depth, float* state, int initialised, int nframes, int hw, float alpha, hipStream_t st) {
+    hipLaunchKernelGGL(ema_kernel, dim3(cdiv(hw, 256)), dim3(256), 0, st, depth, state, initialised, nframes, hw, 1.0f - alpha);
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+}  // namespace d2s

@@ -1,0 +1,189 @@
+// Small model-side kernels around the GEMMs (HBM / L2 bound):
+//   patchify        Conv2d(3->D, k=s=14) as im2col rows            (HF Dinov2PatchEmbeddings)
+//   cls_rows        cls token + pos[0] rows of the residual stream  (HF Dinov2Embeddings.forward)
+//   layernorm       fp32 residual -> T, eps 1e-6, optional cls drop (HF Dinov2Layer norm1/norm2, Dinov2Backbone.layernorm)
+//   bilinear_nhwc   align_corners=True up-sample of NHWC maps       (HF DepthAnythingFeatureFusionLayer / head)
+//   head_final      conv3 (1x1, C->1) + ReLU                        (HF DepthAnythingDepthEstimationHead)
+#include "vit_ops.h"
+
+namespace d2s {
+
+template <typename T> __device__ __forceinline__ T cvt(float v);
+template <> __device__ __forceinline__ float cvt<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t cvt<bf16_t>(float v) { return f2bf(v); }
+__device__ __forceinline__ float tof(float v) { return v; }
+__device__ __forceinline__ float tof(bf16_t v) { return bf2f(v); }
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+patchify_kernel(const float* __restrict__ x, T* __restrict__ A, int B, int h, int w, int p, int Kp) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int gh = h / p, gw = w / p, P = gh * gw;
+    long total = (long)B * P * Kp;
+    if (idx >= total) return;
+    int k = (int)(idx % Kp);
+    int row = (int)(idx / Kp);
+    int b = row / P, pi = row % P;
+    int py = pi / gw, px = pi % gw;
+    float v = 0.f;
+    if (k < 3 * p * p) {
+        int c = k / (p * p), i = (k % (p * p)) / p, j = k % p;
+        v = x[(((long)b * 3 + c) * h + py * p + i) * w + px * p + j];
+    }
+    A[idx] = cvt<T>(v);
+}
+
+__global__ void __launch_bounds__(256)
+cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ resid,
+                int B, int N, int D) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * D) return;
+    int b = idx / D, d = idx % D;
+    resid[(long)b * N * D + d] = cls[d] + pos[d];
+}
+
+// one wave per row; D <= 1024 (4 float4 per lane)
+template <typename T>
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta,
+                 T* __restrict__ out, int rows_out, int D, float eps, int rows_per_img, int img_rows, int row_off) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= rows_out) return;
+    long in_row = rows_per_img ? (long)(row / rows_per_img) * img_rows + (row % rows_per_img) + row_off : row;
+    const float4* xr = (const float4*)(x + in_row * D);
+    int nv = D >> 2;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = lane + 64 * i;
+        if (c < nv) { v[i] = xr[c]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+        else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    float mu = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = lane + 64 * i;
+        if (c < nv) { float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu; q += (a * a + b * b) + (cc * cc + d * d); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    float rstd = 1.0f / sqrtf(q / (float)D + eps);
+    T* orow = out + (long)row * D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = lane + 64 * i;
+        if (c < nv) {
+            float4 gg = ((const float4*)g)[c], bb = ((const float4*)bta)[c];
+            float r[4] = {(v[i].x - mu) * rstd * gg.x + bb.x, (v[i].y - mu) * rstd * gg.y + bb.y,
+                          (v[i].z - mu) * rstd * gg.z + bb.z, (v[i].w - mu) * rstd * gg.w + bb.w};
+            T* o = orow + 4 * c;
+            o[0] = cvt<T>(r[0]); o[1] = cvt<T>(r[1]); o[2] = cvt<T>(r[2]); o[3] = cvt<T>(r[3]);
+        }
+    }
+}
+
+// thread per (output pixel, 4 channels)
+template <typename T>
+__global__ void __launch_bounds__(256)
+bilinear_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                     float sy, float sx) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int c4 = C >> 2;
+    long total = (long)B * Ho * Wo * c4;
+    if (idx >= total) return;
+    int c = (int)(idx % c4) * 4;
+    long pix = idx / c4;
+    int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+    Tap ty = linear_tap(oy, sy, Hi, true), tx = linear_tap(ox, sx, Wi, true);
+    const T* base = in + (long)b * Hi * Wi * C + c;
+    const T* p00 = base + ((long)ty.i0 * Wi + tx.i0) * C;
+    const T* p01 = base + ((long)ty.i0 * Wi + tx.i1) * C;
+    const T* p10 = base + ((long)ty.i1 * Wi + tx.i0) * C;
+    const T* p11 = base + ((long)ty.i1 * Wi + tx.i1) * C;
+    T* o = out + pix * C + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float top = tx.w0 * tof(p00[k]) + tx.w1 * tof(p01[k]);
+        float bot = tx.w0 * tof(p10[k]) + tx.w1 * tof(p11[k]);
+        o[k] = cvt<T>(ty.w0 * top + ty.w1 * bot);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+head_final_kernel(const T* __restrict__ x, const float* __restrict__ w3, float b3, float* __restrict__ depth,
+                  long npix, int C) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix) return;
+    const T* p = x + idx * C;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc += tof(p[c]) * w3[c];
+    depth[idx] = fmaxf(acc + b3, 0.f);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, long n) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = tof(in[idx]);
+}
+
+#define DISPATCH_T(prec, CALL_BF, CALL_F32) do { if ((prec) == D2S_PREC_BF16) { CALL_BF; } else { CALL_F32; } } while (0)
+
+int launch_patchify(int prec, const float* x, void* A, int B, int h, int w, int p, int Kp, hipStream_t st) {
+    long total = (long)B * (h / p) * (w / p) * Kp;
+    dim3 grid(cdiv(total, 256)), block(256);
+    DISPATCH_T(prec, hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, block, 0, st, x, (bf16_t*)A, B, h, w, p, Kp),
+                     hipLaunchKernelGGL(patchify_kernel<float>, grid, block, 0, st, x, (float*)A, B, h, w, p, Kp));
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+int launch_cls_rows(const float* cls, const float* pos, float* resid, int B, int N, int D, hipStream_t st) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(cdiv((long)B * D, 256)), dim3(256), 0, st, cls, pos, resid, B, N, D);
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+int launch_layernorm(int prec, const float* x, const float* g, const float* b, void* out, int rows_out, int D, float eps,
+                     int rows_per_img, int img_rows, int row_off, hipStream_t st) {
+    if (D > 1024 || (D & 3)) { set_error("layernorm: D must be a multiple of 4 and <= 1024"); return D2S_E_UNSUPPORTED; }
+    dim3 grid(cdiv(rows_out, 4)), block(256);
+    DISPATCH_T(prec, hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, st, x, g, b, (bf16_t*)out, rows_out, D, eps, rows_per_img, img_rows, row_off),
+                     hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, st, x, g, b, (float*)out, rows_out, D, eps, rows_per_img, img_rows, row_off));
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+int launch_bilinear_nhwc(int prec, const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t st) {
+    float sy = linear_scale(Hi, Ho, true), sx = linear_scale(Wi, Wo, true);
+    long total = (long)B * Ho * Wo * (C / 4);
+    dim3 grid(cdiv(total, 256)), block(256);
+    DISPATCH_T(prec, hipLaunchKernelGGL(bilinear_nhwc_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)in, (bf16_t*)out, B, Hi, Wi, Ho, Wo, C, sy, sx),
+                     hipLaunchKernelGGL(bilinear_nhwc_kernel<float>, grid, block, 0, st, (const float*)in, (float*)out, B, Hi, Wi, Ho, Wo, C, sy, sx));
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+int launch_head_final(int prec, const void* x, const float* w3, float b3, float* depth, long npix, int C, hipStream_t st) {
+    dim3 grid(cdiv(npix, 256)), block(256);
+    DISPATCH_T(prec, hipLaunchKernelGGL(head_final_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, w3, b3, depth, npix, C),
+                     hipLaunchKernelGGL(head_final_kernel<float>, grid, block, 0, st, (const float*)x, w3, b3, depth, npix, C));
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+int launch_to_f32(int prec, const void* in, float* out, long n, hipStream_t st) {
+    dim3 grid(cdiv(n, 256)), block(256);
+    DISPATCH_T(prec, hipLaunchKernelGGL(to_f32_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)in, out, n),
+                     hipLaunchKernelGGL(to_f32_kernel<float>, grid, block, 0, st, (const float*)in, out, n));
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+}  // namespace d2s

@@ -1,0 +1,231 @@
+"""Stage-level host wrappers over the C-ABI (include/d2s.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every computation
+is a call into libd2s_hip.so with ``tensor.data_ptr()`` (the same convention as the reference's
+MIGraphXEngine.__call__, reference depth.py:1029-1045).  Nothing in this module computes with
+torch ops, and nothing falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (FMT_F32_CHW, FMT_F32_HWC, FMT_U8_CHW, FMT_U8_HWC, MODE, PREC_BF16, PREC_FP32,
+                   ModelDesc, PostParams, SbsParams, check)
+from .config import IMAGENET_MEAN, IMAGENET_STD, ModelConfig, PipelineParams, engine_shape
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def _need_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _lib.D2SError(f"{what} must be a ROCm device tensor (no CPU path in this package)")
+
+
+def post_params(p: PipelineParams) -> PostParams:
+    return PostParams(p.percentile, p.subsample_cap, p.gamma, p.foreground_scale, p.aa_strength, p.ema_alpha)
+
+
+def sbs_params(ipd_uv=0.064, depth_ratio=2.0, convergence=0.0, display_mode="Half-SBS", fill_16_9=False) -> SbsParams:
+    if display_mode not in MODE:
+        raise ValueError(f"display_mode must be one of {list(MODE)}")
+    return SbsParams(float(ipd_uv), float(depth_ratio), float(convergence), MODE[display_mode], int(bool(fill_16_9)))
+
+
+def sbs_shape(H: int, W: int, sp: SbsParams) -> Tuple[int, int]:
+    oh, ow = C.c_int(), C.c_int()
+    check(_lib.load().d2s_sbs_shape(H, W, C.byref(sp), C.byref(oh), C.byref(ow)), "d2s_sbs_shape")
+    return oh.value, ow.value
+
+
+def _frame_fmt(t: torch.Tensor) -> Tuple[int, int, int, int]:
+    """(fmt, batch, H, W) of a frame tensor: u8 HWC / u8 CHW / f32 CHW, optional leading batch."""
+    if t.dtype == torch.uint8 and t.shape[-1] == 3 and t.dim() in (3, 4):
+        b = t.shape[0] if t.dim() == 4 else 1
+        return FMT_U8_HWC, b, t.shape[-3], t.shape[-2]
+    if t.shape[-3] == 3 and t.dim() in (3, 4):
+        b = t.shape[0] if t.dim() == 4 else 1
+        if t.dtype == torch.uint8:
+            return FMT_U8_CHW, b, t.shape[-2], t.shape[-1]
+        if t.dtype == torch.float32:
+            return FMT_F32_CHW, b, t.shape[-2], t.shape[-1]
+    raise ValueError(f"unsupported frame tensor {tuple(t.shape)} {t.dtype}: want uint8 [..,H,W,3], uint8/float32 [..,3,H,W]")
+
+
+def preprocess(frames: torch.Tensor, target: int, patch: int = 14, mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
+    """A2-A4 (reference depth.py:676-706, 1916-1948) -> float32 [B,3,h,w]."""
+    _need_cuda(frames, "frames")
+    frames = frames.contiguous()
+    fmt, B, H, W = _frame_fmt(frames)
+    h, w, stride = engine_shape(H, W, target, patch)
+    out = torch.empty((B, 3, h, w), dtype=torch.float32, device=frames.device)
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    check(_lib.load().d2s_preprocess(_ptr(frames), fmt, B, H, W, _ptr(out), h, w, stride, m, s, _stream()), "d2s_preprocess")
+    return out
+
+
+def post_process_depth(depth: torch.Tensor, p: PipelineParams) -> torch.Tensor:
+    """A10-A11 (reference depth.py:806-814) on float32 [B,h,w] or [h,w]; returns a new tensor."""
+    _need_cuda(depth, "depth")
+    d = depth.to(torch.float32).contiguous().clone()
+    B = d.shape[0] if d.dim() == 3 else 1
+    h, w = d.shape[-2:]
+    lib = _lib.load()
+    nbytes = lib.d2s_post_process_workspace(B, h, w)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=d.device)
+    pp = post_params(p)
+    check(lib.d2s_post_process(_ptr(d), B, h, w, C.byref(pp), _ptr(ws), nbytes, _stream()), "d2s_post_process")
+    return d
+
+
+def ema_update(depth: torch.Tensor, state: torch.Tensor, initialised: bool, alpha: float) -> torch.Tensor:
+    """A12 (reference depth.py:1865-1887); depth [h,w] is overwritten with the returned value."""
+    h, w = depth.shape
+    check(_lib.load().d2s_ema_update(_ptr(depth), _ptr(state), int(initialised), h, w, alpha, _stream()), "d2s_ema_update")
+    return depth
+
+
+def upsample_depth(depth: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """A13 (reference depth.py:1999-2004): [B,h,w] or [h,w] -> same rank at H x W."""
+    _need_cuda(depth, "depth")
+    d = depth.to(torch.float32).contiguous()
+    B = d.shape[0] if d.dim() == 3 else 1
+    h, w = d.shape[-2:]
+    out = torch.empty((B, H, W) if d.dim() == 3 else (H, W), dtype=torch.float32, device=d.device)
+    check(_lib.load().d2s_upsample_depth(_ptr(d), B, h, w, _ptr(out), H, W, _stream()), "d2s_upsample_depth")
+    return out
+
+
+def make_sbs(frames: torch.Tensor, depth: torch.Tensor, sp: SbsParams, out_fmt: int = FMT_U8_HWC) -> torch.Tensor:
+    """A14 (+A13 fused when depth is at model resolution) (reference depth.py:2122-2184)."""
+    _need_cuda(frames, "frames")
+    _need_cuda(depth, "depth")
+    frames = frames.contiguous()
+    d = depth.to(torch.float32).contiguous()
+    fmt, B, H, W = _frame_fmt(frames)
+    dB = d.shape[0] if d.dim() == 3 else 1
+    if dB != B:
+        raise ValueError("frames / depth batch mismatch")
+    dh, dw = d.shape[-2:]
+    oh, ow = sbs_shape(H, W, sp)
+    batched = frames.dim() == 4
+    if out_fmt == FMT_U8_HWC:
+        out = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=frames.device)
+    elif out_fmt == FMT_F32_HWC:
+        out = torch.empty((B, oh, ow, 3), dtype=torch.float32, device=frames.device)
+    elif out_fmt == FMT_F32_CHW:
+        out = torch.empty((B, 3, oh, ow), dtype=torch.float32, device=frames.device)
+    else:
+        raise ValueError("bad out_fmt")
+    check(_lib.load().d2s_make_sbs(_ptr(frames), fmt, _ptr(d), dh, dw, B, H, W, C.byref(sp), _ptr(out), out_fmt, _stream()),
+          "d2s_make_sbs")
+    return out if batched else out[0]
+
+
+class Engine:
+    """The native depth engine: what DepthModelWrapper holds in ``self.model`` for an accelerated
+    backend (reference depth.py:1539-1781).  ``__call__(tensor[B,3,h,w]) -> tensor[B,h,w]``."""
+
+    def __init__(self, cfg: ModelConfig, weights: Dict[str, np.ndarray], h: int, w: int, max_batch: int = 1,
+                 precision: str = "bf16", device: int = 0):
+        if not torch.cuda.is_available():
+            raise _lib.D2SError("no ROCm device: the HIP engine cannot run (and there is no fallback)")
+        self.lib = _lib.load()
+        self.cfg, self.h, self.w, self.max_batch = cfg, h, w, max_batch
+        self.precision = precision
+        self.device = torch.device("cuda", device)
+        desc = ModelDesc(cfg.hidden, cfg.heads, cfg.layers, (C.c_int32 * 4)(*cfg.out_indices), (C.c_int32 * 4)(*cfg.neck),
+                         cfg.fusion, cfg.head_hidden, cfg.mlp, cfg.patch, cfg.pos_grid, cfg.ln_eps,
+                         PREC_BF16 if precision == "bf16" else PREC_FP32)
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self._h = C.c_void_p()
+        check(self.lib.d2s_engine_create(C.byref(desc), device, C.byref(self._h)), "d2s_engine_create")
+        for name, arr in weights.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            check(self.lib.d2s_engine_set_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim),
+                  f"d2s_engine_set_weight({name})")
+        check(self.lib.d2s_engine_finalize(self._h, h, w, max_batch), "d2s_engine_finalize")
+
+    def memory_bytes(self) -> int:
+        b = C.c_uint64()
+        check(self.lib.d2s_engine_memory(self._h, C.byref(b)))
+        return b.value
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        _need_cuda(x, "pixel_values")
+        x = x.to(torch.float32).contiguous()
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        B = x.shape[0]
+        if tuple(x.shape[1:]) != (3, self.h, self.w):
+            raise ValueError(f"engine was built for [B,3,{self.h},{self.w}], got {tuple(x.shape)}")
+        out = torch.empty((B, self.h, self.w), dtype=torch.float32, device=x.device)
+        check(self.lib.d2s_model_forward(self._h, _ptr(x), _ptr(out), B, _stream()), "d2s_model_forward")
+        return out
+
+    def tap(self, name: str) -> torch.Tensor:
+        rows, cols = C.c_int(), C.c_int()
+        n = max(self.cfg.hidden * (self.h // 14 * (self.w // 14) + 1), 16 * (self.h // 14) * (self.w // 14) * self.cfg.fusion)
+        buf = torch.empty(n, dtype=torch.float32, device=self.device)
+        check(self.lib.d2s_engine_tap(self._h, name.encode(), _ptr(buf), n, C.byref(rows), C.byref(cols), _stream()), "d2s_engine_tap")
+        return buf[: rows.value * cols.value].view(rows.value, cols.value)
+
+    def reset_stream(self):
+        check(self.lib.d2s_engine_reset_stream(self._h))
+
+    def pipeline(self, frames: torch.Tensor, p: PipelineParams, sp: SbsParams, use_ema: bool = False,
+                 out_fmt: int = FMT_U8_HWC, want_depth: bool = False, out: Optional[torch.Tensor] = None):
+        """predict_depth + make_sbs for uint8 HWC frames [B,H,W,3] in one stream-ordered call."""
+        _need_cuda(frames, "frames")
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+            raise ValueError("frames must be uint8 [B,H,W,3]")
+        frames = frames.contiguous()
+        B, H, W, _ = frames.shape
+        oh, ow = sbs_shape(H, W, sp)
+        if out is None:
+            if out_fmt == FMT_U8_HWC:
+                out = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=frames.device)
+            elif out_fmt == FMT_F32_HWC:
+                out = torch.empty((B, oh, ow, 3), dtype=torch.float32, device=frames.device)
+            else:
+                out = torch.empty((B, 3, oh, ow), dtype=torch.float32, device=frames.device)
+        depth = torch.empty((B, H, W), dtype=torch.float32, device=frames.device) if want_depth else None
+        pp = post_params(p)
+        check(self.lib.d2s_pipeline(self._h, _ptr(frames), B, H, W, p.depth_resolution, C.byref(pp), C.byref(sp), int(use_ema),
+                                    _ptr(out), out_fmt, _ptr(depth) if want_depth else None, _stream()), "d2s_pipeline")
+        return (out, depth) if want_depth else out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.d2s_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gemm_probe(A: torch.Tensor, Wt: torch.Tensor, bias: Optional[torch.Tensor], precision: str, tile: int = 0, iters: int = 1):
+    """C = A @ Wt^T (+bias) through the engine's MFMA kernel (test / micro-benchmark)."""
+    M, K = A.shape
+    N = Wt.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    check(_lib.load().d2s_gemm_probe(_ptr(A.contiguous()), _ptr(Wt.contiguous()), _ptr(bias) if bias is not None else None,
+                                     _ptr(out), M, N, K, PREC_BF16 if precision == "bf16" else PREC_FP32, tile, iters, _stream()),
+          "d2s_gemm_probe")
+    return out

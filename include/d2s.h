@@ -1,0 +1,182 @@
+/*
+ * d2s.h -- C-ABI of libd2s_hip.so: the MI355X (gfx950) implementation of the
+ * desktop2stereo per-frame hot path  depth inference -> depth post-process -> stereo warp.
+ *
+ * The reference has no FFI for this path; its boundary is the Python call surface of depth.py
+ * plus an internal "engine object" protocol (DepthModelWrapper.__call__, reference
+ * depth.py:1763-1781; MIGraphXEngine.__call__, depth.py:1029-1045: raw device pointers,
+ * caller-allocated output, launched on torch's current hipStream, no host sync).  This header is
+ * what a replacement engine exports under that protocol.  Conventions, mirroring the
+ * reference's own ctypes->libamdhip64 usage (viewer.py:283-299: int status, != 0 -> RuntimeError):
+ *
+ *   - every function returns int: D2S_OK (0) or a D2S_E_* code; d2s_last_error() gives text;
+ *   - all image / tensor pointers are DEVICE pointers owned by the caller (PyTorch-ROCm tensors'
+ *     data_ptr()); the library allocates only weights, workspaces and per-stream state;
+ *   - every call is asynchronous on the hipStream_t passed as `void* stream` (0 = null stream);
+ *     there is no host synchronisation inside the library after engine finalisation;
+ *   - no torch types, only plain pointers and sizes.
+ *
+ * Each entry point cites the reference interface it replaces (file:line in /root/reference).
+ */
+#ifndef D2S_H
+#define D2S_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D2S_OK              0
+#define D2S_E_INVALID       1   /* bad argument / shape / mode */
+#define D2S_E_STATE         2   /* call order (e.g. forward before finalize) */
+#define D2S_E_HIP           3   /* a HIP runtime call failed */
+#define D2S_E_MISSING       4   /* a weight tensor is missing or mis-shaped */
+#define D2S_E_UNSUPPORTED   5
+
+/* display modes of make_sbs_core (reference depth.py:2178-2183) */
+#define D2S_MODE_HALF_SBS   0
+#define D2S_MODE_FULL_SBS   1
+#define D2S_MODE_HALF_TAB   2
+#define D2S_MODE_FULL_TAB   3
+
+/* pixel formats at the boundary */
+#define D2S_FMT_U8_HWC      0   /* uint8  [H,W,3]   (numpy frame, reference depth.py:1921-1922) */
+#define D2S_FMT_F32_CHW     1   /* float  [3,H,W]   (make_sbs_core tensor in/out, depth.py:2135-2138) */
+#define D2S_FMT_F32_HWC     2   /* float  [H,W,3]   (make_sbs return, depth.py:767-773, 2231) */
+#define D2S_FMT_U8_CHW      3   /* uint8  [3,H,W]   (rgb_tensor of predict_depth(return_tuple), depth.py:1922) */
+
+/* arithmetic of the model stage */
+#define D2S_PREC_FP32       0   /* f32 MFMA (v_mfma_f32_16x16x4_f32), fp32 activations: parity class */
+#define D2S_PREC_BF16       1   /* bf16 MFMA, fp32 accumulate / residual / softmax / LayerNorm */
+
+typedef struct d2s_engine d2s_engine;     /* opaque: weights + workspaces + per-stream state */
+
+/* Depth-Anything-v2 architecture (HF DepthAnythingConfig). */
+typedef struct d2s_model_desc {
+    int32_t hidden;            /* D */
+    int32_t heads;
+    int32_t layers;
+    int32_t out_indices[4];    /* 1-based layer taps */
+    int32_t neck[4];           /* neck_hidden_sizes */
+    int32_t fusion;            /* fusion_hidden_size */
+    int32_t head_hidden;       /* 32 */
+    int32_t mlp;               /* 4*D */
+    int32_t patch;             /* 14 */
+    int32_t pos_grid;          /* 37 */
+    float   ln_eps;            /* 1e-6 */
+    int32_t precision;         /* D2S_PREC_* */
+} d2s_model_desc;
+
+/* Post-process constants (reference utils.py:858-859, depth.py:775, 816, 1889). */
+typedef struct d2s_post_params {
+    float   percentile;        /* 2.0 */
+    int32_t subsample_cap;     /* 6144 */
+    float   gamma;             /* 1.45 */
+    float   foreground_scale;  /* FOREGROUND_SCALE = yaml/10 */
+    float   aa_strength;       /* AA_STRENGTH = yaml*2 */
+    float   ema_alpha;         /* 0.9 */
+} d2s_post_params;
+
+/* Stereo parameters of make_sbs_core (reference depth.py:2122-2129). */
+typedef struct d2s_sbs_params {
+    double  ipd_uv;            /* 0.064; double because the reference forms ipd_uv*W in Python floats */
+    float   depth_ratio;       /* 2.0 (function default) / DEPTH_STRENGTH */
+    float   convergence;       /* 0.0 */
+    int32_t display_mode;      /* D2S_MODE_* */
+    int32_t fill_16_9;         /* 0/1 */
+} d2s_sbs_params;
+
+const char* d2s_last_error(void);
+int d2s_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Engine life cycle -- replaces DepthModelWrapper construction + lazy engine build
+ * (reference depth.py:1539-1631, 1784-1789, 1842-1862).
+ * ------------------------------------------------------------------------------------------- */
+int d2s_engine_create(const d2s_model_desc* desc, int device_id, d2s_engine** out);
+/* Upload one tensor by its HF state-dict name (reference weight contract: SURVEY.md section 8c).  `host`
+ * is host float32, C-contiguous, `shape`/`ndim` as in the checkpoint.  Packing (bf16 cast,
+ * [N][K] padding, conv tap order) happens here, once. */
+int d2s_engine_set_weight(d2s_engine* e, const char* name, const float* host,
+                          const int64_t* shape, int ndim);
+/* Fix the model-input shape (cf. _ensure_engine_built, depth.py:1842-1862): h, w multiples of
+ * patch; allocates workspaces for up to max_batch frames and pre-interpolates the position
+ * embedding (HF Dinov2Embeddings.interpolate_pos_encoding, bicubic).  Synchronous. */
+int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch);
+int d2s_engine_destroy(d2s_engine* e);
+/* bytes of device memory the engine holds (weights + workspaces) */
+int d2s_engine_memory(const d2s_engine* e, uint64_t* bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stages.  Each mirrors one reference function; all device pointers, stream-ordered.
+ * ------------------------------------------------------------------------------------------- */
+
+/* A2-A4: ingest + _resize_patch_aligned_t CPU branch (strided decimation, bilinear
+ * align_corners=False) + /255 + (x-mean)/std  (reference depth.py:676-706, 1916-1948).
+ * frames: `batch` frames, format D2S_FMT_U8_HWC or D2S_FMT_U8_CHW or D2S_FMT_F32_CHW (0..255),
+ * each H x W, contiguous.  out: float [batch,3,h,w] with (h,w) the engine shape. */
+int d2s_preprocess(const void* frames, int fmt, int batch, int H, int W,
+                   float* out, int h, int w, int decim_stride,
+                   const float mean[3], const float std[3], void* stream);
+
+/* A5-A9: model(pixel_values=x).predicted_depth  (reference depth.py:1763-1781 -> HF
+ * DepthAnythingForDepthEstimation).  x: float [batch,3,h,w]; depth: float [batch,h,w]. */
+int d2s_model_forward(d2s_engine* e, const float* x, float* depth, int batch, void* stream);
+
+/* A10-A11: post_process_depth = normalize -> gamma -> foreground_scale -> anti_alias
+ * (reference depth.py:806-814), in place on float [batch,h,w].  Stateless. */
+int d2s_post_process(float* depth, int batch, int h, int w, const d2s_post_params* p,
+                     void* workspace, uint64_t workspace_bytes, void* stream);
+uint64_t d2s_post_process_workspace(int batch, int h, int w);
+
+/* A12: DepthStabilizer.__call__ (reference depth.py:1865-1887).  state: float [h,w] owned by the
+ * caller; *initialised == 0 -> state = depth (first frame), else state = lerp(state, depth, 1-alpha);
+ * depth is overwritten with the returned value.  Frames are processed in order. */
+int d2s_ema_update(float* depth, float* state, int initialised, int h, int w, float alpha,
+                   void* stream);
+
+/* A13: F.interpolate(depth, (H,W), bilinear, align_corners=False)  (reference depth.py:1999-2004).
+ * in: float [batch,h,w] -> out: float [batch,H,W]. */
+int d2s_upsample_depth(const float* in, int batch, int h, int w, float* out, int H, int W,
+                       void* stream);
+
+/* A14 (+A13 fused): make_sbs_core  (reference depth.py:2122-2184).
+ * rgb: `batch` frames H x W in `rgb_fmt`; depth: float [batch,dh,dw] -- either full resolution
+ * (dh==H, dw==W: exactly make_sbs_core) or model resolution (the bilinear align_corners=False
+ * up-sample of predict_depth, depth.py:1999-2004, is fused into the warp).
+ * out: `out_fmt` in {U8_HWC (round-half-even, saturate), F32_HWC, F32_CHW}; shape from d2s_sbs_shape. */
+int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, int dh, int dw,
+                 int batch, int H, int W, const d2s_sbs_params* p,
+                 void* out, int out_fmt, void* stream);
+/* output frame size of make_sbs_core for an H x W input (pad_to_aspect_tensor, depth.py:2106-2119) */
+int d2s_sbs_shape(int H, int W, const d2s_sbs_params* p, int* out_h, int* out_w);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused frame pipeline: predict_depth + make_sbs for a batch of frames
+ * (capture -> depth -> warp of reference main.py:232-262, 1336-1341 in one stream-ordered
+ * call).  frames u8 HWC [batch,H,W,3]; out per d2s_sbs_shape in out_fmt; depth_full (optional,
+ * may be NULL) receives predict_depth's return value, float [batch,H,W].
+ * use_ema: run DepthStabilizer across the batch in frame order using the engine's stream state
+ * (d2s_engine_reset_stream clears it). */
+int d2s_pipeline(d2s_engine* e, const uint8_t* frames, int batch, int H, int W,
+                 int depth_resolution, const d2s_post_params* pp, const d2s_sbs_params* sp,
+                 int use_ema, void* out, int out_fmt, float* depth_full, void* stream);
+int d2s_engine_reset_stream(d2s_engine* e);
+
+/* Debug / parity taps: copy an internal activation (after the last d2s_model_forward) to a
+ * caller device buffer as float32.  name: "embeddings", "layer<N>", "neck_feat<i>", "fused<i>".
+ * rows/cols describe [rows, cols] of frame 0 (tokens x D, or pixels x C, NHWC). */
+int d2s_engine_tap(d2s_engine* e, const char* name, float* out, uint64_t out_elems,
+                   int* rows, int* cols, void* stream);
+
+/* Stand-alone GEMM probe used by tests and the micro-benchmark:
+ * C[M,N] = A[M,K] * W[N,K]^T (+bias), A/W given as float32 device arrays, computed with the
+ * engine's MFMA kernel in the requested precision. */
+int d2s_gemm_probe(const float* A, const float* Wt, const float* bias, float* C,
+                   int M, int N, int K, int precision, int tile, int iters, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2S_H */

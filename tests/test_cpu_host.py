@@ -1,0 +1,88 @@
+"""CPU: the C-ABI library loads, exports every symbol include/d2s.h declares, and its pure-host
+entry points (shape logic, error plumbing) behave like the reference's integer logic.  No compute."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from desktop2stereo_amd import _lib
+from desktop2stereo_amd.config import engine_shape
+from oracle import d2s_oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        from desktop2stereo_amd import build
+        build.build()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(REPO, "include", "d2s.h")).read()
+    declared = set(re.findall(r"\b(d2s_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.d2s_version() >= 100
+
+
+def test_struct_layout_matches_header():
+    assert C.sizeof(_lib.ModelDesc) == 4 * (3 + 4 + 4 + 5) + 4 + 4
+    assert C.sizeof(_lib.PostParams) == 24
+    assert C.sizeof(_lib.SbsParams) == 24 and _lib.SbsParams.ipd_uv.offset == 0 and _lib.SbsParams.depth_ratio.offset == 8
+
+
+def test_sbs_shape_matches_reference_padding(lib):
+    from desktop2stereo_amd.ops import sbs_params, sbs_shape
+    for (H, W) in [(1080, 1920), (90, 160), (120, 160), (100, 240), (75, 133), (2160, 3840), (480, 640), (1, 1)]:
+        for mode in _lib.MODE:
+            for fill in (False, True):
+                e = np.zeros((1, H, W), np.float32)
+                if fill:
+                    e = O.pad_to_aspect(e)
+                hp, wp = e.shape[1:]
+                want = {"Half-SBS": (hp, wp), "Half-TAB": (hp, wp), "Full-SBS": (hp, 2 * wp), "Full-TAB": (2 * hp, wp)}[mode]
+                assert sbs_shape(H, W, sbs_params(display_mode=mode, fill_16_9=fill)) == want, (H, W, mode, fill)
+
+
+def test_errors_are_loud(lib):
+    sp = _lib.SbsParams(0.064, 2.0, 0.0, 7, 0)
+    oh, ow = C.c_int(), C.c_int()
+    rc = lib.d2s_sbs_shape(10, 10, C.byref(sp), C.byref(oh), C.byref(ow))
+    assert rc != 0 and lib.d2s_last_error()
+    with pytest.raises(_lib.D2SError):
+        _lib.check(rc, "d2s_sbs_shape")
+    with pytest.raises(_lib.D2SError):
+        _lib.load.__wrapped__ if hasattr(_lib.load, "__wrapped__") else None
+        _lib._lib = None
+        try:
+            _lib.load("/nonexistent/libd2s_hip.so")
+        finally:
+            _lib._lib = None
+            _lib.load()
+
+
+def test_engine_shape_host_logic():
+    # same table as the oracle's (reference depth.py:676-706)
+    for args in [(1080, 1920, 518), (2160, 3840, 518), (1440, 2560, 518), (720, 1280, 518), (1080, 1920, 336), (90, 160, 84),
+                 (600, 800, 518), (1200, 1200, 392), (333, 777, 238)]:
+        assert engine_shape(*args) == O.engine_shape(*args)
+
+
+def test_weight_generator_matches_hf_layout():
+    from desktop2stereo_amd.config import MODELS
+    from desktop2stereo_amd.weights import expected_shapes, make_weights
+    for name, n_params in [("vits", 24.8e6), ("vitb", 97.5e6), ("vitl", 335.3e6)]:
+        shapes = expected_shapes(MODELS[name])
+        total = sum(int(np.prod(s)) for s in shapes.values())
+        # + mask_token (D) which HF holds but the engine never reads
+        assert abs(total + MODELS[name].hidden - n_params) / n_params < 0.005, (name, total)
+    w1, w2 = make_weights(MODELS["tiny"], 0), make_weights(MODELS["tiny"], 0)
+    assert all(np.array_equal(w1[k], w2[k]) for k in w1)
+    assert not np.array_equal(make_weights(MODELS["tiny"], 1)["head.conv1.weight"], w1["head.conv1.weight"])

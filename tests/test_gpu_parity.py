@@ -1,0 +1,307 @@
+"""GPU parity tests proper: every stage of the HIP path, called through the C-ABI, against
+(a) the golden vectors captured from the reference and (b) the numpy oracle on seeded inputs.
+
+Tolerances (stated per test): float stages 1e-5..1e-4 class; post-processed depth <= 1e-3 for the
+fp32 (f32-MFMA) engine; warped RGB <= 1 LSB after round-half-even; the bf16 engine is graded
+against the reference's OWN bf16-vs-fp32 deviation (tests/golden/vits_r518_bf16: max 0.036, mean
+0.0029 on the post-processed depth)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu test selected but no ROCm device is visible")
+    from desktop2stereo_amd import _lib
+    _lib.load()                      # fail loudly if the HIP library is missing
+    return torch.device("cuda", 0)
+
+
+def _golden(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    with open(os.path.join(golden_dir, name + ".json")) as f:
+        return z, json.load(f)
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_preprocess_matches_oracle(dev):
+    from desktop2stereo_amd import ops, synth
+    from oracle import d2s_oracle as O
+    for (H, W, target) in [(1080, 1920, 518), (2160, 3840, 518), (1440, 2560, 518), (720, 1280, 518),
+                           (1080, 1920, 336), (90, 160, 84), (75, 133, 84)]:
+        img = synth.noise_frame(H, W, 3)
+        got = ops.preprocess(_t(img, dev), target).cpu().numpy()[0]
+        want = O.normalise(O.resize_patch_aligned(np.ascontiguousarray(img.transpose(2, 0, 1)), target))
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-5, (H, W, target, np.abs(got - want).max())
+    # CHW uint8 and CHW float inputs (tensor passthrough of predict_depth, reference depth.py:1916-1918)
+    img = synth.structured_frame(270, 480, 1)
+    want = O.normalise(O.resize_patch_aligned(np.ascontiguousarray(img.transpose(2, 0, 1)), 140))
+    chw = np.ascontiguousarray(img.transpose(2, 0, 1))
+    for t in (_t(chw, dev), _t(chw.astype(np.float32), dev)):
+        got = ops.preprocess(t, 140).cpu().numpy()[0]
+        assert np.abs(got - want).max() <= 2e-5
+
+
+def test_post_process_matches_golden(dev, golden_dir):
+    from desktop2stereo_amd import ops
+    from desktop2stereo_amd.config import PipelineParams
+    p = PipelineParams()
+    for name in ("tiny_r84", "tiny_r518", "vits_r518", "vitb_r518"):
+        z, meta = _golden(golden_dir, name)
+        for fi in range(len(meta["frames"])):
+            raw = z[f"f{fi}_raw_depth"]
+            got = ops.post_process_depth(_t(raw, dev), p).cpu().numpy()
+            err = np.abs(got - z[f"f{fi}_post_depth"]).max()
+            assert err <= 5e-6, (name, fi, err)
+    # batched call == per-frame calls; other strengths
+    z, _ = _golden(golden_dir, "tiny_r84")
+    from oracle import d2s_oracle as O
+    raws = np.stack([z[f"f{i}_raw_depth"] for i in range(3)])
+    for fg, aa in [(0.05, 4.0), (0.0, 4.0), (0.3, 2.0), (-0.2, 0.5), (0.05, 0.0)]:
+        pp = PipelineParams(foreground_scale=fg, aa_strength=aa)
+        got = ops.post_process_depth(_t(raws, dev), pp).cpu().numpy()
+        for i in range(3):
+            want = O.post_process_depth(raws[i], fg, aa)
+            assert np.abs(got[i] - want).max() <= 5e-6, (fg, aa, i)
+
+
+def test_post_process_edge_cases(dev):
+    from desktop2stereo_amd import ops
+    from desktop2stereo_amd.config import PipelineParams
+    from oracle import d2s_oracle as O
+    p = PipelineParams()
+    rng = np.random.default_rng(0)
+    for shape in [(1, 5), (3, 3), (2, 7), (14, 14), (80, 80), (200, 311)]:   # n<=10 branch, n<cap, n>cap
+        raw = rng.uniform(0, 10, shape).astype(np.float32)
+        got = ops.post_process_depth(_t(raw, dev), p).cpu().numpy().reshape(shape)
+        want = O.post_process_depth(raw, p.foreground_scale, p.aa_strength).reshape(shape)
+        assert np.abs(got - want).max() <= 5e-6, shape
+    flat = np.full((42, 84), 3.25, np.float32)                                  # zero range -> denom clamp
+    got = ops.post_process_depth(_t(flat, dev), p).cpu().numpy()
+    assert np.abs(got - O.post_process_depth(flat, p.foreground_scale, p.aa_strength)).max() <= 5e-6
+    neg = rng.normal(0, 1, (42, 84)).astype(np.float32)                         # negative values sort correctly
+    got = ops.post_process_depth(_t(neg, dev), p).cpu().numpy()
+    assert np.abs(got - O.post_process_depth(neg, p.foreground_scale, p.aa_strength)).max() <= 5e-6
+
+
+def test_ema_and_upsample(dev, golden_dir):
+    from desktop2stereo_amd import ops
+    from oracle import d2s_oracle as O
+    z, meta = _golden(golden_dir, "tiny_r84")
+    state = torch.zeros((42, 84), dtype=torch.float32, device=dev)
+    for fi in range(3):
+        d = _t(z[f"f{fi}_post_depth"], dev).clone()
+        ops.ema_update(d, state, fi > 0, 0.9)
+        assert np.abs(state.cpu().numpy() - z[f"f{fi}_ema_state"]).max() <= 2e-6
+        up = ops.upsample_depth(d, 90, 160).cpu().numpy()
+        assert np.abs(up - z[f"f{fi}_depth_ema_full"]).max() <= 5e-6
+    rng = np.random.default_rng(1)
+    d = rng.uniform(0, 1, (2, 294, 518)).astype(np.float32)
+    got = ops.upsample_depth(_t(d, dev), 1080, 1920).cpu().numpy()
+    for b in range(2):
+        assert np.abs(got[b] - O.upsample_depth(d[b], 1080, 1920)).max() <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("generic", [False, True])
+def test_warp_matches_golden(dev, golden_dir, generic, monkeypatch):
+    """All display modes x fill_16_9 x convergence x aspect ratios, against the reference's outputs."""
+    from desktop2stereo_amd import ops, synth, _lib
+    from oracle import d2s_oracle as O
+    z, meta = _golden(golden_dir, "warp")
+    cache = {}
+    for c in meta["cases"]:
+        k = (c["shape"], c["kind"])
+        if k not in cache:
+            gen = synth.structured_frame if c["kind"] == "S2" else synth.noise_frame
+            cache[k] = (_t(gen(c["h"], c["w"], c["seed"]), dev), _t(synth.smooth_depth(c["h"], c["w"], c["seed"]), dev))
+        img, dep = cache[k]
+        sp = ops.sbs_params(c["ipd_uv"], c["depth_ratio"], c["convergence"], c["mode"], c["fill_16_9"])
+        ref = z[c["key"]].astype(np.float32) / 256.0
+        # float32 HWC output = what make_sbs returns (reference depth.py:2231)
+        out = ops.make_sbs(img, dep, sp, _lib.FMT_F32_HWC).cpu().numpy()
+        assert list(out.shape) == c["out_shape"], c["key"]
+        got = out[::c["row_stride"]]
+        tol = 0.08 if c["kind"] == "S1" else 0.03          # reference's own fp32 coordinate noise
+        assert np.abs(got - ref).max() <= tol, (c["key"], np.abs(got - ref).max())
+        # uint8 output (fast path unless generic): <= 1 LSB from the rounded reference
+        if generic:
+            continue
+        u8 = ops.make_sbs(img, dep, sp, _lib.FMT_U8_HWC).cpu().numpy()[::c["row_stride"]]
+        assert np.abs(u8.astype(int) - O.to_u8(ref).astype(int)).max() <= 1, c["key"]
+        # CHW float in / CHW float out = make_sbs_core's own tensor surface
+        chw = ops.make_sbs(img.permute(2, 0, 1).float().contiguous(), dep, sp, _lib.FMT_F32_CHW).cpu().numpy()
+        assert np.abs(chw.transpose(1, 2, 0)[::c["row_stride"]] - got).max() <= 1e-4
+
+
+def test_warp_fast_equals_generic_and_fused_upsample(dev):
+    """u8 fast path (LDS-staged) == generic kernel bit-for-bit on the float->u8 rounding, and the
+    fused model-resolution depth path == explicit upsample + warp."""
+    from desktop2stereo_amd import ops, synth, _lib
+    from oracle import d2s_oracle as O
+    img_np = synth.noise_frame(1080, 1920, 11)
+    img = _t(img_np, dev)
+    dsmall_np = synth.smooth_depth(294, 518, 5)
+    dsmall = _t(dsmall_np, dev)
+    dfull = ops.upsample_depth(dsmall, 1080, 1920)
+    for mode in ("Half-SBS", "Full-SBS", "Half-TAB", "Full-TAB"):
+        for ratio in (4.0, 40.0):                              # 40: shifts beyond the LDS halo and reflections
+            sp = ops.sbs_params(0.064, ratio, 0.05, mode, True)
+            fast = ops.make_sbs(img, dsmall, sp, _lib.FMT_U8_HWC).cpu().numpy()
+            ref_f = ops.make_sbs(img, dfull, sp, _lib.FMT_F32_HWC).cpu().numpy()       # generic kernel, explicit upsample
+            assert np.abs(fast.astype(np.float32) - ref_f).max() <= 0.5 + 2e-3, (mode, ratio)
+            if ratio == 4.0 and mode in ("Half-SBS", "Full-TAB"):
+                want = O.make_sbs_core(img_np.transpose(2, 0, 1).astype(np.float32), dfull.cpu().numpy(), 0.064, ratio,
+                                       mode, True, 0.05).transpose(1, 2, 0)
+                assert np.abs(fast.astype(int) - O.to_u8(want).astype(int)).max() <= 1
+    # batch of frames
+    imgs = torch.stack([img, _t(synth.structured_frame(1080, 1920, 2), dev)])
+    deps = torch.stack([dsmall, _t(synth.smooth_depth(294, 518, 6), dev)])
+    sp = ops.sbs_params(0.064, 4.0, 0.0, "Full-SBS", True)
+    both = ops.make_sbs(imgs, deps, sp).cpu().numpy()
+    for b in range(2):
+        one = ops.make_sbs(imgs[b], deps[b], sp).cpu().numpy()
+        assert np.array_equal(both[b], one)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_gemm_probe(dev):
+    """MFMA GEMM kernel vs float64 numpy: asymmetric operands (transpose-detecting), ragged M/N/K."""
+    from desktop2stereo_amd import ops
+    rng = np.random.default_rng(0)
+    for (M, N, K) in [(64, 64, 64), (778, 2304, 768), (777, 768, 608), (130, 132, 72), (1, 4, 8), (300, 96, 3072)]:
+        A = rng.normal(0, 1, (M, K)).astype(np.float32)
+        W = rng.normal(0, 1, (N, K)).astype(np.float32) * np.linspace(0.5, 1.5, N, dtype=np.float32)[:, None]
+        b = rng.normal(0, 1, N).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64).T + b
+        for tile in (64, 128):
+            got = ops.gemm_probe(_t(A, dev), _t(W, dev), _t(b, dev), "fp32", tile).cpu().numpy()
+            assert np.abs(got - ref).max() <= 2e-4 * np.sqrt(K / 64), (M, N, K, tile, "fp32", np.abs(got - ref).max())
+            got = ops.gemm_probe(_t(A, dev), _t(W, dev), _t(b, dev), "bf16", tile).cpu().numpy()
+            Ab = torch.from_numpy(A).bfloat16().double().numpy()
+            Wb = torch.from_numpy(W).bfloat16().double().numpy()
+            refb = Ab @ Wb.T + b
+            assert np.abs(got - refb).max() <= 2e-4 * np.sqrt(K / 64) + 1e-3, (M, N, K, tile, "bf16", np.abs(got - refb).max())
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tiny_fp32(dev):
+    os.environ["D2S_TAPS"] = "1"
+    from desktop2stereo_amd import ops
+    from desktop2stereo_amd.config import MODELS
+    from desktop2stereo_amd.weights import make_weights
+    cfg = MODELS["tiny"]
+    eng = ops.Engine(cfg, make_weights(cfg, 0), 42, 84, max_batch=3, precision="fp32")
+    os.environ.pop("D2S_TAPS")
+    return eng
+
+
+def test_tiny_engine_taps_fp32(dev, golden_dir, tiny_fp32):
+    """KAT-tiny: hidden state after embeddings and every layer, raw depth, vs the reference."""
+    z, meta = _golden(golden_dir, "tiny_r84")
+    for fi in range(3):
+        x = _t(z[f"f{fi}_model_input"], dev)
+        raw = tiny_fp32(x).cpu().numpy()[0]
+        emb = tiny_fp32.tap("embeddings").cpu().numpy()
+        assert np.abs(emb - z[f"f{fi}_embeddings"]).max() <= 5e-5
+        for li in range(1, 5):
+            got = tiny_fp32.tap(f"layer{li}").cpu().numpy()
+            assert np.abs(got - z[f"f{fi}_layer{li}"]).max() <= 2e-4, (fi, li, np.abs(got - z[f"f{fi}_layer{li}"]).max())
+        scale = float(z[f"f{fi}_raw_depth"].max())
+        assert np.abs(raw - z[f"f{fi}_raw_depth"]).max() <= 1e-4 * scale, (fi, np.abs(raw - z[f"f{fi}_raw_depth"]).max(), scale)
+    # batch of 3 == three single calls
+    xs = _t(np.stack([z[f"f{i}_model_input"] for i in range(3)]), dev)
+    raws = tiny_fp32(xs).cpu().numpy()
+    for i in range(3):
+        one = tiny_fp32(xs[i]).cpu().numpy()[0]
+        assert np.abs(raws[i] - one).max() <= 1e-4 * float(one.max())
+
+
+def test_tiny_engine_bf16(dev, golden_dir):
+    from desktop2stereo_amd import ops
+    from desktop2stereo_amd.config import MODELS, PipelineParams
+    from desktop2stereo_amd.weights import make_weights
+    cfg = MODELS["tiny"]
+    eng = ops.Engine(cfg, make_weights(cfg, 0), 42, 84, max_batch=1, precision="bf16")
+    z, _ = _golden(golden_dir, "tiny_r84")
+    for fi in range(3):
+        raw = eng(_t(z[f"f{fi}_model_input"], dev)).cpu().numpy()[0]
+        ref = z[f"f{fi}_raw_depth"]
+        rel = np.abs(raw - ref).max() / float(ref.max())
+        assert rel <= 0.03, (fi, rel)                      # bf16 operands, fp32 accumulate
+        post = ops.post_process_depth(_t(raw, dev), PipelineParams()).cpu().numpy()
+        d = np.abs(post - z[f"f{fi}_post_depth"])
+        assert d.max() <= 0.04 and d.mean() <= 0.004, (fi, d.max(), d.mean())
+
+
+@pytest.mark.parametrize("name,model,res", [("tiny_r518", "tiny", 518), ("vits_r518", "vits", 518),
+                                            ("vits_r336", "vits", 336), ("vitb_r518", "vitb", 518)])
+def test_full_size_predict_depth(dev, golden_dir, name, model, res):
+    """1080p frame -> post-processed depth at model resolution, fp32 engine <= 1e-3 (parity gate),
+    bf16 engine within the reference's own bf16-vs-fp32 class."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS, PipelineParams, engine_shape
+    from desktop2stereo_amd.weights import make_weights
+    cfg = MODELS[model]
+    z, meta = _golden(golden_dir, name)
+    fr = meta["frames"][0]
+    img = _t(synth.structured_frame(fr["h"], fr["w"], fr["seed"]), dev)
+    h, w, _ = engine_shape(fr["h"], fr["w"], res)
+    p = PipelineParams(depth_resolution=res)
+    wts = make_weights(cfg, 0)
+    x = ops.preprocess(img, res)
+    ref_raw, ref_post = z["f0_raw_depth"], z["f0_post_depth"]
+    scale = float(ref_raw.max())
+    eng = ops.Engine(cfg, wts, h, w, 1, "fp32")
+    raw = eng(x)
+    post = ops.post_process_depth(raw, p).cpu().numpy()[0]
+    raw = raw.cpu().numpy()[0]
+    assert np.abs(raw - ref_raw).max() <= 2e-4 * scale, ("fp32 raw", np.abs(raw - ref_raw).max() / scale)
+    assert np.abs(post - ref_post).max() <= 1e-3, ("fp32 post", np.abs(post - ref_post).max())
+    eng.close()
+    eng = ops.Engine(cfg, wts, h, w, 1, "bf16")
+    raw = eng(x)
+    post = ops.post_process_depth(raw, p).cpu().numpy()[0]
+    d = np.abs(post - ref_post)
+    print(f"[{name}] bf16 engine post-depth vs fp32 reference: max {d.max():.4f} mean {d.mean():.5f}")
+    assert d.max() <= 0.06 and d.mean() <= 0.006, (d.max(), d.mean())
+    eng.close()
+
+
+def test_pipeline_end_to_end(dev):
+    """d2s_pipeline (fused frame path, batch 2, EMA on) vs the oracle: depth <= 1e-3, RGB <= 1 LSB."""
+    from desktop2stereo_amd import ops, synth, _lib
+    from desktop2stereo_amd.config import MODELS, PipelineParams, engine_shape
+    from desktop2stereo_amd.weights import make_weights
+    from oracle import d2s_oracle as O
+    cfg = MODELS["tiny"]
+    wts = make_weights(cfg, 0)
+    H, W, res = 270, 480, 140
+    h, w, _ = engine_shape(H, W, res)
+    p = PipelineParams(depth_resolution=res)
+    eng = ops.Engine(cfg, wts, h, w, 2, "fp32")
+    orc = O.PipelineOracle(cfg, wts, res, p.foreground_scale, p.aa_strength)
+    frames = np.stack([synth.structured_frame(H, W, 0), synth.structured_frame(H, W, 1)])
+    sp = ops.sbs_params(0.064, 4.0, 0.0, "Half-SBS", True)
+    out, depth = eng.pipeline(_t(frames, dev), p, sp, use_ema=True, want_depth=True)
+    out, depth = out.cpu().numpy(), depth.cpu().numpy()
+    for b in range(2):
+        d_ref = orc.predict_depth(frames[b], use_temporal_smooth=True)
+        assert np.abs(depth[b] - d_ref).max() <= 1e-3, (b, np.abs(depth[b] - d_ref).max())
+        sbs_ref = orc.make_sbs(frames[b], depth[b], ipd_uv=0.064, depth_ratio=4.0, display_mode="Half-SBS", fill_16_9=True)
+        assert np.abs(out[b].astype(int) - O.to_u8(sbs_ref).astype(int)).max() <= 1
+    eng.close()
