@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Throughput bench of the hot path: stereo frames/s, 1080p, Depth-Anything-v2 ViT-B, Full-SBS.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+One step = one pass of predict_depth + make_sbs (d2s_pipeline) over one batch of synthetic uint8
+frames already resident in HBM.  Workload = BASELINE.json configs[1]: DA-v2 ViT-B bf16,
+1920x1080, batch 1, Full-SBS, Depth Resolution 518 (model input 294x518), seeded synthetic weights.
+Frames shard across ranks with no data-path collective (weak scaling: per-GPU work fixed).
+
+Rank 0 prints ONE JSON line: the contract fields plus
+  roofline      -- the dominant kernel class, timed live with HIP events on the launch stream
+                   (d2s_engine_profile) in a second pass over the same workload;
+  kernels       -- the same numbers for every kernel class;
+  roofline_warp -- the stereo-warp kernel against the HBM roofline;
+  cpu_baseline  -- the numpy oracle (a port of the reference's CPU path) on a bounded sample,
+                   rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0                          # HBM3E spec
+SURVEY_GF_PER_FRAME = {("vitb", 518): 176.9, ("vits", 518): 45.8, ("vitl", 518): 635.9,
+                       ("vitb", 336): 76.5, ("vits", 336): 19.8, ("vitl", 336): 275.2}
+
+
+def cpu_baseline(cfg, weights, p, H, W, mode, budget_s=15.0, max_frames=3):
+    """The oracle (numpy port of the reference CPU path) timed on this host's cores."""
+    import numpy as np
+    from desktop2stereo_amd import synth
+    from oracle import d2s_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    orc = O.PipelineOracle(cfg, weights, p.depth_resolution, p.foreground_scale, p.aa_strength)
+    n, t_total = 0, 0.0
+    while n < max_frames and t_total < budget_s:
+        frame = synth.noise_frame(H, W, 100 + n)
+        t0 = time.perf_counter()
+        d = orc.predict_depth(frame)
+        orc.make_sbs(frame, d, ipd_uv=p.ipd, depth_ratio=p.depth_strength, convergence=p.convergence,
+                     display_mode=mode, fill_16_9=p.fill_16_9)
+        t_total += time.perf_counter() - t0
+        n += 1
+    return {"value": n / t_total, "unit": "stereo frames/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} frame(s) {W}x{H} {cfg.name} fp32 numpy oracle, {mode}, {t_total:.1f} s of CPU work",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU (configs[1]: 1)")
+    ap.add_argument("--model", default="vitb")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--res", type=int, default=518)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--mode", default="Full-SBS")
+    ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from desktop2stereo_amd import _lib, ops, synth
+    from desktop2stereo_amd.config import MODELS, PipelineParams, engine_shape
+    from desktop2stereo_amd.weights import make_weights
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the HIP path has no fallback)")
+    _lib.load()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = MODELS[args.model]
+    H, W, B = args.height, args.width, args.batch
+    p = PipelineParams(depth_resolution=args.res, display_mode=args.mode)
+    h, w, _ = engine_shape(H, W, args.res)
+    weights = make_weights(cfg, 0)
+    eng = ops.Engine(cfg, weights, h, w, max_batch=B, precision=args.precision, device=local_rank)
+    sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, args.mode, p.fill_16_9)
+    oh, ow = ops.sbs_shape(H, W, sp)
+    # a small pool of distinct batches, resident in HBM before the timed region
+    pool = [torch.from_numpy(np.stack([synth.noise_frame(H, W, 1000 * rank + 10 * j + i) for i in range(B)])).to(dev)
+            for j in range(4)]
+    out = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=dev)
+
+    def step(i):
+        eng.pipeline(pool[i & 3], p, sp, use_ema=False, out=out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.barrier()
+    frames_total = args.steps * B * world
+    value = frames_total / dt
+
+    result = {
+        "metric": "stereo frames/sec @1080p DepthAnything-v2-ViT-B", "value": value, "unit": "stereo frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"DepthAnything-v2-{cfg.name} {args.precision}, {W}x{H} uint8 RGB noise frames, batch {B} per GPU, "
+                               f"Depth Resolution {args.res} (model input {h}x{w}), {args.mode} uint8 output {ow}x{oh}, "
+                               f"predict_depth + make_sbs fused (d2s_pipeline), EMA off, seeded synthetic weights",
+                   "frames_per_step_per_gpu": B, "parallelism": f"frame-sharded dp{world}, no data-path collective"},
+    }
+    if args.model != "vitb" or (H, W) != (1080, 1920):
+        result["metric"] = f"stereo frames/sec @{W}x{H} DepthAnything-v2-{cfg.name}"
+
+    if rank == 0 and not args.no_profile:
+        eng.profile(True)
+        for i in range(args.profile_steps):
+            step(i)
+        torch.cuda.synchronize()
+        prof = eng.profile_read()
+        eng.profile(False)
+        nf = args.profile_steps * B
+        kernels = {}
+        for name, r in prof.items():
+            if not r["launches"]:
+                continue
+            k = {"launches_per_step": r["launches"] / args.profile_steps, "ms_per_step": r["ms"] / args.profile_steps,
+                 "avg_launch_us": 1e3 * r["ms"] / r["launches"]}
+            if r["flops"]:
+                k["gflop_per_frame"] = r["flops"] / nf / 1e9
+                k["tflops"] = r["flops"] / (r["ms"] * 1e-3) / 1e12
+                k["frac_of_mfma_peak"] = k["tflops"] / PEAK_TFLOPS[args.precision]
+            if r["bytes"]:
+                k["mb_per_frame"] = r["bytes"] / nf / 1e6
+                k["gbs"] = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+                k["frac_of_hbm_peak"] = k["gbs"] / PEAK_HBM_GBS
+            kernels[name] = k
+        result["kernels"] = kernels
+        gpu_ms = sum(k["ms_per_step"] for k in kernels.values())
+        result["gpu_busy_ms_per_step"] = gpu_ms
+        dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
+        kd = kernels[dom]
+        if "tflops" in kd:
+            result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kd["tflops"], "peak": PEAK_TFLOPS[args.precision],
+                                  "unit": "TFLOP/s", "frac": kd["frac_of_mfma_peak"], "traffic": None,
+                                  "flop_per_launch": 1e9 * kd["gflop_per_frame"] * B / kd["launches_per_step"],
+                                  "avg_launch_us": kd["avg_launch_us"]}
+        else:
+            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kd.get("gbs"), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": kd.get("frac_of_hbm_peak"), "traffic": None, "avg_launch_us": kd["avg_launch_us"]}
+        if "stereo_warp" in kernels:
+            kw = kernels["stereo_warp"]
+            result["roofline_warp"] = {"kernel": "stereo_warp", "bound": "hbm", "achieved": kw["gbs"], "peak": PEAK_HBM_GBS,
+                                       "unit": "GB/s", "frac": kw["frac_of_hbm_peak"], "traffic": None,
+                                       "bytes_per_launch": 1e6 * kw["mb_per_frame"] * B, "avg_launch_us": kw["avg_launch_us"]}
+        mf = sum(k.get("gflop_per_frame", 0.0) for k in kernels.values())
+        result["model_gflop_per_frame"] = {"counted": mf, "survey": SURVEY_GF_PER_FRAME.get((args.model, args.res))}
+        result["model_stage_tflops_at_measured_fps"] = value / world * mf / 1e3
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, weights, p, H, W, args.mode)
+        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(result))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,10 @@ SYMBOLS = {
                                C.POINTER(SbsParams), C.c_int, _P, C.c_int, _P, _P]),
     "d2s_engine_reset_stream": (C.c_int, [_P]),
     "d2s_engine_tap": (C.c_int, [_P, C.c_char_p, _P, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
+    "d2s_engine_profile": (C.c_int, [_P, C.c_int]),
+    "d2s_engine_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "d2s_profile_class_name": (C.c_char_p, [C.c_int]),
     "d2s_gemm_probe": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
 }
 

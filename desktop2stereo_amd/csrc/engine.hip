@@ -69,6 +69,12 @@ struct d2s_engine {
     bool taps = false;
     float* tap_hidden = nullptr;                   // [(layers+1), N, D]
     int last_batch = 0;
+    // per-kernel-class timing with HIP events (d2s_engine_profile): off in the throughput path
+    struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
+    bool prof_on = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    size_t prof_used = 0;
 };
 
 namespace {
@@ -81,6 +87,26 @@ int dev_alloc(d2s_engine* e, void** p, size_t bytes, bool zero = false) {
     if (zero) D2S_HIP(hipMemset(*p, 0, bytes));
     return D2S_OK;
 }
+
+enum { PC_GEMM = 0, PC_CONV, PC_ATTN, PC_LN, PC_ELT, PC_PRE, PC_POST, PC_WARP, PC_N };
+const char* const PC_NAMES[PC_N] = {"gemm_linear", "gemm_conv3x3", "attention", "layernorm", "elementwise", "preprocess",
+                                    "post_process", "stereo_warp"};
+
+hipEvent_t prof_event(d2s_engine* e) {
+    if (e->prof_used == e->prof_pool.size()) { hipEvent_t ev; (void)hipEventCreate(&ev); e->prof_pool.push_back(ev); }
+    return e->prof_pool[e->prof_used++];
+}
+void prof_begin(d2s_engine* e, int cls, double flops, double bytes, hipStream_t st) {
+    if (!e->prof_on) return;
+    d2s_engine::ProfRec r; r.cls = cls; r.flops = flops; r.bytes = bytes; r.a = prof_event(e); r.b = prof_event(e);
+    (void)hipEventRecord(r.a, st);
+    e->prof_recs.push_back(r);
+}
+void prof_end(d2s_engine* e, hipStream_t st) {
+    if (!e->prof_on) return;
+    (void)hipEventRecord(e->prof_recs.back().b, st);
+}
+#define PROF(cls, fl, by, call) do { prof_begin(e, cls, fl, by, st); int _rc = (call); prof_end(e, st); if (_rc != D2S_OK) return _rc; } while (0)
 
 const HostT* find(d2s_engine* e, const std::string& name) {
     auto it = e->host.find(name);
@@ -207,7 +233,9 @@ GemmEpi rowsE(void* out, int out_type, long ldc, const float* bias) {
 }
 
 int gemm(d2s_engine* e, const GemmA& a, const PackedW& w, int M, const GemmEpi& ep, hipStream_t st) {
-    return launch_gemm(e->prec, 0, a, w.w, M, w.N, w.K, w.Kpad, ep, st);
+    int Kl = w.K % (e->prec == D2S_PREC_BF16 ? 8 : 4) ? w.Kpad : w.K;   // ragged K (patch embed): A is zero padded to Kpad
+    PROF(a.mode == A_CONV3 ? PC_CONV : PC_GEMM, 2.0 * M * w.N * w.K, 0, launch_gemm(e->prec, 0, a, w.w, M, w.N, Kl, w.Kpad, ep, st));
+    return D2S_OK;
 }
 
 #define RC(x) do { int _rc = (x); if (_rc != D2S_OK) return _rc; } while (0)
@@ -227,33 +255,32 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     const int D = d.hidden, N = e->N, P = e->P, M = B * N, Mp = B * P, prec = e->prec;
     const int F = d.fusion;
     // ---- embeddings (HF Dinov2Embeddings)
-    RC(launch_patchify(prec, x, e->patchA, B, e->h, e->w, d.patch, e->patch.Kpad, st));
+    PROF(PC_ELT, 0, 0, launch_patchify(prec, x, e->patchA, B, e->h, e->w, d.patch, e->patch.Kpad, st));
     {
         GemmEpi ep = rowsE(e->resid, OUT_F32, D, e->patch.bias);
         ep.rows_per_img = P; ep.img_rows = N; ep.row_off = 1;
         ep.res1 = e->pos; ep.res1_mod = P; ep.res1_off = 1;
-        GemmA a = plainA(e->patchA, e->patch.Kpad);
-        RC(launch_gemm(prec, 0, a, e->patch.w, Mp, D, e->patch.Kpad, e->patch.Kpad, ep, st));
+        RC(gemm(e, plainA(e->patchA, e->patch.Kpad), e->patch, Mp, ep, st));
     }
-    RC(launch_cls_rows(e->cls, e->pos, e->resid, B, N, D, st));
+    PROF(PC_ELT, 0, 0, launch_cls_rows(e->cls, e->pos, e->resid, B, N, D, st));
     if (e->taps) D2S_HIP(hipMemcpyAsync(e->tap_hidden, e->resid, (size_t)N * D * 4, hipMemcpyDeviceToDevice, st));
     // ---- encoder (HF Dinov2Layer x L)
     int tap_i = 0;
     for (int l = 0; l < d.layers; ++l) {
         const Layer& ly = e->L[l];
-        RC(launch_layernorm(prec, e->resid, ly.ln1g, ly.ln1b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st));
+        PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln1g, ly.ln1b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st));
         {
             GemmEpi ep = rowsE(e->qkv, OUT_T, 3 * D, ly.qkv.bias);
             ep.map = MAP_QKV; ep.vt = e->vt; ep.ntok = N; ep.npad = e->Npad; ep.qk_cols = 2 * D; ep.heads = d.heads;
             RC(gemm(e, plainA(e->lnbuf, D), ly.qkv, M, ep, st));
         }
-        RC(launch_attention(prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st));
+        PROF(PC_ATTN, 4.0 * B * d.heads * (double)N * N * 64, 0, launch_attention(prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st));
         {
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.proj.bias);
             ep.scale = ly.ls1; ep.res1 = e->resid;
             RC(gemm(e, plainA(e->attn, D), ly.proj, M, ep, st));
         }
-        RC(launch_layernorm(prec, e->resid, ly.ln2g, ly.ln2b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st));
+        PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln2g, ly.ln2b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st));
         {
             GemmEpi ep = rowsE(e->mlp, OUT_T, d.mlp, ly.fc1.bias);
             ep.act = ACT_GELU;
@@ -266,7 +293,7 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         }
         if (e->taps) D2S_HIP(hipMemcpyAsync(e->tap_hidden + (size_t)(l + 1) * N * D, e->resid, (size_t)N * D * 4, hipMemcpyDeviceToDevice, st));
         if (tap_i < 4 && l + 1 == d.out_indices[tap_i]) {     // HF Dinov2Backbone: shared final LN, drop cls
-            RC(launch_layernorm(prec, e->resid, e->lnfg, e->lnfb, e->tapbuf[tap_i], Mp, D, d.ln_eps, P, N, 1, st));
+            PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, e->lnfg, e->lnfb, e->tapbuf[tap_i], Mp, D, d.ln_eps, P, N, 1, st));
             ++tap_i;
         }
     }
@@ -307,16 +334,16 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         RC(conv3(e, X, B, Hc, Wc, F, 1, 1, e->fu[idx].r2c2, Z, ACT_NONE, hcur, nullptr, st));
         int Ho, Wo;
         if (idx < 3) { Ho = e->fH[mi - 1]; Wo = e->fW[mi - 1]; } else { Ho = Hc * 2; Wo = Wc * 2; }
-        RC(launch_bilinear_nhwc(prec, Z, X, B, Hc, Wc, Ho, Wo, F, st));
+        PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, Z, X, B, Hc, Wc, Ho, Wo, F, st));
         void* pout = e->scr[3 + (idx & 1)];
         RC(gemm(e, plainA(X, F), e->fu[idx].proj, B * Ho * Wo, rowsE(pout, OUT_T, F, e->fu[idx].proj.bias), st));
         fused = pout; Hc = Ho; Wc = Wo;
     }
     // ---- head (HF DepthAnythingDepthEstimationHead)
     RC(conv3(e, fused, B, Hc, Wc, F, 1, 0, e->head1, X, ACT_NONE, nullptr, nullptr, st));
-    RC(launch_bilinear_nhwc(prec, X, Y, B, Hc, Wc, e->h, e->w, F / 2, st));
+    PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, X, Y, B, Hc, Wc, e->h, e->w, F / 2, st));
     RC(conv3(e, Y, B, e->h, e->w, F / 2, 1, 0, e->head2, Z, ACT_RELU, nullptr, nullptr, st));
-    RC(launch_head_final(prec, Z, e->w3, e->b3, depth, (long)B * e->h * e->w, d.head_hidden, st));
+    PROF(PC_ELT, 0, 0, launch_head_final(prec, Z, e->w3, e->b3, depth, (long)B * e->h * e->w, d.head_hidden, st));
     e->last_batch = B;
     return D2S_OK;
 }
@@ -499,15 +526,21 @@ extern "C" int d2s_pipeline(d2s_engine* e, const uint8_t* frames, int batch, int
     if (stride < 1) stride = 1;
     hipStream_t st = (hipStream_t)stream;
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};   // depth.py:1798-1799
-    RC(d2s_preprocess(frames, D2S_FMT_U8_HWC, batch, H, W, e->pre_x, e->h, e->w, stride, mean, stdv, stream));
+    PROF(PC_PRE, 0, (double)batch * ((double)H * W * 3 + (double)e->h * e->w * 12), d2s_preprocess(frames, D2S_FMT_U8_HWC, batch, H, W, e->pre_x, e->h, e->w, stride, mean, stdv, stream));
     RC(forward(e, e->pre_x, e->depth_small, batch, st));
-    RC(d2s_post_process(e->depth_small, batch, e->h, e->w, pp, e->post_ws, e->post_ws_bytes, stream));
+    PROF(PC_POST, 0, 0, d2s_post_process(e->depth_small, batch, e->h, e->w, pp, e->post_ws, e->post_ws_bytes, stream));
     if (use_ema) {
         RC(ema_batch(e->depth_small, e->ema_state, e->ema_init, batch, e->h * e->w, pp->ema_alpha, st));
         e->ema_init = 1;
     }
     if (depth_full) RC(d2s_upsample_depth(e->depth_small, batch, e->h, e->w, depth_full, H, W, stream));
-    RC(d2s_make_sbs(frames, D2S_FMT_U8_HWC, e->depth_small, e->h, e->w, batch, H, W, sp, out, out_fmt, stream));
+    {
+        int oh = 0, ow = 0;
+        RC(d2s_sbs_shape(H, W, sp, &oh, &ow));
+        double obytes = (double)oh * ow * 3 * (out_fmt == D2S_FMT_U8_HWC ? 1 : 4);
+        PROF(PC_WARP, 0, batch * ((double)H * W * 3 + (double)e->h * e->w * 4 + obytes),
+             d2s_make_sbs(frames, D2S_FMT_U8_HWC, e->depth_small, e->h, e->w, batch, H, W, sp, out, out_fmt, stream));
+    }
     return D2S_OK;
 }
 
@@ -536,3 +569,27 @@ extern "C" int d2s_engine_tap(d2s_engine* e, const char* name, float* out, uint6
     set_error("unknown tap: " + n);
     return D2S_E_INVALID;
 }
+
+extern "C" int d2s_engine_profile(d2s_engine* e, int enable) {
+    D2S_REQUIRE(e, "null engine");
+    e->prof_on = enable != 0;
+    e->prof_recs.clear();
+    e->prof_used = 0;
+    return D2S_OK;
+}
+
+extern "C" int d2s_engine_profile_read(d2s_engine* e, int max_classes, double* ms, double* flops, double* bytes,
+                                       int64_t* launches, int* n_classes) {
+    D2S_REQUIRE(e && ms && flops && bytes && launches && n_classes && max_classes >= PC_N, "bad argument");
+    for (int c = 0; c < PC_N; ++c) { ms[c] = 0; flops[c] = 0; bytes[c] = 0; launches[c] = 0; }
+    for (auto& r : e->prof_recs) {
+        D2S_HIP(hipEventSynchronize(r.b));
+        float t = 0.f;
+        D2S_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.cls] += t; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes; launches[r.cls] += 1;
+    }
+    *n_classes = PC_N;
+    return D2S_OK;
+}
+
+extern "C" const char* d2s_profile_class_name(int cls) { return cls >= 0 && cls < PC_N ? PC_NAMES[cls] : ""; }

@@ -183,6 +183,19 @@ class Engine:
         check(self.lib.d2s_engine_tap(self._h, name.encode(), _ptr(buf), n, C.byref(rows), C.byref(cols), _stream()), "d2s_engine_tap")
         return buf[: rows.value * cols.value].view(rows.value, cols.value)
 
+    def profile(self, enable: bool):
+        """Start (and clear) / stop HIP-event timing around every kernel launch."""
+        check(self.lib.d2s_engine_profile(self._h, int(enable)), "d2s_engine_profile")
+
+    def profile_read(self) -> Dict[str, dict]:
+        n = 16
+        ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        nc = C.c_int()
+        check(self.lib.d2s_engine_profile_read(self._h, n, ms, fl, by, cnt, C.byref(nc)), "d2s_engine_profile_read")
+        return {self.lib.d2s_profile_class_name(i).decode(): {"ms": ms[i], "flops": fl[i], "bytes": by[i], "launches": cnt[i]}
+                for i in range(nc.value)}
+
     def reset_stream(self):
         check(self.lib.d2s_engine_reset_stream(self._h))
 

@@ -164,6 +164,16 @@ int d2s_pipeline(d2s_engine* e, const uint8_t* frames, int batch, int H, int W,
                  int use_ema, void* out, int out_fmt, float* depth_full, void* stream);
 int d2s_engine_reset_stream(d2s_engine* e);
 
+/* Per-kernel-class timing with HIP events on the launch stream (used by bench.py for the
+ * roofline figures; not part of the throughput path).  enable=1 clears the records and starts
+ * recording around every kernel launch of d2s_model_forward / d2s_pipeline; read() synchronises on
+ * the recorded events and returns per class: total milliseconds, algorithmic FLOPs, algorithmic
+ * bytes and launch count.  Arrays must hold >= 8 entries; class names via d2s_profile_class_name. */
+int d2s_engine_profile(d2s_engine* e, int enable);
+int d2s_engine_profile_read(d2s_engine* e, int max_classes, double* ms, double* flops, double* bytes,
+                            int64_t* launches, int* n_classes);
+const char* d2s_profile_class_name(int cls);
+
 /* Debug / parity taps: copy an internal activation (after the last d2s_model_forward) to a
  * caller device buffer as float32.  name: "embeddings", "layer<N>", "neck_feat<i>", "fused<i>".
  * rows/cols describe [rows, cols] of frame 0 (tokens x D, or pixels x C, NHWC). */
