@@ -20,6 +20,7 @@ namespace d2s {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers (HIP's u32x4 struct arrays went to scratch)
 
 template <typename T> struct AT;
 template <> struct AT<bf16_t> {
@@ -36,10 +37,10 @@ template <> struct AT<float> {
     __device__ static int key_of(int j, int i) { return j * 16 + i; }
 };
 
-__device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b, bf16_t) {
+__device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b, bf16_t) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, acc, 0, 0, 0);
 }
-__device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b, float) {
+__device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b, float) {
     const float* af = (const float*)&a;
     const float* bf = (const float*)&b;
 #pragma unroll
@@ -47,16 +48,16 @@ __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b
 }
 
 // pack the P values a lane group contributes to one V^T chunk
-__device__ __forceinline__ uint4 pack_p(const f32x4& lo, const f32x4& hi, bf16_t) {
-    uint4 r;
+__device__ __forceinline__ u32x4 pack_p(const f32x4& lo, const f32x4& hi, bf16_t) {
+    u32x4 r;
     r.x = (uint32_t)f2bf(lo[0]) | ((uint32_t)f2bf(lo[1]) << 16);
     r.y = (uint32_t)f2bf(lo[2]) | ((uint32_t)f2bf(lo[3]) << 16);
     r.z = (uint32_t)f2bf(hi[0]) | ((uint32_t)f2bf(hi[1]) << 16);
     r.w = (uint32_t)f2bf(hi[2]) | ((uint32_t)f2bf(hi[3]) << 16);
     return r;
 }
-__device__ __forceinline__ uint4 pack_p(const f32x4& lo, const f32x4&, float) {
-    uint4 r;
+__device__ __forceinline__ u32x4 pack_p(const f32x4& lo, const f32x4&, float) {
+    u32x4 r;
     r.x = __float_as_uint(lo[0]); r.y = __float_as_uint(lo[1]); r.z = __float_as_uint(lo[2]); r.w = __float_as_uint(lo[3]);
     return r;
 }
@@ -78,7 +79,7 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
     constexpr int TILE_CHUNKS = 64 * CPR;              // chunks in one 64-row tile
     constexpr int LPT = TILE_CHUNKS / 256;             // chunk loads per thread per tile (2 / 4)
     constexpr int BQ = 4 * QF * 16;
-    __shared__ __attribute__((aligned(16))) uint4 lds[2][2 * TILE_CHUNKS];   // [buf][K | V^T]
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2][2 * TILE_CHUNKS];   // [buf][K | V^T]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -90,7 +91,7 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
     const T* vbase = vt + ((long)b * heads + h) * 64 * Npad;
 
     // ---- Q fragments (B operand of S^T): Q[q][chunk ks*4+fg]
-    uint4 qf[QF][NKS];
+    u32x4 qf[QF][NKS];
     int qrow[QF];
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
@@ -98,7 +99,7 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
         bool ok = qrow[f] < N;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
-            qf[f][ks] = ok ? *(const uint4*)(qbase + (long)qrow[f] * row3 + (ks * 4 + fg) * CE) : make_uint4(0, 0, 0, 0);
+            qf[f][ks] = ok ? *(const u32x4*)(qbase + (long)qrow[f] * row3 + (ks * 4 + fg) * CE) : (u32x4){0u, 0u, 0u, 0u};
     }
 
     f32x4 o[QF][4];
@@ -110,15 +111,15 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
         for (int d = 0; d < 4; ++d) o[f][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    uint4 rk[LPT], rv[LPT];
+    u32x4 rk[LPT], rv[LPT];
     auto load_tile = [&](int t) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             int idx = tid + 256 * i;
             int r = idx / CPR, c = idx % CPR;
             int key = t * 64 + r;
-            rk[i] = key < N ? *(const uint4*)(kbase + (long)key * row3 + c * CE) : make_uint4(0, 0, 0, 0);
-            rv[i] = *(const uint4*)(vbase + (long)r * Npad + t * 64 + c * CE);     // r = d row, zero padded in memory
+            rk[i] = key < N ? *(const u32x4*)(kbase + (long)key * row3 + c * CE) : (u32x4){0u, 0u, 0u, 0u};
+            rv[i] = *(const u32x4*)(vbase + (long)r * Npad + t * 64 + c * CE);     // r = d row, zero padded in memory
         }
     };
     auto store_tile = [&](int buf) {
@@ -137,8 +138,8 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) load_tile(t + 1);
-        const uint4* Kl = lds[t & 1];
-        const uint4* Vl = lds[t & 1] + TILE_CHUNKS;
+        const u32x4* Kl = lds[t & 1];
+        const u32x4* Vl = lds[t & 1] + TILE_CHUNKS;
         // ---- S^T = K Q^T
         f32x4 s[QF][4];
 #pragma unroll
@@ -150,7 +151,7 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
             int kr = A::key_of(j, fr);
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                uint4 kf = Kl[kr * CPR + ((ks * 4 + fg) ^ A::swzK(kr))];
+                u32x4 kf = Kl[kr * CPR + ((ks * 4 + fg) ^ A::swzK(kr))];
 #pragma unroll
                 for (int f = 0; f < QF; ++f) mma16(s[f][j], kf, qf[f][ks], T());
             }
@@ -191,7 +192,7 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int pc = 0; pc < NKS; ++pc) {
-            uint4 pf[QF];
+            u32x4 pf[QF];
 #pragma unroll
             for (int f = 0; f < QF; ++f)
             {
@@ -201,7 +202,7 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 int vr = d * 16 + fr;
-                uint4 vf = Vl[vr * CPR + ((pc * 4 + fg) ^ A::swzV(vr))];
+                u32x4 vf = Vl[vr * CPR + ((pc * 4 + fg) ^ A::swzV(vr))];
 #pragma unroll
                 for (int f = 0; f < QF; ++f) mma16(o[f][d], vf, pf[f], T());
             }

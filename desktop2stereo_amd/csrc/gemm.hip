@@ -19,28 +19,29 @@ namespace d2s {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers (HIP's u32x4 struct arrays went to scratch)
 
 template <typename T> struct Prec;
 template <> struct Prec<bf16_t> { static constexpr int CE = 8; };   // elements per 16-byte chunk
 template <> struct Prec<float>  { static constexpr int CE = 4; };
 
-__device__ __forceinline__ uint4 relu_chunk(uint4 v, bf16_t) {
+__device__ __forceinline__ u32x4 relu_chunk(u32x4 v, bf16_t) {
     uint32_t* p = (uint32_t*)&v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { uint32_t m = ((p[i] >> 15) & 0x00010001u) * 0xffffu; p[i] &= ~m; }
     return v;
 }
-__device__ __forceinline__ uint4 relu_chunk(uint4 v, float) {
+__device__ __forceinline__ u32x4 relu_chunk(u32x4 v, float) {
     float* p = (float*)&v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) p[i] = fmaxf(p[i], 0.f);
     return v;
 }
 
-__device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& w, const uint4& a, bf16_t) {
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& w, const u32x4& a, bf16_t) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w, *(const bf16x8*)&a, acc, 0, 0, 0);
 }
-__device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& w, const uint4& a, float) {
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& w, const u32x4& a, float) {
     const float* wf = (const float*)&w;
     const float* af = (const float*)&a;
 #pragma unroll
@@ -106,7 +107,7 @@ gemm_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, Gem
     constexpr int BK = 8 * CE;                 // 128-byte K tile
     constexpr int AI = BM / 32, BI = BN / 32;  // chunks per thread per tile
     constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave
-    __shared__ __attribute__((aligned(16))) uint4 lds[2][(BM + BN) * 8];
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2][(BM + BN) * 8];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wave_m = wid >> 1, wave_n = wid & 1;
@@ -132,38 +133,38 @@ gemm_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, Gem
     }
     const T* wrow = W + (long)(bn0 + lrow) * Kpad + lchunk * CE;
 
-    uint4 ra[AI], rb[BI];
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + lchunk * CE;
-        if (a.mode == A_PLAIN) {
-#pragma unroll
-            for (int i = 0; i < AI; ++i)
-                ra[i] = (aok[i] && k < K) ? *(const uint4*)(arow[i] + k) : make_uint4(0, 0, 0, 0);
-        } else {
-            int tap = k / a.C, c0 = k - tap * a.C;
-            int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-            for (int i = 0; i < AI; ++i) {
-                int iy = aiy[i] + ky, ix = aix[i] + kx;
-                bool ok = aok[i] && k < K && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
-                ra[i] = ok ? *(const uint4*)(arow[i] + ((long)iy * a.Wi + ix) * a.C + c0) : make_uint4(0, 0, 0, 0);
-            }
-        }
-        if (a.relu) {
-#pragma unroll
-            for (int i = 0; i < AI; ++i) ra[i] = relu_chunk(ra[i], T());
-        }
-#pragma unroll
-        for (int i = 0; i < BI; ++i) rb[i] = *(const uint4*)(wrow + (long)(32 * i) * Kpad + kt * BK);
-    };
-    auto store_tile = [&](int buf) {
-        uint4* A_l = lds[buf];
-        uint4* B_l = lds[buf] + BM * 8;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) { int r = lrow + 32 * i; A_l[r * 8 + (lchunk ^ ((r >> 1) & 7))] = ra[i]; }
-#pragma unroll
-        for (int i = 0; i < BI; ++i) { int r = lrow + 32 * i; B_l[r * 8 + (lchunk ^ ((r >> 1) & 7))] = rb[i]; }
-    };
+    u32x4 ra[AI], rb[BI];
+    // (macros, not lambdas: by-reference captures of the staging arrays end up in scratch)
+#define D2S_LOAD_TILE(KT)                                                                                        \
+    {                                                                                                            \
+        const int k_ = (KT) * BK + lchunk * CE;                                                                  \
+        if (a.mode == A_PLAIN) {                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                     \
+                u32x4 z_ = (u32x4){0u, 0u, 0u, 0u};                                                               \
+                if (aok[i] && k_ < K) z_ = *(const u32x4*)(arow[i] + k_);                                        \
+                ra[i] = z_;                                                                                      \
+            }                                                                                                    \
+        } else {                                                                                                 \
+            int tap_ = k_ / a.C, c0_ = k_ - tap_ * a.C;                                                          \
+            int ky_ = tap_ / 3, kx_ = tap_ - ky_ * 3;                                                            \
+            _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                     \
+                int iy_ = aiy[i] + ky_, ix_ = aix[i] + kx_;                                                      \
+                u32x4 z_ = (u32x4){0u, 0u, 0u, 0u};                                                               \
+                if (aok[i] && k_ < K && iy_ >= 0 && iy_ < a.Hi && ix_ >= 0 && ix_ < a.Wi)                        \
+                    z_ = *(const u32x4*)(arow[i] + ((long)iy_ * a.Wi + ix_) * a.C + c0_);                        \
+                ra[i] = z_;                                                                                      \
+            }                                                                                                    \
+        }                                                                                                        \
+        if (a.relu) { _Pragma("unroll") for (int i = 0; i < AI; ++i) ra[i] = relu_chunk(ra[i], T()); }           \
+        _Pragma("unroll") for (int i = 0; i < BI; ++i) rb[i] = *(const u32x4*)(wrow + (long)(32 * i) * Kpad + (KT) * BK); \
+    }
+#define D2S_STORE_TILE(BUF)                                                                                      \
+    {                                                                                                            \
+        u32x4* A_s = lds[BUF];                                                                                   \
+        u32x4* B_s = lds[BUF] + BM * 8;                                                                          \
+        _Pragma("unroll") for (int i = 0; i < AI; ++i) { int r = lrow + 32 * i; A_s[r * 8 + (lchunk ^ ((r >> 1) & 7))] = ra[i]; } \
+        _Pragma("unroll") for (int i = 0; i < BI; ++i) { int r = lrow + 32 * i; B_s[r * 8 + (lchunk ^ ((r >> 1) & 7))] = rb[i]; } \
+    }
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -172,17 +173,17 @@ gemm_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, Gem
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nkt = Kpad / BK;
-    load_tile(0);
-    store_tile(0);
+    D2S_LOAD_TILE(0)
+    D2S_STORE_TILE(0)
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        const uint4* A_l = lds[kt & 1] + (wave_m * (BM / 2)) * 8;
-        const uint4* B_l = lds[kt & 1] + BM * 8 + (wave_n * (BN / 2)) * 8;
+        if (kt + 1 < nkt) D2S_LOAD_TILE(kt + 1)
+        const u32x4* A_l = lds[kt & 1] + (wave_m * (BM / 2)) * 8;
+        const u32x4* B_l = lds[kt & 1] + BM * 8 + (wave_n * (BN / 2)) * 8;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 fa[FM], fb[FN];
+            u32x4 fa[FM], fb[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i) { int r = i * 16 + fr; fa[i] = A_l[r * 8 + ((ks * 4 + fg) ^ ((r >> 1) & 7))]; }
 #pragma unroll
@@ -192,7 +193,7 @@ gemm_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, Gem
 #pragma unroll
                 for (int j = 0; j < FN; ++j) mma_chunk(acc[i][j], fb[j], fa[i], T());
         }
-        if (kt + 1 < nkt) store_tile((kt + 1) & 1);
+        if (kt + 1 < nkt) D2S_STORE_TILE((kt + 1) & 1)
         __syncthreads();
     }
 

@@ -1,0 +1,190 @@
+"""Drop-in call surface of the reference's ``depth.py`` for the hot path, backed by libd2s_hip.so.
+
+Same names, argument meaning and return conventions as the reference (callers: reference
+main.py:44, 244, 249, 1321, 1340):
+
+    process(img, height)                                              reference depth.py:540-629
+    predict_depth(image_rgb, return_tuple=False, use_temporal_smooth=True, dtype=None)   :1897-2025
+    make_sbs(rgb_c, depth, ipd_uv=0.064, depth_ratio=2.0, convergence=0.0,
+             fill_16_9=False, display_mode="Half-SBS", fps=None)      :2186-2231
+    make_sbs_core(rgb, depth, ipd_uv, depth_ratio, display_mode, fill_16_9, convergence, device)  :2122-2184
+    post_process_depth / DepthStabilizer / depth_stabilizer           :806-814, 1865-1889
+plus ``predict`` / ``to_stereo`` (the names BASELINE.json's north_star uses) and the batched
+``pipeline``.  Differences from the reference, all deliberate:
+
+  * the module is configured explicitly (``configure``) instead of reading settings.yaml and
+    building the model at import time (reference depth.py:1784; utils.py:635);
+  * every computation is a HIP kernel behind the C-ABI; if the library or a GPU is missing the
+    call raises -- there is no eager-PyTorch fallback (the reference degrades silently,
+    depth.py:1597-1631);
+  * BGR(A)->RGB ``process`` keeps only the channel swizzle + optional area down-scale contract
+    for uint8 frames (the capture side is out of scope).
+"""
+from __future__ import annotations
+
+from threading import Lock
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .config import MODELS, MODEL_IDS, ModelConfig, PipelineParams, engine_shape
+
+_state = {"cfg": None, "weights": None, "params": PipelineParams(), "precision": "bf16", "device": 0,
+          "engine": None, "engine_key": None, "max_batch": 1}
+lock = Lock()                         # one-time engine build (reference depth.py:1838-1862)
+
+
+def configure(model="vitb", weights: Optional[Dict[str, np.ndarray]] = None, params: Optional[PipelineParams] = None,
+              precision: str = "bf16", device: int = 0, max_batch: int = 1, seed: int = 0):
+    """Select model / weights / constants (what settings.yaml + utils.py do in the reference).
+    `model`: "vits" | "vitb" | "vitl" | "tiny" | a reference MODEL_ID | a ModelConfig.
+    `weights`: HF-keyed float arrays, a path to model.safetensors, or None (seeded synthetic)."""
+    from .weights import load_safetensors, make_weights
+    cfg = model if isinstance(model, ModelConfig) else MODELS[MODEL_IDS.get(model, model)]
+    if weights is None:
+        weights = make_weights(cfg, seed)
+    elif isinstance(weights, str):
+        weights = load_safetensors(weights, cfg)
+    with lock:
+        if _state["engine"] is not None:
+            _state["engine"].close()
+        _state.update(cfg=cfg, weights=weights, params=params or PipelineParams(), precision=precision, device=device,
+                      engine=None, engine_key=None, max_batch=max_batch)
+    depth_stabilizer.prev = None
+
+
+def _device() -> torch.device:
+    return torch.device("cuda", _state["device"])
+
+
+def _ensure_engine_built(engine_h: int, engine_w: int) -> ops.Engine:
+    """Build the native engine on the first frame, once its shape is known (reference depth.py:1842-1862)."""
+    if _state["cfg"] is None:
+        raise _lib.D2SError("desktop2stereo_amd.depth.configure(...) has not been called")
+    key = (engine_h, engine_w)
+    if _state["engine"] is not None and _state["engine_key"] == key:
+        return _state["engine"]
+    with lock:
+        if _state["engine"] is not None and _state["engine_key"] == key:
+            return _state["engine"]
+        if _state["engine"] is not None:
+            _state["engine"].close()
+        _state["engine"] = ops.Engine(_state["cfg"], _state["weights"], engine_h, engine_w, _state["max_batch"],
+                                      _state["precision"], _state["device"])
+        _state["engine_key"] = key
+    return _state["engine"]
+
+
+def process(img, height: int):
+    """BGR(A) -> RGB, optional down-scale to `height` rows (reference depth.py:570-629, numpy path).
+    Only the uint8 numpy swizzle is provided host-side; frames normally arrive as RGB already."""
+    a = np.asarray(img)
+    rgb = np.ascontiguousarray(a[..., 2::-1] if a.shape[-1] >= 3 else a)
+    h0, w0 = rgb.shape[:2]
+    if height < h0:
+        raise _lib.D2SError("process(): OUTPUT_RESOLUTION down-scaling is outside the implemented hot path (SURVEY.md 8f4)")
+    return rgb
+
+
+class DepthStabilizer:
+    """EMA of the model-resolution depth across frames (reference depth.py:1865-1887); state on device."""
+
+    def __init__(self, alpha=0.9):
+        self.alpha = alpha
+        self.prev = None
+        self.enabled = True
+        self.lock = Lock()
+
+    def __call__(self, depth: torch.Tensor):
+        if not self.enabled:
+            return depth
+        with self.lock:
+            fresh = self.prev is None or self.prev.shape != depth.shape or self.prev.device != depth.device
+            if fresh:
+                self.prev = torch.empty_like(depth)
+            ops.ema_update(depth, self.prev, not fresh, self.alpha)
+            return depth if fresh else self.prev
+
+
+depth_stabilizer = DepthStabilizer(alpha=0.9)
+
+
+def post_process_depth(depth: torch.Tensor) -> torch.Tensor:
+    """normalize -> gamma -> foreground scale -> anti-alias (reference depth.py:806-814)."""
+    return ops.post_process_depth(depth, _state["params"])
+
+
+def predict_depth(image_rgb, return_tuple=False, use_temporal_smooth: bool = True, dtype=None):
+    """HWC uint8 RGB numpy frame or CHW tensor (0..255) -> [H,W] float32 depth in [0,1] on the
+    compute device, near ~ 1 (reference depth.py:1897-2025)."""
+    p = _state["params"]
+    if isinstance(image_rgb, torch.Tensor):
+        rgb_tensor = image_rgb.to(device=_device())
+        h, w = rgb_tensor.shape[1:]
+        src = rgb_tensor if rgb_tensor.dtype in (torch.uint8, torch.float32) else rgb_tensor.float()
+    else:
+        h, w = image_rgb.shape[:2]
+        hwc = torch.from_numpy(np.ascontiguousarray(image_rgb)).to(device=_device(), non_blocking=True)
+        rgb_tensor = hwc.permute(2, 0, 1)
+        src = hwc
+    x = ops.preprocess(src, p.depth_resolution, _state["cfg"].patch if _state["cfg"] else 14, p.mean, p.std)
+    eng = _ensure_engine_built(x.shape[2], x.shape[3])
+    depth = eng(x)
+    depth = ops.post_process_depth(depth, p)[0]
+    if use_temporal_smooth:
+        depth = depth_stabilizer(depth)
+    depth = ops.upsample_depth(depth, h, w)
+    return (depth, rgb_tensor) if return_tuple else depth
+
+
+def make_sbs_core(rgb: torch.Tensor, depth: torch.Tensor, ipd_uv=0.064, depth_ratio=2.0, display_mode="Half-SBS",
+                  fill_16_9=False, convergence=0.0, device=None) -> torch.Tensor:
+    """rgb [C,H,W] float (0..255), depth [H,W] -> [C,H',W'] float32 0..255 (reference depth.py:2122-2184)."""
+    sp = ops.sbs_params(ipd_uv, depth_ratio, convergence, display_mode, fill_16_9)
+    rgb = rgb.to(device=_device())
+    if rgb.dtype != torch.uint8:
+        rgb = rgb.float()
+    return ops.make_sbs(rgb, depth.to(device=_device()), sp, _lib.FMT_F32_CHW)
+
+
+def make_sbs(rgb_c, depth, ipd_uv=0.064, depth_ratio=2.0, convergence=0.0, fill_16_9=False, display_mode="Half-SBS", fps=None):
+    """-> HWC float32 numpy 0..255, like the reference (depth.py:2186-2231).  `fps` overlay is not
+    part of the hot path (reference depth.py:2061-2103) and is rejected rather than ignored."""
+    if fps is not None:
+        raise _lib.D2SError("make_sbs(fps=...) overlay is outside the implemented hot path")
+    if isinstance(depth, np.ndarray):
+        depth = torch.from_numpy(depth)
+    depth = depth.to(device=_device())
+    if isinstance(rgb_c, np.ndarray):
+        rgb = torch.from_numpy(np.ascontiguousarray(rgb_c)).to(device=_device())       # HWC uint8 / float
+        if rgb.dtype != torch.uint8:
+            rgb = rgb.float().permute(2, 0, 1).contiguous()
+    else:
+        rgb = rgb_c.to(device=_device())
+        if rgb.dtype != torch.uint8:
+            rgb = rgb.float()
+    sp = ops.sbs_params(ipd_uv, depth_ratio, convergence, display_mode, fill_16_9)
+    return ops.make_sbs(rgb, depth, sp, _lib.FMT_F32_HWC).cpu().numpy()
+
+
+def pipeline(frames, display_mode=None, use_temporal_smooth=False, out_u8=True, want_depth=False):
+    """Batched predict_depth + make_sbs: uint8 [B,H,W,3] (numpy or device tensor) -> device tensor
+    [B,H',W',3] (uint8, or float32 when out_u8=False) in one stream-ordered native call."""
+    p = _state["params"]
+    t = torch.from_numpy(np.ascontiguousarray(frames)) if isinstance(frames, np.ndarray) else frames
+    t = t.to(device=_device())
+    B, H, W, _ = t.shape
+    h, w, _s = engine_shape(H, W, p.depth_resolution, _state["cfg"].patch)
+    if B > _state["max_batch"]:
+        raise _lib.D2SError(f"batch {B} > configured max_batch {_state['max_batch']}")
+    eng = _ensure_engine_built(h, w)
+    sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, display_mode or p.display_mode, p.fill_16_9)
+    return eng.pipeline(t, p, sp, use_ema=use_temporal_smooth, out_fmt=_lib.FMT_U8_HWC if out_u8 else _lib.FMT_F32_HWC,
+                        want_depth=want_depth)
+
+
+# names used by BASELINE.json's north_star
+predict = predict_depth
+to_stereo = make_sbs
