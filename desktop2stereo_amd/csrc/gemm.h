@@ -38,14 +38,14 @@ struct GemmEpi {
     void* vt; int ntok, npad, qk_cols, heads;
 };
 
-// precision: D2S_PREC_FP32 (T = float) / D2S_PREC_BF16 (T = bf16).  tile: 0 = auto, 64, 128.
+// precision: D2S_PREC_FP32 (T = float) / D2S_PREC_BF16 (T = bf16).  tile: 0 = auto, 64, 128, 256128, 256256.
 int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad,
                 const GemmEpi& e, hipStream_t st);
 
 // packed-weight geometry
 static inline int gemm_bk(int precision) { return precision == D2S_PREC_BF16 ? 64 : 32; }   // 128-byte K tile
 static inline int gemm_kpad(int K, int precision) { int bk = gemm_bk(precision); return (K + bk - 1) / bk * bk; }
-static inline int gemm_npad(int N) { return (N + 127) / 128 * 128; }
+static inline int gemm_npad(int N) { return (N + 255) / 256 * 256; }
 static inline size_t elem_size(int precision) { return precision == D2S_PREC_BF16 ? 2 : 4; }
 
 }  // namespace d2s

@@ -14,6 +14,7 @@
 //    convolution over an NHWC activation, with optional ReLU-on-load (pre-activation units);
 //  * double-buffered LDS, register-staged prefetch of the next K tile, one barrier per tile.
 #include "gemm.h"
+#include <type_traits>
 
 namespace d2s {
 
@@ -100,9 +101,28 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float
     store4((OT*)e.out + off, v);
 }
 
+// XCD-aware block -> tile map.  Workgroup b is dispatched to XCD b % 8 (observed, used for speed
+// only), each XCD has a private 4 MiB L2.  The 8 XCDs form an xn x (8/xn) grid over the tile space;
+// XCD (xi, xj) owns a rectangle of tiles and walks it m-slow / n-fast, so the blocks resident on one
+// XCD share a few W tiles (L2 hits) and each A tile is fetched from far memory once per XCD.
+// xn == 0: plain row-major order.  Returns false for surplus blocks of the padded grid.
+__device__ __forceinline__ bool tile_of_block(int bid, int tiles_m, int tiles_n, int xn, int& tm, int& tn) {
+    if (xn == 0) { tm = bid / tiles_n; tn = bid - tm * tiles_n; return true; }
+    const int xm = 8 / xn;
+    const int x = bid & 7, seq = bid >> 3;
+    const int xi = x % xn, xj = x / xn;
+    const int n0 = (tiles_n * xi) / xn, n1 = (tiles_n * (xi + 1)) / xn;
+    const int m0 = (tiles_m * xj) / xm, m1 = (tiles_m * (xj + 1)) / xm;
+    const int nl = n1 - n0, ml = m1 - m0;
+    if (seq >= nl * ml) return false;
+    const int q = seq / nl;
+    tm = m0 + q; tn = n0 + (seq - q * nl);
+    return true;
+}
+
 template <typename T, int BM, int BN>
 __global__ void __launch_bounds__(256)
-gemm_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e) {
+gemm_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
     constexpr int CE = Prec<T>::CE;
     constexpr int BK = 8 * CE;                 // 128-byte K tile
     constexpr int AI = BM / 32, BI = BN / 32;  // chunks per thread per tile
@@ -111,8 +131,9 @@ gemm_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, Gem
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wave_m = wid >> 1, wave_n = wid & 1;
-    const int tiles_n = (N + BN - 1) / BN;
-    const int bm0 = (blockIdx.x / tiles_n) * BM, bn0 = (blockIdx.x % tiles_n) * BN;
+    int tm_, tn_;
+    if (!tile_of_block(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, xn, tm_, tn_)) return;
+    const int bm0 = tm_ * BM, bn0 = tn_ * BN;
     const int lrow = tid >> 3, lchunk = tid & 7;
 
     // ---- per-thread A row descriptors (fixed across K tiles)
@@ -213,16 +234,228 @@ gemm_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, Gem
     }
 }
 
+
+// ================================================================================================
+// v2: LDS-DMA ring.  Same tile / fragment / epilogue design as gemm_kernel, but the K tiles travel
+// global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging VGPRs, no
+// ds_write pass) into a ring of NS stages, PD = NS-1 tiles ahead, with counted vmcnt and ONE raw
+// s_barrier per tile:
+//     wait my loads of tile t (vmcnt <= (PD-1) tiles in flight)  ->  s_barrier  (all loads of t
+//     landed AND everybody finished computing t-1)  ->  issue tile t+PD into the stage t-1 used
+//     ->  compute t.
+// LDS-DMA writes lane-linear (base + lane*16), so the XOR swizzle moves to the SOURCE address:
+// the lane that owns LDS slot (row r, phys chunk p) fetches global chunk p ^ ((r>>1)&7)
+// (cdna_hip_programming.md rule 21: linear dest + swizzled source + swizzled read).
+// Out-of-range rows / K tail / conv padding fetch from a zero page.  ReLU-on-load is applied when
+// the A fragments are read (v_pk_max_i16 for bf16).
+// ================================================================================================
+__device__ u32x4 d2s_zero_page[4];
+
+// max(x, floor) on a fragment: floor = 0 gives ReLU, floor = lowest gives identity (no branch in the MFMA stream).
+// bf16 as int16: sign bit set <=> negative, and positive bf16 order like positive int16 -> v_pk_max_i16.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32x4 relu_frag(u32x4 v, int floor_bits, bf16_t) {
+    s16x8 x = __builtin_bit_cast(s16x8, v);
+    short f = (short)floor_bits;
+    x = __builtin_elementwise_max(x, (s16x8){f, f, f, f, f, f, f, f});
+    return __builtin_bit_cast(u32x4, x);
+}
+__device__ __forceinline__ u32x4 relu_frag(u32x4 v, int floor_bits, float) {
+    f32x4 x = __builtin_bit_cast(f32x4, v);
+    float f = floor_bits == 0 ? 0.f : -3.0e38f;
+    x = __builtin_elementwise_max(x, (f32x4){f, f, f, f});
+    return __builtin_bit_cast(u32x4, x);
+}
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for_impl(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_impl<I + 1, N>(f); }
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+__global__ void __launch_bounds__(64 * WM * WN)
+gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
+    constexpr int CE = Prec<T>::CE;
+    constexpr int BK = 8 * CE;
+    constexpr int NW = WM * WN;                     // waves per block
+    constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);   // LDS-DMA instructions per thread per tile (A / W)
+    constexpr int LPT = AI + BI;
+    constexpr int FM = BM / WM / 16, FN = BN / WN / 16;   // 16x16 fragments per wave
+    constexpr int PD = NS - 1;
+    constexpr int STAGE = (BM + BN) * 8;            // chunks per stage
+    __shared__ __attribute__((aligned(16))) u32x4 lds[NS * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wid / WN, wave_n = wid % WN;
+    int tm_, tn_;
+    if (!tile_of_block(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, xn, tm_, tn_)) return;
+    const int bm0 = tm_ * BM, bn0 = tn_ * BN;
+    // this lane's slot inside a 64-slot wave-instruction: row (lane>>3) of 8, phys chunk lane&7;
+    // its source chunk is the same for every instruction i (rows differ by multiples of 32)
+    const int src_chunk = (lane & 7) ^ ((4 * wid + (lane >> 4)) & 7);
+    const T* zero = (const T*)d2s_zero_page;
+
+    const T* arow[AI];
+    int aiy[AI], aix[AI];
+    bool aok[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        int m = bm0 + (i * NW + wid) * 8 + (lane >> 3);
+        aok[i] = m < M;
+        int mm = aok[i] ? m : 0;
+        if (a.mode == A_PLAIN) { arow[i] = (const T*)a.ptr + (long)mm * a.lda; aiy[i] = aix[i] = 0; }
+        else {
+            int ox = mm % a.Wo, oy = (mm / a.Wo) % a.Ho, b = mm / (a.Wo * a.Ho);
+            aiy[i] = oy * a.stride - 1; aix[i] = ox * a.stride - 1;
+            arow[i] = (const T*)a.ptr + (long)b * a.Hi * a.Wi * a.C;
+        }
+    }
+    const T* wrow = W + (long)(bn0 + wid * 8 + (lane >> 3)) * Kpad + src_chunk * CE;
+    const float inv_c = a.mode == A_CONV3 ? 1.0f / (float)a.C : 0.f;
+
+#define D2S_GLDS(SRC, DST) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
+#define D2S_ISSUE_TILE(KT)                                                                                       \
+    {                                                                                                            \
+        u32x4* st_ = lds + ((KT) % NS) * STAGE;                                                                  \
+        const int k_ = (KT) * BK + src_chunk * CE;                                                               \
+        if (a.mode == A_PLAIN) {                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                     \
+                const T* s_ = (aok[i] && k_ < K) ? arow[i] + k_ : zero;                                          \
+                D2S_GLDS(s_, st_ + (i * NW + wid) * 64);                                                          \
+            }                                                                                                    \
+        } else {                                                                                                 \
+            int tap_ = (int)(((float)k_ + 0.5f) * inv_c);                                                        \
+            int c0_ = k_ - tap_ * a.C;                                                                           \
+            int ky_ = tap_ / 3, kx_ = tap_ - ky_ * 3;                                                            \
+            _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                     \
+                int iy_ = aiy[i] + ky_, ix_ = aix[i] + kx_;                                                      \
+                bool ok_ = aok[i] && k_ < K && iy_ >= 0 && iy_ < a.Hi && ix_ >= 0 && ix_ < a.Wi;                 \
+                const T* s_ = ok_ ? arow[i] + ((long)iy_ * a.Wi + ix_) * a.C + c0_ : zero;                       \
+                D2S_GLDS(s_, st_ + (i * NW + wid) * 64);                                                          \
+            }                                                                                                    \
+        }                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < BI; ++i)                                                           \
+            D2S_GLDS(wrow + (long)(8 * NW * i) * Kpad + (KT) * BK, st_ + BM * 8 + (i * NW + wid) * 64);               \
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = Kpad / BK;
+#pragma unroll
+    for (int t = 0; t < PD; ++t)
+        if (t < nkt) D2S_ISSUE_TILE(t)
+    const int fr = lane & 15, fg = lane >> 4;
+    const int relu_floor = a.relu ? 0 : -32768;
+    for (int kt = 0; kt < nkt; ++kt) {
+        // tiles kt .. min(kt+PD-1, nkt-1) are in flight; let all but tile kt stay in flight
+        if (kt + PD - 1 < nkt) wait_vmcnt<(PD - 1) * LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + PD < nkt) D2S_ISSUE_TILE(kt + PD)
+        const u32x4* A_l = lds + (kt % NS) * STAGE + (wave_m * (BM / WM)) * 8;
+        const u32x4* B_l = lds + (kt % NS) * STAGE + BM * 8 + (wave_n * (BN / WN)) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // W fragments stay live for the k-step; A fragments stream through one at a time
+            // (keeps the 8-wave 256-row tiles inside the 256-register budget)
+            u32x4 fb[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) { int r = j * 16 + fr; fb[j] = B_l[r * 8 + ((ks * 4 + fg) ^ ((r >> 1) & 7))]; }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                int r = i * 16 + fr;
+                u32x4 fa = A_l[r * 8 + ((ks * 4 + fg) ^ ((r >> 1) & 7))];
+                fa = relu_frag(fa, relu_floor, T());           // branch-free: floor = 0 (ReLU) or lowest (identity)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma_chunk(acc[i][j], fb[j], fa, T());
+            }
+        }
+    }
+#undef D2S_ISSUE_TILE
+#undef D2S_GLDS
+
+    // compile-time indices (a plain `#pragma unroll` over this large body is not honoured for the
+    // 32-fragment tiles, and a run-time index would put the accumulators in scratch)
+    static_for<FM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int m = bm0 + wave_m * (BM / WM) + i * 16 + fr;
+        if (m < M) {
+            static_for<FN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int n0 = bn0 + wave_n * (BN / WN) + j * 16 + fg * 4;
+                if (n0 < N) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v);
+                    else epilogue4<T>(e, m, n0, v);
+                }
+            });
+        }
+    });
+}
+
+// pick the XCD grid (xn x 8/xn) for a tiles_m x tiles_n tile space: least padding, W chunk within L2
+static int pick_xn(int tiles_m, int tiles_n, int BN, int Kpad, size_t es, unsigned& grid) {
+    static const int force = getenv("D2S_GEMM_XN") ? atoi(getenv("D2S_GEMM_XN")) : -1;
+    long total = (long)tiles_m * tiles_n;
+    if (force == 0 || total < 16) { grid = (unsigned)total; return 0; }
+    int best = 0; double best_score = 1e30; long best_grid = total;
+    for (int xn = 1; xn <= 8; xn *= 2) {
+        if (force > 0 && xn != force) continue;
+        int xm = 8 / xn;
+        long g = 8L * cdiv(tiles_n, xn) * cdiv(tiles_m, xm);
+        double score = (double)(g - total) / (double)total;
+        double wbytes = (double)cdiv(tiles_n, xn) * BN * Kpad * es;
+        if (wbytes > 2.5e6) score += 0.5 * (wbytes / 2.5e6);
+        if (score < best_score) { best_score = score; best = xn; best_grid = g; }
+    }
+    grid = (unsigned)best_grid;
+    return best;
+}
+
+// tile codes: 64 (64x64), 128 (128x128), 256128 / 256256 (8 waves), 25664 / 25632 (256 x 64|32, 4 waves); 0 = auto
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
+    unsigned grid = 0;
+    int xn = pick_xn(cdiv(M, BM), cdiv(N, BN), BN, Kpad, sizeof(T), grid);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS>), dim3(grid), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn);
+}
+
 template <typename T>
 static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
-    if (tile == 0) tile = ((long)cdiv(M, 128) * cdiv(N, 128) >= 192) ? 128 : 64;
-    if (tile == 128) {
-        dim3 grid((unsigned)((long)cdiv(M, 128) * cdiv(N, 128)));
-        hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e);
-    } else if (tile == 64) {
-        dim3 grid((unsigned)((long)cdiv(M, 64) * cdiv(N, 64)));
-        hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), grid, dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e);
-    } else { set_error("launch_gemm: tile must be 0, 64 or 128"); return D2S_E_INVALID; }
+    static const bool v1 = getenv("D2S_GEMM_V1") && atoi(getenv("D2S_GEMM_V1")) != 0;
+    static const int force_tile = getenv("D2S_GEMM_TILE") ? atoi(getenv("D2S_GEMM_TILE")) : 0;
+    if (tile == 0) tile = force_tile;
+    if (tile == 0) {
+        // 256-row tiles (intensity >= 85 flop/byte of L2 traffic) once they fill the chip, with the
+        // N extent matched to the layer (DPT head: 64 / 32 output channels); 64x64 otherwise.
+        int bn = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
+        long blocks = (long)cdiv(M, 256) * cdiv(N, bn);
+        if (blocks >= 224) tile = bn == 128 ? 256128 : (bn == 64 ? 25664 : 25632);
+        else tile = 64;
+    }
+    if (v1 && (tile == 128 || tile == 64)) {
+        unsigned grid = 0;
+        if (tile == 128) { int xn = pick_xn(cdiv(M, 128), cdiv(N, 128), 128, Kpad, sizeof(T), grid);
+            hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), dim3(grid), dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn); }
+        else { int xn = pick_xn(cdiv(M, 64), cdiv(N, 64), 64, Kpad, sizeof(T), grid);
+            hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), dim3(grid), dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn); }
+    }
+    else if (tile == 256256) launch_glds<T, 256, 256, 2, 4, 2>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 256128) launch_glds<T, 256, 128, 4, 2, 3>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 25664) launch_glds<T, 256, 64, 4, 1, 3>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 25632) launch_glds<T, 256, 32, 4, 1, 3>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 128) launch_glds<T, 128, 128, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 64) launch_glds<T, 64, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
+    else { set_error("launch_gemm: bad tile code"); return D2S_E_INVALID; }
     D2S_CHECK_LAUNCH();
     return D2S_OK;
 }
