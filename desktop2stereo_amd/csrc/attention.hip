@@ -70,15 +70,16 @@ __device__ __forceinline__ void store_o4(bf16_t* p, const float v[4]) {
     *(uint2*)p = t;
 }
 
-template <typename T, int QF>
-__global__ void __launch_bounds__(256)
+template <typename T, int QF, int NW>
+__global__ void __launch_bounds__(64 * NW)
 attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restrict__ out,
                  int N, int Npad, int heads, float scale_log2e) {
     using A = AT<T>;
     constexpr int CE = A::CE, CPR = A::CPR, NKS = A::NKS;
     constexpr int TILE_CHUNKS = 64 * CPR;              // chunks in one 64-row tile
-    constexpr int LPT = TILE_CHUNKS / 256;             // chunk loads per thread per tile (2 / 4)
-    constexpr int BQ = 4 * QF * 16;
+    constexpr int NT = 64 * NW;                        // threads per block
+    constexpr int LPT = TILE_CHUNKS / NT;              // chunk loads per thread per tile
+    constexpr int BQ = NW * QF * 16;
     __shared__ __attribute__((aligned(16))) u32x4 lds[2][2 * TILE_CHUNKS];   // [buf][K | V^T]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -115,7 +116,7 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
     auto load_tile = [&](int t) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            int idx = tid + 256 * i;
+            int idx = tid + NT * i;
             int r = idx / CPR, c = idx % CPR;
             int key = t * 64 + r;
             rk[i] = key < N ? *(const u32x4*)(kbase + (long)key * row3 + c * CE) : (u32x4){0u, 0u, 0u, 0u};
@@ -125,7 +126,7 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            int idx = tid + 256 * i;
+            int idx = tid + NT * i;
             int r = idx / CPR, c = idx % CPR;
             lds[buf][r * CPR + (c ^ A::swzK(r))] = rk[i];
             lds[buf][TILE_CHUNKS + r * CPR + (c ^ A::swzV(r))] = rv[i];
@@ -230,20 +231,21 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
 
 int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B, int N, int Npad, int heads, hipStream_t st) {
     const float scale_log2e = 0.125f * 1.4426950408889634f;          // 64^-0.5 * log2(e)
-    // 64-row q tiles (QF=1) when the grid would otherwise leave CUs idle
-    long blocks128 = (long)cdiv(N, 128) * heads * B;
+    // q rows per block: 128 (4 waves x 2 fragments) when that still fills the chip, else 64, else 32
+    static const int force = getenv("D2S_ATTN_BQ") ? atoi(getenv("D2S_ATTN_BQ")) : 0;
+    long hb = (long)heads * B;
+    int bq = force ? force : (cdiv(N, 128) * hb >= 512 ? 128 : 64);       // (32-row blocks measured slower: K/V tile loads not amortised)
+#define D2S_ATT(TT, QF_, NW_) hipLaunchKernelGGL((attention_kernel<TT, QF_, NW_>), dim3(cdiv(N, NW_ * QF_ * 16), heads, B), dim3(64 * NW_), 0, st, \
+        (const TT*)qkv, (const TT*)vt, (TT*)out, N, Npad, heads, scale_log2e)
     if (prec == D2S_PREC_BF16) {
-        if (blocks128 >= 512) {
-            dim3 grid(cdiv(N, 128), heads, B);
-            hipLaunchKernelGGL((attention_kernel<bf16_t, 2>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, N, Npad, heads, scale_log2e);
-        } else {
-            dim3 grid(cdiv(N, 64), heads, B);
-            hipLaunchKernelGGL((attention_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, N, Npad, heads, scale_log2e);
-        }
+        if (bq == 128) D2S_ATT(bf16_t, 2, 4);
+        else if (bq == 64) D2S_ATT(bf16_t, 1, 4);
+        else D2S_ATT(bf16_t, 1, 2);
     } else {
-        dim3 grid(cdiv(N, 64), heads, B);
-        hipLaunchKernelGGL((attention_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)qkv, (const float*)vt, (float*)out, N, Npad, heads, scale_log2e);
+        if (bq >= 64) D2S_ATT(float, 1, 4);
+        else D2S_ATT(float, 1, 2);
     }
+#undef D2S_ATT
     D2S_CHECK_LAUNCH();
     return D2S_OK;
 }

@@ -44,7 +44,7 @@ int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, i
 
 // packed-weight geometry
 static inline int gemm_bk(int precision) { return precision == D2S_PREC_BF16 ? 64 : 32; }   // 128-byte K tile
-static inline int gemm_kpad(int K, int precision) { int bk = gemm_bk(precision); return (K + bk - 1) / bk * bk; }
+static inline int gemm_kpad(int K, int precision) { int bk = 2 * gemm_bk(precision); return (K + bk - 1) / bk * bk; }   // 256-byte multiple
 static inline int gemm_npad(int N) { return (N + 255) / 256 * 256; }
 static inline size_t elem_size(int precision) { return precision == D2S_PREC_BF16 ? 2 : 4; }
 

@@ -275,17 +275,21 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS>
+// chunk XOR for a row of CPR chunks: conflict-free ds_read_b128 for 128-byte (CPR 8) and 256-byte (CPR 16) rows
+template <int CPR> __device__ __forceinline__ int swz_row(int r) { return CPR == 8 ? ((r >> 1) & 7) : (r & 15); }
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR>
 __global__ void __launch_bounds__(64 * WM * WN)
 gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
     constexpr int CE = Prec<T>::CE;
-    constexpr int BK = 8 * CE;
+    constexpr int BK = CPR * CE;                    // K tile: CPR 16-byte chunks per row (8 -> 128 B, 16 -> 256 B)
+    constexpr int RPI = 64 / CPR;                   // rows covered by one 1-KiB LDS-DMA wave-instruction
     constexpr int NW = WM * WN;                     // waves per block
-    constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);   // LDS-DMA instructions per thread per tile (A / W)
+    constexpr int AI = BM / (RPI * NW), BI = BN / (RPI * NW);   // LDS-DMA instructions per thread per tile (A / W)
     constexpr int LPT = AI + BI;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;   // 16x16 fragments per wave
     constexpr int PD = NS - 1;
-    constexpr int STAGE = (BM + BN) * 8;            // chunks per stage
+    constexpr int STAGE = (BM + BN) * CPR;          // chunks per stage
     __shared__ __attribute__((aligned(16))) u32x4 lds[NS * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -294,9 +298,12 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     int tm_, tn_;
     if (!tile_of_block(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, xn, tm_, tn_)) return;
     const int bm0 = tm_ * BM, bn0 = tn_ * BN;
-    // this lane's slot inside a 64-slot wave-instruction: row (lane>>3) of 8, phys chunk lane&7;
-    // its source chunk is the same for every instruction i (rows differ by multiples of 32)
-    const int src_chunk = (lane & 7) ^ ((4 * wid + (lane >> 4)) & 7);
+    // this lane's slot inside a 64-slot wave-instruction: row lane/CPR of RPI, phys chunk lane%CPR;
+    // its source chunk is the same for every instruction i (rows differ by multiples of RPI*NW,
+    // which the row swizzle's period divides)
+    static_assert((RPI * NW) % 16 == 0, "row swizzle must be invariant across a thread's instructions");
+    const int lrow = wid * RPI + lane / CPR;
+    const int src_chunk = (lane % CPR) ^ swz_row<CPR>(lrow);
     const T* zero = (const T*)d2s_zero_page;
 
     const T* arow[AI];
@@ -304,7 +311,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     bool aok[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        int m = bm0 + (i * NW + wid) * 8 + (lane >> 3);
+        int m = bm0 + i * NW * RPI + lrow;
         aok[i] = m < M;
         int mm = aok[i] ? m : 0;
         if (a.mode == A_PLAIN) { arow[i] = (const T*)a.ptr + (long)mm * a.lda; aiy[i] = aix[i] = 0; }
@@ -314,7 +321,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
             arow[i] = (const T*)a.ptr + (long)b * a.Hi * a.Wi * a.C;
         }
     }
-    const T* wrow = W + (long)(bn0 + wid * 8 + (lane >> 3)) * Kpad + src_chunk * CE;
+    const T* wrow = W + (long)(bn0 + lrow) * Kpad + src_chunk * CE;
     const float inv_c = a.mode == A_CONV3 ? 1.0f / (float)a.C : 0.f;
 
 #define D2S_GLDS(SRC, DST) \
@@ -340,7 +347,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
             }                                                                                                    \
         }                                                                                                        \
         _Pragma("unroll") for (int i = 0; i < BI; ++i)                                                           \
-            D2S_GLDS(wrow + (long)(8 * NW * i) * Kpad + (KT) * BK, st_ + BM * 8 + (i * NW + wid) * 64);               \
+            D2S_GLDS(wrow + (long)(RPI * NW * i) * Kpad + (KT) * BK, st_ + BM * CPR + (i * NW + wid) * 64);               \
     }
 
     f32x4 acc[FM][FN];
@@ -349,7 +356,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = Kpad / BK;
+    const int nkt = (K + BK - 1) / BK;
 #pragma unroll
     for (int t = 0; t < PD; ++t)
         if (t < nkt) D2S_ISSUE_TILE(t)
@@ -361,19 +368,19 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kt + PD < nkt) D2S_ISSUE_TILE(kt + PD)
-        const u32x4* A_l = lds + (kt % NS) * STAGE + (wave_m * (BM / WM)) * 8;
-        const u32x4* B_l = lds + (kt % NS) * STAGE + BM * 8 + (wave_n * (BN / WN)) * 8;
+        const u32x4* A_l = lds + (kt % NS) * STAGE + (wave_m * (BM / WM)) * CPR;
+        const u32x4* B_l = lds + (kt % NS) * STAGE + BM * CPR + (wave_n * (BN / WN)) * CPR;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < CPR / 4; ++ks) {
             // W fragments stay live for the k-step; A fragments stream through one at a time
             // (keeps the 8-wave 256-row tiles inside the 256-register budget)
             u32x4 fb[FN];
 #pragma unroll
-            for (int j = 0; j < FN; ++j) { int r = j * 16 + fr; fb[j] = B_l[r * 8 + ((ks * 4 + fg) ^ ((r >> 1) & 7))]; }
+            for (int j = 0; j < FN; ++j) { int r = j * 16 + fr; fb[j] = B_l[r * CPR + ((ks * 4 + fg) ^ swz_row<CPR>(r))]; }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 int r = i * 16 + fr;
-                u32x4 fa = A_l[r * 8 + ((ks * 4 + fg) ^ ((r >> 1) & 7))];
+                u32x4 fa = A_l[r * CPR + ((ks * 4 + fg) ^ swz_row<CPR>(r))];
                 fa = relu_frag(fa, relu_floor, T());           // branch-free: floor = 0 (ReLU) or lowest (identity)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) mma_chunk(acc[i][j], fb[j], fa, T());
@@ -422,11 +429,11 @@ static int pick_xn(int tiles_m, int tiles_n, int BN, int Kpad, size_t es, unsign
 }
 
 // tile codes: 64 (64x64), 128 (128x128), 256128 / 256256 (8 waves), 25664 / 25632 (256 x 64|32, 4 waves); 0 = auto
-template <typename T, int BM, int BN, int WM, int WN, int NS>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR = 8>
 static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
     unsigned grid = 0;
     int xn = pick_xn(cdiv(M, BM), cdiv(N, BN), BN, Kpad, sizeof(T), grid);
-    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS>), dim3(grid), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR>), dim3(grid), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn);
 }
 
 template <typename T>
@@ -440,7 +447,8 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
         int bn = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
         long blocks = (long)cdiv(M, 256) * cdiv(N, bn);
         if (blocks >= 224) tile = bn == 128 ? 256128 : (bn == 64 ? 25664 : 25632);
-        else tile = 64;
+        else if ((long)cdiv(M, 64) * cdiv(N, 64) >= 384) tile = 64;
+        else tile = 3264;                           // skinny launches (batch 1, N = 768): more, smaller blocks
     }
     if (v1 && (tile == 128 || tile == 64)) {
         unsigned grid = 0;
@@ -455,6 +463,10 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     else if (tile == 25632) launch_glds<T, 256, 32, 4, 1, 3>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 128) launch_glds<T, 128, 128, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 64) launch_glds<T, 64, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 3264) launch_glds<T, 32, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 6416) launch_glds<T, 64, 64, 2, 2, 3, 16>(a, W, M, N, K, Kpad, e, st);      // 256-byte K tiles
+    else if (tile == 326416) launch_glds<T, 32, 64, 2, 2, 3, 16>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 12812816) launch_glds<T, 128, 128, 2, 2, 2, 16>(a, W, M, N, K, Kpad, e, st);
     else { set_error("launch_gemm: bad tile code"); return D2S_E_INVALID; }
     D2S_CHECK_LAUNCH();
     return D2S_OK;
@@ -463,7 +475,7 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
 int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad,
                 const GemmEpi& e, hipStream_t st) {
     const int ce = precision == D2S_PREC_BF16 ? 8 : 4;
-    if (M <= 0 || N <= 0 || K <= 0 || (N & 3) || (K % ce) || Kpad % gemm_bk(precision)) {
+    if (M <= 0 || N <= 0 || K <= 0 || (N & 3) || (K % ce) || Kpad % (2 * gemm_bk(precision))) {
         set_error("launch_gemm: bad dims (N % 4, K % chunk, Kpad % BK)"); return D2S_E_INVALID;
     }
     if (a.mode == A_PLAIN && (a.lda % ce)) { set_error("launch_gemm: lda not chunk aligned"); return D2S_E_INVALID; }

@@ -20,33 +20,58 @@ __device__ __forceinline__ float key2f(uint32_t k) {
     return __uint_as_float(u);
 }
 
-// One block per frame: v = depth.flatten()[::step] (m <= cap values), bitonic sort in LDS,
-// bounds[b] = { s[tail-1], s[m-tail] }  (the tail-th smallest / largest).
+// One block per frame: v = depth.flatten()[::step] (m <= cap values, held in registers), then an exact
+// radix select (4 passes x 8 bits, LDS histograms) of the two order statistics
+//   bounds[b] = { s[tail-1], s[m-tail] }   (the tail-th smallest / largest; no lerp, depth.py:784-794).
 __global__ void __launch_bounds__(SORT_THREADS)
 percentile_bounds_kernel(const float* __restrict__ depth, int n, int step, int m, int tail,
                          float* __restrict__ bounds) {
-    __shared__ uint32_t keys[SORT_N];
+    constexpr int PER = SORT_N / SORT_THREADS;
+    __shared__ unsigned hist[2][256];
+    __shared__ unsigned sel_prefix[2], sel_rank[2];
     const float* d = depth + (long)blockIdx.x * n;
-    for (int i = threadIdx.x; i < SORT_N; i += SORT_THREADS)
-        keys[i] = i < m ? f2key(d[(long)i * step]) : 0xffffffffu;
-    __syncthreads();
-    for (int k = 2; k <= SORT_N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < SORT_N / 2; t += SORT_THREADS) {
-                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j cleared
-                int l = i | j;
-                bool up = ((i & k) == 0);
-                uint32_t a = keys[i], b = keys[l];
-                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
-            }
-            __syncthreads();
-        }
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t key[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { int idx = tid + i * SORT_THREADS; key[i] = idx < m ? f2key(d[(long)idx * step]) : 0u; }
+    if (tid == 0) {
+        bool all = tail >= m;                                   // depth.py:790-791: (min, max)
+        sel_rank[0] = all ? 0 : tail - 1; sel_rank[1] = all ? m - 1 : m - tail;
+        sel_prefix[0] = sel_prefix[1] = 0;
     }
-    if (threadIdx.x == 0) {
-        float lo, hi;
-        if (n <= 10) { lo = 0.f; hi = 0.f; }                                     // depth.py:852-854
-        else if (tail >= m) { lo = key2f(keys[0]); hi = key2f(keys[m - 1]); }    // depth.py:790-791
-        else { lo = key2f(keys[tail - 1]); hi = key2f(keys[m - tail]); }
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 512) hist[tid >> 8][tid & 255] = 0;
+        __syncthreads();
+        const unsigned p0 = sel_prefix[0], p1 = sel_prefix[1];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if (tid + i * SORT_THREADS < m) {
+                unsigned hi = pass == 0 ? 0u : key[i] >> (shift + 8);
+                unsigned bin = (key[i] >> shift) & 255u;
+                if (hi == p0) atomicAdd(&hist[0][bin], 1u);
+                if (hi == p1) atomicAdd(&hist[1][bin], 1u);
+            }
+        }
+        __syncthreads();
+        if (wid < 2) {                                           // wave r resolves rank r: 4 bins per lane
+            unsigned c0 = hist[wid][4 * lane], c1 = hist[wid][4 * lane + 1], c2 = hist[wid][4 * lane + 2], c3 = hist[wid][4 * lane + 3];
+            unsigned s = c0 + c1 + c2 + c3, incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            unsigned excl = incl - s, target = sel_rank[wid];
+            if (target >= excl && target < incl) {
+                unsigned r = target - excl, bin;
+                if (r < c0) bin = 0; else if ((r -= c0) < c1) bin = 1; else if ((r -= c1) < c2) bin = 2; else { r -= c2; bin = 3; }
+                sel_prefix[wid] = (sel_prefix[wid] << 8) | (4 * lane + bin);
+                sel_rank[wid] = r;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float lo = key2f(sel_prefix[0]), hi = key2f(sel_prefix[1]);
+        if (n <= 10) { lo = 0.f; hi = 0.f; }                     // depth.py:852-854
         bounds[2 * blockIdx.x] = lo;
         bounds[2 * blockIdx.x + 1] = hi;
     }

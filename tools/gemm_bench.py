@@ -12,7 +12,7 @@ def t_probe(A, W, prec, tile, iters):
     torch.cuda.synchronize(); return time.perf_counter() - t0
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, nargs="+", default=[1, 16]); ap.add_argument("--prec", default="bf16")
-ap.add_argument("--tiles", type=int, nargs="+", default=[64, 128, 256128, 256256])
+ap.add_argument("--tiles", type=int, nargs="+", default=[3264, 64, 326416, 6416])
 a = ap.parse_args()
 dev = torch.device("cuda")
 shapes = [("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]
@@ -24,4 +24,4 @@ for B in a.batch:
             t_probe(A, W, a.prec, tile, 3)
             n = 200 if B == 1 else 50
             dt = (t_probe(A, W, a.prec, tile, n + 1) - t_probe(A, W, a.prec, tile, 1)) / n
-            print(f"B={B:3d} {name:5s} M={M:6d} N={N:5d} K={K:5d} tile={tile:6d}: {dt*1e6:8.1f} us  {2*M*N*K/dt/1e12:7.1f} TF/s", flush=True)
+            print(f"B={B:3d} {name:5s} M={M:6d} N={N:5d} K={K:5d} tile={tile:8d}: {dt*1e6:8.1f} us  {2*M*N*K/dt/1e12:7.1f} TF/s", flush=True)
