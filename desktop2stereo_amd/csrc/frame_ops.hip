@@ -108,14 +108,18 @@ __device__ __forceinline__ float depth_at(const float* __restrict__ dep, const W
 }
 
 // reflect about [0, span] then clip (ATen grid_sampler reflect_coordinates, align_corners=True)
-__device__ __forceinline__ float reflect_clip(float x, float span) {
-    if (span <= 0.f) return 0.f;
-    x = fabsf(x);
-    if (x <= span) return x;                                   // common case: at most one reflection at 0
+__device__ __noinline__ float reflect_clip_slow(float x, float span) {         // |x| > 2*span: more than two reflections
     float extra = fmodf(x, span);
     int flips = (int)floorf(x / span);
     float r = (flips & 1) ? span - extra : extra;
     return fminf(fmaxf(r, 0.f), span);
+}
+__device__ __forceinline__ float reflect_clip(float x, float span) {
+    if (span <= 0.f) return 0.f;
+    x = fabsf(x);                                              // reflection at 0
+    if (x <= span) return x;                                   // common case
+    if (x <= 2.f * span) return span - (x - span);             // one reflection at span (= span - fmod(x, span), exact)
+    return reflect_clip_slow(x, span);
 }
 
 // one eye-plane sample: E(eye, y, x) for in-frame (y, x); sign = +1 left eye, -1 right eye
@@ -153,9 +157,14 @@ __device__ __forceinline__ void cat_sample(const void* __restrict__ rgb, long fo
     eye_sample<IN_FMT>(rgb, fo, dep, g, y, x, eye ? -1.0f : 1.0f, r, gg, b);
 }
 
-__device__ __forceinline__ uint8_t to_u8(float v) {
-    v = fminf(fmaxf(v, 0.f), 255.f);
-    return (uint8_t)__float2int_rn(v);                         // round-half-even, saturate
+// v_cvt_pk_u8_f32 = round-half-even + saturate to [0,255] + insert into byte `sel` (checked on gfx950 with
+// tools/ubench/cvt_test: 0.5->0, 1.5->2, 2.5->2, 255.5->255, 300->255, -5->0)
+__device__ __forceinline__ uint8_t to_u8(float v) { return (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(v, 0, 0); }
+__device__ __forceinline__ uint32_t pack4_u8(float a, float b, float c, float d) {
+    uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(a, 0, 0);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(b, 1, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(c, 2, r);
+    return __builtin_amdgcn_cvt_pk_u8_f32(d, 3, r);
 }
 
 // Generic kernel: one thread per output pixel, any alignment / padding / mode.
@@ -323,6 +332,193 @@ stereo_warp_fast(const uint8_t* __restrict__ rgb, const float* __restrict__ dept
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming version of the fast path (v2): persistent blocks walk (frame, row, tile) items with a
+// balanced grid; the NEXT item's source window and depth rows are prefetched into registers while
+// the current one is computed (global latency hidden, one barrier per item); the source window is
+// unpacked once into one RGBX dword per pixel in LDS, so a bilinear tap pair is two ds_read_b32
+// (+ v_cvt_f32_ubyteN) instead of six byte reads.
+// ------------------------------------------------------------------------------------------------
+constexpr int SW_LDS_PX = FP_TW + 2 * FP_MARGIN;       // 1152 pixels, multiple of 4
+constexpr int SW_GROUPS = SW_LDS_PX / 4;               // 12-byte groups of 4 pixels
+constexpr int SW_DN = (FP_TW + 8 + 255) / 256;         // depth-row values per thread
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
+                   int B, WarpGeom g) {
+    __shared__ __attribute__((aligned(16))) uint32_t spix[2][SW_LDS_PX];
+    __shared__ float drow[2][FP_TW + 8];
+    const int tid = threadIdx.x;
+    const int items = B * g.H;                            // rows of all frames
+    const float span = (float)(g.W - 1);
+    const long per = (long)g.out_h * g.out_w;
+
+    uint32_t pre[2][3];
+    float dpre[SW_DN], dpre2[SW_DN], dw0 = 0.f, dw1 = 0.f;   // prefetched depth rows (lerped when stored: no early wait)
+
+    // the column tile is fixed per block (blockIdx.y); items are rows (frame-major) strided by gridDim.x
+    const int xa = blockIdx.y * FP_TW;
+    const int wx0 = xa - FP_MARGIN < 0 ? 0 : xa - FP_MARGIN;
+    const int wx1 = xa + FP_TW + FP_MARGIN > g.W ? g.W : xa + FP_TW + FP_MARGIN;
+    const int xe = xa + FP_TW - 1 > g.W - 1 ? g.W - 1 : xa + FP_TW - 1;
+    const int dxa = linear_tap(xa, g.dsx, g.dw, false).i0;
+    const int dn = linear_tap(xe, g.dsx, g.dw, false).i1 - dxa + 1;
+    const int groups = (wx1 - wx0) >> 2;
+#define SW_DECODE(ITEM, b_, y_)                                                               \
+    const int b_ = (ITEM) / g.H;                                                              \
+    const int y_ = (ITEM) - b_ * g.H;
+
+#define SW_LOAD(ITEM)                                                                         \
+    {                                                                                         \
+        SW_DECODE(ITEM, lb, ly)                                                               \
+        const uint8_t* row_ = rgb + ((long)lb * g.H + ly) * (long)g.W * 3;                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
+            int gi = tid + 256 * j;                                                           \
+            if (gi < groups) {                                                                \
+                const uint32_t* q = (const uint32_t*)(row_ + (long)(wx0 + 4 * gi) * 3);       \
+                pre[j][0] = q[0]; pre[j][1] = q[1]; pre[j][2] = q[2];                         \
+            }                                                                                 \
+        }                                                                                     \
+        const float* dep_ = depth + (long)lb * g.dh * g.dw;                                   \
+        Tap ty_ = linear_tap(ly, g.dsy, g.dh, false);                                         \
+        dw0 = ty_.w0; dw1 = ty_.w1;                                                           \
+        _Pragma("unroll") for (int i = 0; i < SW_DN; ++i) {                                   \
+            int di = tid + 256 * i;                                                           \
+            if (di < dn) { dpre[i] = dep_[ty_.i0 * g.dw + dxa + di]; dpre2[i] = dep_[ty_.i1 * g.dw + dxa + di]; }   /* raw: lerp at store time */ \
+        }                                                                                     \
+    }
+#define SW_STORE(ITEM, BUF)                                                                   \
+    {                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
+            int gi = tid + 256 * j;                                                           \
+            if (gi < groups) {                                                                \
+                uint4 px_;                                                                    \
+                px_.x = pre[j][0];                                                            \
+                px_.y = __builtin_amdgcn_alignbyte(pre[j][1], pre[j][0], 3);                  \
+                px_.z = __builtin_amdgcn_alignbyte(pre[j][2], pre[j][1], 2);                  \
+                px_.w = pre[j][2] >> 8;                                                       \
+                *(uint4*)&spix[BUF][4 * gi] = px_;                                            \
+            }                                                                                 \
+        }                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < SW_DN; ++i) {                                   \
+            int di = tid + 256 * i;                                                           \
+            if (di < dn) drow[BUF][di] = dw0 * dpre[i] + dw1 * dpre2[i];                                            \
+        }                                                                                     \
+    }
+
+    int item = blockIdx.x;
+    if (item >= items) return;
+    SW_LOAD(item)
+    SW_STORE(item, 0)
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+        const int next = item + (int)gridDim.x;
+        const bool has = next < items;
+        if (has) SW_LOAD(next)
+        {
+            SW_DECODE(item, b, y)
+            const uint8_t* src_row = rgb + ((long)b * g.H + y) * (long)g.W * 3;
+            const int x_base = xa + tid * FP_PX;
+            if (x_base < g.W) {
+                float shift[FP_PX];
+#pragma unroll
+                for (int k = 0; k < FP_PX; ++k) {
+                    int x = x_base + k; if (x > g.W - 1) x = g.W - 1;
+                    Tap t = linear_tap(x, g.dsx, g.dw, false);
+                    float d = t.w0 * drow[buf][t.i0 - dxa] + t.w1 * drow[buf][t.i1 - dxa] - g.conv;
+                    shift[k] = ((-d * g.ratio) * g.max_px) * 0.05f;
+                }
+#pragma unroll
+                for (int eye = 0; eye < 2; ++eye) {
+                    float px[FP_PX][3];
+                    // branch-free coordinates (at most one reflection per side); one wave-level test
+                    // decides between the LDS taps and the rare generic path (shift beyond the staged
+                    // halo, or more than one reflection)
+                    float sxv[FP_PX];
+                    bool fast = true;
+#pragma unroll
+                    for (int k = 0; k < FP_PX; ++k) {
+                        float xr = fabsf((float)(x_base + k) + (eye ? -shift[k] : shift[k]));
+                        fast = fast && (xr <= 2.f * span);
+                        sxv[k] = xr <= span ? xr : span - (xr - span);
+                        int x0 = (int)sxv[k];
+                        fast = fast && (x0 >= wx0) && (x0 + 1 < wx1 || (x0 + 1 >= g.W && x0 < wx1));
+                    }
+                    if (fast) {
+#pragma unroll
+                        for (int k = 0; k < FP_PX; ++k) {
+                            int x0 = (int)sxv[k];
+                            float w1 = sxv[k] - (float)x0, w0 = 1.0f - w1;
+                            int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
+                            uint32_t p0 = spix[buf][x0 - wx0], p1 = spix[buf][x1 - wx0];   // (a planar-by-(x&3) layout measured no faster)
+                            px[k][0] = w0 * (float)(p0 & 0xffu) + w1 * (float)(p1 & 0xffu);
+                            px[k][1] = w0 * (float)((p0 >> 8) & 0xffu) + w1 * (float)((p1 >> 8) & 0xffu);
+                            px[k][2] = w0 * (float)((p0 >> 16) & 0xffu) + w1 * (float)((p1 >> 16) & 0xffu);
+                        }
+                    } else {
+                        for (int k = 0; k < FP_PX; ++k) {
+                            float sx = reflect_clip((float)(x_base + k) + (eye ? -shift[k] : shift[k]), span);
+                            int x0 = (int)sx;
+                            float w1 = sx - (float)x0, w0 = 1.0f - w1;
+                            int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
+                            const uint8_t* q0 = src_row + (long)x0 * 3; const uint8_t* q1 = src_row + (long)x1 * 3;
+                            for (int c = 0; c < 3; ++c) px[k][c] = w0 * (float)q0[c] + w1 * (float)q1[c];
+                        }
+                    }
+                    // values are convex combinations of bytes: already inside [0,255], round-half-even only
+                    if (x_base + FP_PX <= g.W) {
+                        if (MODE == D2S_MODE_FULL_SBS || MODE == D2S_MODE_FULL_TAB) {
+                            long row = (MODE == D2S_MODE_FULL_SBS) ? y : (long)eye * g.H + y;
+                            long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + x_base : x_base;
+                            // v_cvt_pk_u8_f32: round-half-even + saturate + byte insert in one instruction
+                            // (semantics checked on gfx950: tools/ubench/cvt_test)
+                            const float* f = &px[0][0];
+                            uint32_t* o = (uint32_t*)(out + (b * per + row * g.out_w + col) * 3);
+                            uint3 w3;
+                            w3.x = pack4_u8(f[0], f[1], f[2], f[3]);
+                            w3.y = pack4_u8(f[4], f[5], f[6], f[7]);
+                            w3.z = pack4_u8(f[8], f[9], f[10], f[11]);
+                            *(uint3*)o = w3;
+                        } else {  // HALF_SBS
+                            long col = ((long)eye * g.W + x_base) >> 1;
+                            uint16_t* o16 = (uint16_t*)(out + (b * per + (long)y * g.out_w + col) * 3);
+                            float h6[6];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) { h6[c] = (px[0][c] + px[1][c]) * 0.5f; h6[3 + c] = (px[2][c] + px[3][c]) * 0.5f; }
+                            uint32_t lo = pack4_u8(h6[0], h6[1], h6[2], h6[3]);
+                            uint32_t hi = pack4_u8(h6[4], h6[5], 0.f, 0.f);
+                            o16[0] = (uint16_t)lo; o16[1] = (uint16_t)(lo >> 16); o16[2] = (uint16_t)hi;
+                        }
+                    } else {
+                        for (int k = 0; k < FP_PX && x_base + k < g.W; ++k) {
+                            if (MODE == D2S_MODE_FULL_SBS || MODE == D2S_MODE_FULL_TAB) {
+                                long row = (MODE == D2S_MODE_FULL_SBS) ? y : (long)eye * g.H + y;
+                                long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + x_base + k : x_base + k;
+                                uint8_t* o = out + (b * per + row * g.out_w + col) * 3;
+                                for (int c = 0; c < 3; ++c) o[c] = to_u8(px[k][c]);
+                            } else if ((k & 1) == 0 && x_base + k + 1 < g.W) {
+                                long col = ((long)eye * g.W + x_base + k) >> 1;
+                                uint8_t* o = out + (b * per + (long)y * g.out_w + col) * 3;
+                                for (int c = 0; c < 3; ++c) o[c] = to_u8((px[k][c] + px[k + 1][c]) * 0.5f);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (has) SW_STORE(next, buf ^ 1)
+        __syncthreads();
+        if (!has) break;
+        item = next;
+        buf ^= 1;
+    }
+#undef SW_DECODE
+#undef SW_LOAD
+#undef SW_STORE
+}
+
 // Half-TAB fast path: thread = 4 source pixels x 2 rows (y, y+1 with even y); H even.
 __global__ void __launch_bounds__(256)
 stereo_warp_fast_halftab(const uint8_t* __restrict__ rgb, const float* __restrict__ depth,
@@ -469,7 +665,7 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
     hipStream_t st = (hipStream_t)stream;
     static const bool force_generic = getenv("D2S_WARP_GENERIC") && atoi(getenv("D2S_WARP_GENERIC")) != 0;
     bool nopad = (g.Hp == H && g.Wp == W);
-    bool fast_ok = !force_generic && rgb_fmt == D2S_FMT_U8_HWC && out_fmt == D2S_FMT_U8_HWC && nopad &&
+    bool fast_ok = !force_generic && rgb_fmt == D2S_FMT_U8_HWC && out_fmt == D2S_FMT_U8_HWC && nopad && ((long)batch * H * cdiv(W, FP_TW) < (1L << 30)) &&
                    (W % 4 == 0) && dw <= W && dh <= H && ((uintptr_t)rgb % 4 == 0) && ((uintptr_t)out % 4 == 0) &&
                    ((long)H * W * 3 % 4 == 0);
     if (fast_ok && g.mode == D2S_MODE_HALF_TAB && (H % 2 != 0)) fast_ok = false;
@@ -480,6 +676,18 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
             hipLaunchKernelGGL(stereo_warp_fast_halftab, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
         } else {
             dim3 grid((unsigned)((long)tiles_x * H * batch));
+            static const bool warp_v1 = getenv("D2S_WARP_V1") && atoi(getenv("D2S_WARP_V1")) != 0;
+            if (!warp_v1) {
+                long rows = (long)H * batch;
+                long rounds = (rows * tiles_x + 256 * 6 - 1) / (256 * 6);   // balanced persistent grid: every block walks `rounds` rows
+                dim3 pgrid((unsigned)((rows + rounds - 1) / rounds), tiles_x);
+                if (g.mode == D2S_MODE_FULL_SBS)
+                    hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+                else if (g.mode == D2S_MODE_FULL_TAB)
+                    hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+                else
+                    hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_HALF_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+            } else
             if (g.mode == D2S_MODE_FULL_SBS)
                 hipLaunchKernelGGL(stereo_warp_fast<D2S_MODE_FULL_SBS>, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
             else if (g.mode == D2S_MODE_FULL_TAB)
