@@ -464,6 +464,9 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     else if (tile == 128) launch_glds<T, 128, 128, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 64) launch_glds<T, 64, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 3264) launch_glds<T, 32, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 648) launch_glds<T, 64, 64, 2, 2, 8>(a, W, M, N, K, Kpad, e, st);           // 8-stage ring: 112 KB in flight per block
+    else if (tile == 32648) launch_glds<T, 32, 64, 2, 2, 8>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 646) launch_glds<T, 64, 64, 2, 2, 6>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 6416) launch_glds<T, 64, 64, 2, 2, 3, 16>(a, W, M, N, K, Kpad, e, st);      // 256-byte K tiles
     else if (tile == 326416) launch_glds<T, 32, 64, 2, 2, 3, 16>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 12812816) launch_glds<T, 128, 128, 2, 2, 2, 16>(a, W, M, N, K, Kpad, e, st);

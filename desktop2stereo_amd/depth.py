@@ -185,6 +185,38 @@ def pipeline(frames, display_mode=None, use_temporal_smooth=False, out_u8=True, 
                         want_depth=want_depth)
 
 
+def pipeline_mixed(frames_list, display_mode=None, out_u8=True):
+    """Mixed-resolution batch (BASELINE config 5): a list of uint8 HWC frames of different sizes whose
+    model-input shape is the same (every 16:9 frame maps to 294x518 at Depth Resolution 518, reference
+    depth.py:676-706).  Pre-process per frame size, ONE batched model + post-process pass over all frames,
+    then the warp per frame size.  Returns a list of device tensors in input order."""
+    p = _state["params"]
+    cfg = _state["cfg"]
+    dev = _device()
+    ts = [torch.from_numpy(np.ascontiguousarray(f)).to(dev) if isinstance(f, np.ndarray) else f.to(dev) for f in frames_list]
+    shapes = {engine_shape(t.shape[0], t.shape[1], p.depth_resolution, cfg.patch)[:2] for t in ts}
+    if len(shapes) != 1:
+        raise _lib.D2SError(f"pipeline_mixed: frames map to different model-input shapes {sorted(shapes)}")
+    h, w = shapes.pop()
+    if len(ts) > _state["max_batch"]:
+        raise _lib.D2SError(f"batch {len(ts)} > configured max_batch {_state['max_batch']}")
+    eng = _ensure_engine_built(h, w)
+    groups = {}
+    for i, t in enumerate(ts):
+        groups.setdefault(tuple(t.shape[:2]), []).append(i)
+    x = torch.empty((len(ts), 3, h, w), dtype=torch.float32, device=dev)
+    for (H, W), idx in groups.items():
+        x[idx] = ops.preprocess(torch.stack([ts[i] for i in idx]), p.depth_resolution, cfg.patch, p.mean, p.std)
+    depth = ops.post_process_depth(eng(x), p)
+    sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, display_mode or p.display_mode, p.fill_16_9)
+    out = [None] * len(ts)
+    for (H, W), idx in groups.items():
+        o = ops.make_sbs(torch.stack([ts[i] for i in idx]), depth[idx], sp, _lib.FMT_U8_HWC if out_u8 else _lib.FMT_F32_HWC)
+        for j, i in enumerate(idx):
+            out[i] = o[j]
+    return out
+
+
 # names used by BASELINE.json's north_star
 predict = predict_depth
 to_stereo = make_sbs

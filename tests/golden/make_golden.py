@@ -134,6 +134,8 @@ JOBS = {
     "vitb_r518": lambda o: gen_model("vitb", 518, [("S2", 1080, 1920, 0)], False, False, o),
     # the as-shipped CPU autocast (bf16) result, to report distance to it
     "vits_r518_bf16": lambda o: gen_model("vits", 518, [("S2", 1080, 1920, 0)], False, False, o, fp32=False),
+    # config 3 shapes: ViT-L, 3840x2160 frame (CPU branch decimates ::3 before the bilinear resize)
+    "vitl_r518_4k": lambda o: gen_model("vitl", 518, [("S2", 2160, 3840, 0)], False, False, o),
     "warp": gen_warp,
 }
 

@@ -74,3 +74,20 @@ def test_errors_are_loud(D):
         D.make_sbs(np.zeros((8, 8, 3), np.uint8), torch.zeros(8, 8), fps=60.0)
     with pytest.raises(_lib.D2SError):
         D.pipeline(np.zeros((5, 270, 480, 3), np.uint8))          # > max_batch
+
+
+def test_mixed_resolution_batch(D, orc):
+    """BASELINE config 5 shape logic at KAT size: 16:9 frames of three sizes share one model-input shape."""
+    from desktop2stereo_amd import synth
+    from oracle import d2s_oracle as O
+    sizes = [(270, 480), (180, 320), (360, 640), (270, 480)]
+    assert len({O.engine_shape(h, w, 140)[:2] for h, w in sizes}) == 1
+    frames = [synth.structured_frame(h, w, 20 + i) for i, (h, w) in enumerate(sizes)]
+    outs = D.pipeline_mixed(frames, display_mode="Half-SBS")
+    for f, o in zip(frames, outs):
+        assert tuple(o.shape) == f.shape and o.dtype == torch.uint8
+        d = orc.predict_depth(f)
+        want = O.to_u8(orc.make_sbs(f, d, ipd_uv=0.064, depth_ratio=4.0, display_mode="Half-SBS", fill_16_9=True))
+        # depth comes from the fp32 engine (<= 1e-3 of the oracle's): allow 1 LSB + rare 2-LSB flips on edges
+        diff = np.abs(o.cpu().numpy().astype(int) - want.astype(int))
+        assert diff.max() <= 2 and (diff > 1).mean() < 1e-3

@@ -250,7 +250,8 @@ def test_tiny_engine_bf16(dev, golden_dir):
 
 
 @pytest.mark.parametrize("name,model,res", [("tiny_r518", "tiny", 518), ("vits_r518", "vits", 518),
-                                            ("vits_r336", "vits", 336), ("vitb_r518", "vitb", 518)])
+                                            ("vits_r336", "vits", 336), ("vitb_r518", "vitb", 518),
+                                            ("vitl_r518_4k", "vitl", 518)])
 def test_full_size_predict_depth(dev, golden_dir, name, model, res):
     """1080p frame -> post-processed depth at model resolution, fp32 engine <= 1e-3 (parity gate),
     bf16 engine within the reference's own bf16-vs-fp32 class."""
