@@ -255,14 +255,13 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     const int D = d.hidden, N = e->N, P = e->P, M = B * N, Mp = B * P, prec = e->prec;
     const int F = d.fusion;
     // ---- embeddings (HF Dinov2Embeddings)
-    PROF(PC_ELT, 0, 0, launch_patchify(prec, x, e->patchA, B, e->h, e->w, d.patch, e->patch.Kpad, st));
+    PROF(PC_ELT, 0, 0, launch_patchify(prec, x, e->patchA, B, e->h, e->w, d.patch, e->patch.Kpad, e->cls, e->pos, e->resid, N, D, st));
     {
         GemmEpi ep = rowsE(e->resid, OUT_F32, D, e->patch.bias);
         ep.rows_per_img = P; ep.img_rows = N; ep.row_off = 1;
         ep.res1 = e->pos; ep.res1_mod = P; ep.res1_off = 1;
         RC(gemm(e, plainA(e->patchA, e->patch.Kpad), e->patch, Mp, ep, st));
     }
-    PROF(PC_ELT, 0, 0, launch_cls_rows(e->cls, e->pos, e->resid, B, N, D, st));
     if (e->taps) D2S_HIP(hipMemcpyAsync(e->tap_hidden, e->resid, (size_t)N * D * 4, hipMemcpyDeviceToDevice, st));
     // ---- encoder (HF Dinov2Layer x L)
     int tap_i = 0;
@@ -334,9 +333,11 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         RC(conv3(e, X, B, Hc, Wc, F, 1, 1, e->fu[idx].r2c2, Z, ACT_NONE, hcur, nullptr, st));
         int Ho, Wo;
         if (idx < 3) { Ho = e->fH[mi - 1]; Wo = e->fW[mi - 1]; } else { Ho = Hc * 2; Wo = Wc * 2; }
-        PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, Z, X, B, Hc, Wc, Ho, Wo, F, st));
+        // HF: projection(interpolate(h)).  The 1x1 projection (+bias) commutes with bilinear interpolation
+        // (interpolation weights sum to 1), so it runs BEFORE the up-sample on 4x fewer pixels.
         void* pout = e->scr[3 + (idx & 1)];
-        RC(gemm(e, plainA(X, F), e->fu[idx].proj, B * Ho * Wo, rowsE(pout, OUT_T, F, e->fu[idx].proj.bias), st));
+        RC(gemm(e, plainA(Z, F), e->fu[idx].proj, B * Hc * Wc, rowsE(X, OUT_T, F, e->fu[idx].proj.bias), st));
+        PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, X, pout, B, Hc, Wc, Ho, Wo, F, st));
         fused = pout; Hc = Ho; Wc = Wo;
     }
     // ---- head (HF DepthAnythingDepthEstimationHead)

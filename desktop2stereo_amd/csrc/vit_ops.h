@@ -4,7 +4,8 @@
 
 namespace d2s {
 
-int launch_patchify(int prec, const float* x, void* A, int B, int h, int w, int p, int Kp, hipStream_t st);
+int launch_patchify(int prec, const float* x, void* A, int B, int h, int w, int p, int Kp,
+                    const float* cls, const float* pos, float* resid, int N, int D, hipStream_t st);   // also writes the cls rows
 int launch_cls_rows(const float* cls, const float* pos, float* resid, int B, int N, int D, hipStream_t st);
 int launch_layernorm(int prec, const float* x, const float* g, const float* b, void* out, int rows_out, int D, float eps,
                      int rows_per_img, int img_rows, int row_off, hipStream_t st);

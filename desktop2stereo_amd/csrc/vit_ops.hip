@@ -16,10 +16,14 @@ __device__ __forceinline__ float tof(bf16_t v) { return bf2f(v); }
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-patchify_kernel(const float* __restrict__ x, T* __restrict__ A, int B, int h, int w, int p, int Kp) {
+patchify_kernel(const float* __restrict__ x, T* __restrict__ A, int B, int h, int w, int p, int Kp,
+                const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ resid, int N, int D) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int gh = h / p, gw = w / p, P = gh * gw;
     long total = (long)B * P * Kp;
+    // the cls-token row of every frame (cls + pos[0], HF Dinov2Embeddings.forward) rides along here:
+    // the patch-embed GEMM only writes rows 1..P of the residual stream
+    if (cls && idx < (long)B * D) { int b = (int)(idx / D), d = (int)(idx % D); resid[(long)b * N * D + d] = cls[d] + pos[d]; }
     if (idx >= total) return;
     int k = (int)(idx % Kp);
     int row = (int)(idx / Kp);
@@ -92,26 +96,32 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 bilinear_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo, int C,
                      float sy, float sx) {
+    // one thread = one output pixel x one 16-byte channel chunk (8 bf16 / 4 f32): 4 x 16-B tap loads, one 16-B store
+    constexpr int CE = 16 / sizeof(T);
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int c4 = C >> 2;
-    long total = (long)B * Ho * Wo * c4;
+    int cc = C / CE;
+    long total = (long)B * Ho * Wo * cc;
     if (idx >= total) return;
-    int c = (int)(idx % c4) * 4;
-    long pix = idx / c4;
+    int c = (int)(idx % cc) * CE;
+    long pix = idx / cc;
     int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
     Tap ty = linear_tap(oy, sy, Hi, true), tx = linear_tap(ox, sx, Wi, true);
     const T* base = in + (long)b * Hi * Wi * C + c;
-    const T* p00 = base + ((long)ty.i0 * Wi + tx.i0) * C;
-    const T* p01 = base + ((long)ty.i0 * Wi + tx.i1) * C;
-    const T* p10 = base + ((long)ty.i1 * Wi + tx.i0) * C;
-    const T* p11 = base + ((long)ty.i1 * Wi + tx.i1) * C;
-    T* o = out + pix * C + c;
+    u32x4 v00 = *(const u32x4*)(base + ((long)ty.i0 * Wi + tx.i0) * C);
+    u32x4 v01 = *(const u32x4*)(base + ((long)ty.i0 * Wi + tx.i1) * C);
+    u32x4 v10 = *(const u32x4*)(base + ((long)ty.i1 * Wi + tx.i0) * C);
+    u32x4 v11 = *(const u32x4*)(base + ((long)ty.i1 * Wi + tx.i1) * C);
+    const T *p00 = (const T*)&v00, *p01 = (const T*)&v01, *p10 = (const T*)&v10, *p11 = (const T*)&v11;
+    u32x4 r;
+    T* o = (T*)&r;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < CE; ++k) {
         float top = tx.w0 * tof(p00[k]) + tx.w1 * tof(p01[k]);
         float bot = tx.w0 * tof(p10[k]) + tx.w1 * tof(p11[k]);
         o[k] = cvt<T>(ty.w0 * top + ty.w1 * bot);
     }
+    *(u32x4*)(out + pix * C + c) = r;
 }
 
 template <typename T>
@@ -135,11 +145,13 @@ to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, long n) {
 
 #define DISPATCH_T(prec, CALL_BF, CALL_F32) do { if ((prec) == D2S_PREC_BF16) { CALL_BF; } else { CALL_F32; } } while (0)
 
-int launch_patchify(int prec, const float* x, void* A, int B, int h, int w, int p, int Kp, hipStream_t st) {
+int launch_patchify(int prec, const float* x, void* A, int B, int h, int w, int p, int Kp,
+                    const float* cls, const float* pos, float* resid, int N, int D, hipStream_t st) {
     long total = (long)B * (h / p) * (w / p) * Kp;
+    if (total < (long)B * D) total = (long)B * D;
     dim3 grid(cdiv(total, 256)), block(256);
-    DISPATCH_T(prec, hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, block, 0, st, x, (bf16_t*)A, B, h, w, p, Kp),
-                     hipLaunchKernelGGL(patchify_kernel<float>, grid, block, 0, st, x, (float*)A, B, h, w, p, Kp));
+    DISPATCH_T(prec, hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, block, 0, st, x, (bf16_t*)A, B, h, w, p, Kp, cls, pos, resid, N, D),
+                     hipLaunchKernelGGL(patchify_kernel<float>, grid, block, 0, st, x, (float*)A, B, h, w, p, Kp, cls, pos, resid, N, D));
     D2S_CHECK_LAUNCH();
     return D2S_OK;
 }
@@ -162,7 +174,9 @@ int launch_layernorm(int prec, const float* x, const float* g, const float* b, v
 
 int launch_bilinear_nhwc(int prec, const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t st) {
     float sy = linear_scale(Hi, Ho, true), sx = linear_scale(Wi, Wo, true);
-    long total = (long)B * Ho * Wo * (C / 4);
+    const int ce = prec == D2S_PREC_BF16 ? 8 : 4;
+    if (C % ce) { set_error("bilinear_nhwc: channels must be a multiple of the 16-byte chunk"); return D2S_E_INVALID; }
+    long total = (long)B * Ho * Wo * (C / ce);
     dim3 grid(cdiv(total, 256)), block(256);
     DISPATCH_T(prec, hipLaunchKernelGGL(bilinear_nhwc_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)in, (bf16_t*)out, B, Hi, Wi, Ho, Wo, C, sy, sx),
                      hipLaunchKernelGGL(bilinear_nhwc_kernel<float>, grid, block, 0, st, (const float*)in, (float*)out, B, Hi, Wi, Ho, Wo, C, sy, sx));
