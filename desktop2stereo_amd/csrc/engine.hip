@@ -59,6 +59,8 @@ struct d2s_engine {
     void* feat[4] = {nullptr, nullptr, nullptr, nullptr};
     int fH[4], fW[4];
     void* scr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* splitk_ws = nullptr;                    // fp32 partials for split-K launches (tiny-M, long-K DPT convs)
+    size_t splitk_elems = 0;
     // pipeline buffers
     float *pre_x = nullptr, *depth_small = nullptr;
     void* post_ws = nullptr;
@@ -234,7 +236,9 @@ GemmEpi rowsE(void* out, int out_type, long ldc, const float* bias) {
 
 int gemm(d2s_engine* e, const GemmA& a, const PackedW& w, int M, const GemmEpi& ep, hipStream_t st) {
     int Kl = w.K % (e->prec == D2S_PREC_BF16 ? 8 : 4) ? w.Kpad : w.K;   // ragged K (patch embed): A is zero padded to Kpad
-    PROF(a.mode == A_CONV3 ? PC_CONV : PC_GEMM, 2.0 * M * w.N * w.K, 0, launch_gemm(e->prec, 0, a, w.w, M, w.N, Kl, w.Kpad, ep, st));
+    GemmEpi ep2 = ep;
+    if (ep.map == MAP_ROWS) { ep2.part = e->splitk_ws; ep2.part_elems = e->splitk_elems; }   // launcher decides whether to split K
+    PROF(a.mode == A_CONV3 ? PC_CONV : PC_GEMM, 2.0 * M * w.N * w.K, 0, launch_gemm(e->prec, 0, a, w.w, M, w.N, Kl, w.Kpad, ep2, st));
     return D2S_OK;
 }
 
@@ -343,8 +347,21 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     // ---- head (HF DepthAnythingDepthEstimationHead)
     RC(conv3(e, fused, B, Hc, Wc, F, 1, 0, e->head1, X, ACT_NONE, nullptr, nullptr, st));
     PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, X, Y, B, Hc, Wc, e->h, e->w, F / 2, st));
-    RC(conv3(e, Y, B, e->h, e->w, F / 2, 1, 0, e->head2, Z, ACT_RELU, nullptr, nullptr, st));
-    PROF(PC_ELT, 0, 0, launch_head_final(prec, Z, e->w3, e->b3, depth, (long)B * e->h * e->w, d.head_hidden, st));
+    {
+        const int Mh = B * e->h * e->w, Nh = d.head_hidden;
+        const int bn = Nh <= 32 ? 32 : 64;
+        if (Nh <= 64 && (long)cdiv(Mh, 256) * cdiv(Nh, bn) >= 224) {
+            // conv2 + ReLU + conv3 (1x1 -> 1 channel) + ReLU in one launch (MAP_HEAD; needs the 256 x 32|64 tile,
+            // which launch_gemm's auto rule picks for exactly this shape)
+            GemmA a = convA(Y, e->h, e->w, F / 2, e->h, e->w, 1, 0);
+            GemmEpi ep = rowsE(depth, OUT_F32, 1, e->head2.bias);
+            ep.map = MAP_HEAD; ep.scale = e->w3; ep.head_b3 = e->b3;
+            PROF(PC_CONV, 2.0 * Mh * Nh * e->head2.K, 0, launch_gemm(prec, bn == 32 ? 25632 : 25664, a, e->head2.w, Mh, Nh, e->head2.K, e->head2.Kpad, ep, st));
+        } else {
+            RC(conv3(e, Y, B, e->h, e->w, F / 2, 1, 0, e->head2, Z, ACT_RELU, nullptr, nullptr, st));
+            PROF(PC_ELT, 0, 0, launch_head_final(prec, Z, e->w3, e->b3, depth, (long)B * e->h * e->w, d.head_hidden, st));
+        }
+    }
     e->last_batch = B;
     return D2S_OK;
 }
@@ -469,6 +486,8 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
     }
     size_t scr_elems = std::max({(size_t)64 * gh * gw * F, (size_t)h * w * (F / 2), (size_t)h * w * d.head_hidden}) * B;
     for (int i = 0; i < 5; ++i) RC(dev_alloc(e, &e->scr[i], scr_elems * es));
+    e->splitk_elems = (size_t)B * 16 * e->fH[2] * e->fW[2] * std::max(F, d.neck[3]);
+    RC(dev_alloc(e, (void**)&e->splitk_ws, e->splitk_elems * 4));
     RC(dev_alloc(e, (void**)&e->pre_x, (size_t)B * 3 * h * w * 4));
     RC(dev_alloc(e, (void**)&e->depth_small, (size_t)B * h * w * 4));
     e->post_ws_bytes = d2s_post_process_workspace(B, h, w);

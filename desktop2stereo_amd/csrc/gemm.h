@@ -7,7 +7,7 @@ namespace d2s {
 
 enum { A_PLAIN = 0, A_CONV3 = 1 };
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
-enum { MAP_ROWS = 0, MAP_SHUFFLE = 1, MAP_QKV = 2 };
+enum { MAP_ROWS = 0, MAP_SHUFFLE = 1, MAP_QKV = 2, MAP_HEAD = 3 };
 enum { OUT_T = 0, OUT_F32 = 1 };
 
 struct GemmA {
@@ -36,6 +36,10 @@ struct GemmEpi {
     // MAP_QKV: row-major [M, 3D] for q | k; the v third goes TRANSPOSED to vt[B, heads, 64, npad]
     // (m = b*ntok + t, n - 2D = h*64 + d) so the attention kernel reads V^T rows with 16-byte chunks.
     void* vt; int ntok, npad, qk_cols, heads;
+    // split-K workspace (optional): fp32 partials [ksplit][M][N]; ksplit is chosen by the launcher
+    float* part; size_t part_elems; int ksplit;
+    // MAP_HEAD: out = float depth[M]; bias = conv2 bias, scale = conv3 weights [N], head_b3 = conv3 bias
+    float head_b3;
 };
 
 // precision: D2S_PREC_FP32 (T = float) / D2S_PREC_BF16 (T = bf16).  tile: 0 = auto, 64, 128, 256128, 256256.

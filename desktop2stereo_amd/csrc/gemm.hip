@@ -339,7 +339,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
 #define D2S_ISSUE_TILE(KT)                                                                                       \
     {                                                                                                            \
         u32x4* st_ = lds + ((KT) % NS) * STAGE;                                                                  \
-        const int k_ = (KT) * BK + src_chunk * CE;                                                               \
+        const int k_ = ((KT) + kt0) * BK + src_chunk * CE;                                                       \
         if (a.mode == A_PLAIN) {                                                                                 \
             _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                     \
                 const T* s_ = (aok[i] && k_ < K) ? arow[i] + k_ : zero;                                          \
@@ -357,7 +357,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
             }                                                                                                    \
         }                                                                                                        \
         _Pragma("unroll") for (int i = 0; i < BI; ++i)                                                           \
-            D2S_GLDS(wrow + (long)(RPI * NW * i) * Kpad + (KT) * BK, st_ + BM * CPR + (i * NW + wid) * 64);               \
+            D2S_GLDS(wrow + (long)(RPI * NW * i) * Kpad + ((KT) + kt0) * BK, st_ + BM * CPR + (i * NW + wid) * 64);       \
     }
 
     f32x4 acc[FM][FN];
@@ -366,7 +366,11 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = (K + BK - 1) / BK;
+    // split-K (e.ksplit > 1): blockIdx.y owns a contiguous range of K tiles and writes raw fp32 partials
+    const int nkt_all = (K + BK - 1) / BK;
+    const int ksplit = e.ksplit > 1 ? e.ksplit : 1;
+    const int kt0 = (int)(((long)nkt_all * blockIdx.y) / ksplit);
+    const int nkt = (int)(((long)nkt_all * (blockIdx.y + 1)) / ksplit) - kt0;
 #pragma unroll
     for (int t = 0; t < PD; ++t)
         if (t < nkt) D2S_ISSUE_TILE(t)
@@ -400,6 +404,33 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
 #undef D2S_ISSUE_TILE
 #undef D2S_GLDS
 
+    // MAP_HEAD: the DPT head's tail fused into conv2 -- depth[m] = relu(b3 + sum_n w3[n] * relu(acc[m][n] + bias[n]))
+    // (HF DepthAnythingDepthEstimationHead: conv2 -> ReLU -> conv3 (1x1, C->1) -> ReLU).  One wave owns all N
+    // columns of its rows (WN == 1, N <= BN), so the channel sum is registers + two cross-lane-group shuffles.
+    if constexpr (WN == 1) {
+        if (e.map == MAP_HEAD) {
+            static_for<FM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const int m = bm0 + wave_m * (BM / WM) + i * 16 + fr;
+                float s = 0.f;
+                static_for<FN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const int n0 = j * 16 + fg * 4;
+                    if (n0 < N) {
+                        float b[4], w[4];
+                        load4(e.bias + n0, b); load4(e.scale + n0, w);
+                        s += fmaxf(acc[i][j][0] + b[0], 0.f) * w[0] + fmaxf(acc[i][j][1] + b[1], 0.f) * w[1] +
+                             fmaxf(acc[i][j][2] + b[2], 0.f) * w[2] + fmaxf(acc[i][j][3] + b[3], 0.f) * w[3];
+                    }
+                });
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                if (fg == 0 && m < M) ((float*)e.out)[m] = fmaxf(s + e.head_b3, 0.f);
+            });
+            return;
+        }
+    }
+
     // compile-time indices (a plain `#pragma unroll` over this large body is not honoured for the
     // 32-fragment tiles, and a run-time index would put the accumulators in scratch)
     static_for<FM>([&](auto ic) {
@@ -411,12 +442,31 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
                 const int n0 = bn0 + wave_n * (BN / WN) + j * 16 + fg * 4;
                 if (n0 < N) {
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v);
+                    if (ksplit > 1) store4(e.part + ((long)blockIdx.y * M + m) * N + n0, v);     // reduced by splitk_reduce_kernel
+                    else if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v);
                     else epilogue4<T>(e, m, n0, v);
                 }
             });
         }
     });
+}
+
+// split-K second pass: sum the fp32 partials of all splits and run the fused epilogue once
+template <typename T>
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(GemmEpi e, int M, int N) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int n4 = N >> 2;
+    if (idx >= (long)M * n4) return;
+    int m = (int)(idx / n4), n0 = (int)(idx % n4) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < e.ksplit; ++s) {
+        float p[4];
+        load4(e.part + ((long)s * M + m) * N + n0, p);
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+    }
+    if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v);
+    else epilogue4<T>(e, m, n0, v);
 }
 
 // pick the XCD grid (xn x 8/xn) for a tiles_m x tiles_n tile space: least padding, W chunk within L2
@@ -443,7 +493,22 @@ template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR = 8>
 static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
     unsigned grid = 0;
     int xn = pick_xn(cdiv(M, BM), cdiv(N, BN), BN, Kpad, sizeof(T), grid);
-    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR>), dim3(grid), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn);
+    // split-K for the few launches with almost no tiles but a long K loop (DPT 3x3 convs on the 11x19 /
+    // 21x37 maps with 768 input channels: 14-112 blocks x 108 K tiles): the caller provides e.part
+    int nkt = cdiv(K, CPR * (16 / (int)sizeof(T)));
+    int ks = 1;
+    if (e.part && e.part_elems > 0 && grid < 128 && nkt >= 24) {
+        ks = nkt / 6; if (ks > 16) ks = 16;
+        while (ks > 1 && (size_t)ks * M * N > e.part_elems) --ks;
+    }
+    if (ks > 1) {
+        GemmEpi e2 = e; e2.ksplit = ks;
+        hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR>), dim3(grid, ks), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e2, xn);
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(cdiv((long)M * (N / 4), 256)), dim3(256), 0, st, e2, M, N);
+        return;
+    }
+    GemmEpi e1 = e; e1.ksplit = 1;
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR>), dim3(grid), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn);
 }
 
 template <typename T>
