@@ -70,6 +70,8 @@ __device__ __forceinline__ void store_o4(bf16_t* p, const float v[4]) {
     *(uint2*)p = t;
 }
 
+__device__ u32x4 d2s_attn_zero_page[4];
+
 template <typename T, int QF, int NW>
 __global__ void __launch_bounds__(64 * NW)
 attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restrict__ out,
@@ -78,9 +80,9 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
     constexpr int CE = A::CE, CPR = A::CPR, NKS = A::NKS;
     constexpr int TILE_CHUNKS = 64 * CPR;              // chunks in one 64-row tile
     constexpr int NT = 64 * NW;                        // threads per block
-    constexpr int LPT = TILE_CHUNKS / NT;              // chunk loads per thread per tile
     constexpr int BQ = NW * QF * 16;
-    __shared__ __attribute__((aligned(16))) u32x4 lds[2][2 * TILE_CHUNKS];   // [buf][K | V^T]
+    constexpr int NS = 3, PD = NS - 1;                 // LDS ring stages / prefetch distance
+    __shared__ __attribute__((aligned(16))) u32x4 lds[NS * 2 * TILE_CHUNKS];   // [stage][K | V^T]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -112,35 +114,39 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
         for (int d = 0; d < 4; ++d) o[f][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    u32x4 rk[LPT], rv[LPT];
-    auto load_tile = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            int idx = tid + NT * i;
-            int r = idx / CPR, c = idx % CPR;
-            int key = t * 64 + r;
-            rk[i] = key < N ? *(const u32x4*)(kbase + (long)key * row3 + c * CE) : (u32x4){0u, 0u, 0u, 0u};
-            rv[i] = *(const u32x4*)(vbase + (long)r * Npad + t * 64 + c * CE);     // r = d row, zero padded in memory
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            int idx = tid + NT * i;
-            int r = idx / CPR, c = idx % CPR;
-            lds[buf][r * CPR + (c ^ A::swzK(r))] = rk[i];
-            lds[buf][TILE_CHUNKS + r * CPR + (c ^ A::swzV(r))] = rv[i];
-        }
-    };
+    // K / V^T tiles travel global -> LDS by LDS-DMA (1 KiB per wave-instruction = 64/CPR rows) into an NS-stage
+    // ring, PD tiles ahead, counted vmcnt + one raw barrier per tile (same scheme as gemm_glds_kernel).  The row
+    // XOR swizzles move to the source address: the lane owning LDS slot (row r, phys chunk p) fetches chunk p ^ swz(r).
+    constexpr int RPI = 64 / CPR;                       // rows per wave-instruction
+    constexpr int IPW = 64 / (RPI * NW);                // instructions per wave per operand tile
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
+    const T* zero = (const T*)d2s_attn_zero_page;
+#define ATT_GLDS(SRC, DST) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
+#define ATT_ISSUE(TT)                                                                                  \
+    {                                                                                                  \
+        u32x4* st_ = lds + ((TT) % NS) * 2 * TILE_CHUNKS;                                              \
+        _Pragma("unroll") for (int i = 0; i < IPW; ++i) {                                              \
+            const int r_ = (i * NW + wu) * RPI + lane / CPR, p_ = lane % CPR;                          \
+            const int key_ = (TT) * 64 + r_;                                                           \
+            const T* ks_ = key_ < N ? kbase + (long)key_ * row3 + (p_ ^ A::swzK(r_)) * CE : zero;      \
+            ATT_GLDS(ks_, st_ + (i * NW + wu) * 64);                                                   \
+            ATT_GLDS(vbase + (long)r_ * Npad + (TT) * 64 + (p_ ^ A::swzV(r_)) * CE, st_ + TILE_CHUNKS + (i * NW + wu) * 64); \
+        }                                                                                              \
+    }
+    constexpr int LPTA = 2 * IPW;                       // LDS-DMA instructions per thread per tile
 
     const int ntiles = (N + 63) / 64;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < PD; ++t)
+        if (t < ntiles) ATT_ISSUE(t)
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) load_tile(t + 1);
-        const u32x4* Kl = lds[t & 1];
-        const u32x4* Vl = lds[t & 1] + TILE_CHUNKS;
+        if (t + PD - 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPTA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + PD < ntiles) ATT_ISSUE(t + PD)
+        const u32x4* Kl = lds + (t % NS) * 2 * TILE_CHUNKS;
+        const u32x4* Vl = Kl + TILE_CHUNKS;
         // ---- S^T = K Q^T
         f32x4 s[QF][4];
 #pragma unroll
@@ -208,9 +214,9 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
                 for (int f = 0; f < QF; ++f) mma16(o[f][d], vf, pf[f], T());
             }
         }
-        if (t + 1 < ntiles) store_tile((t + 1) & 1);
-        __syncthreads();
     }
+#undef ATT_ISSUE
+#undef ATT_GLDS
     // ---- normalise and store: lane holds d = dfrag*16 + fg*4 + r for query fr
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
