@@ -13,6 +13,8 @@ Rank 0 prints ONE JSON line: the contract fields plus
                    (d2s_engine_profile) in a second pass over the same workload;
   kernels       -- the same numbers for every kernel class;
   roofline_warp -- the stereo-warp kernel against the HBM roofline;
+  batched       -- (N=1 only) the same pipeline at --also-batch frames per step (throughput regime:
+                   M = batch*778 tokens fills the chip), with its own roofline;
   cpu_baseline  -- the numpy oracle (a port of the reference's CPU path) on a bounded sample,
                    rank 0 at N=1 only.
 """
@@ -35,7 +37,6 @@ SURVEY_GF_PER_FRAME = {("vitb", 518): 176.9, ("vits", 518): 45.8, ("vitl", 518):
 
 def cpu_baseline(cfg, weights, p, H, W, mode, budget_s=15.0, max_frames=3):
     """The oracle (numpy port of the reference CPU path) timed on this host's cores."""
-    import numpy as np
     from desktop2stereo_amd import synth
     from oracle import d2s_oracle as O
     try:
@@ -58,12 +59,56 @@ def cpu_baseline(cfg, weights, p, H, W, mode, budget_s=15.0, max_frames=3):
             "host_cpus": os.cpu_count()}
 
 
+def profile_pass(eng, step, steps, B, precision):
+    """Second pass with HIP events around every kernel launch -> per-class table + roofline objects."""
+    import torch
+    eng.profile(True)
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    prof = eng.profile_read()
+    eng.profile(False)
+    nf = steps * B
+    kernels = {}
+    for name, r in prof.items():
+        if not r["launches"]:
+            continue
+        k = {"launches_per_step": r["launches"] / steps, "ms_per_step": r["ms"] / steps, "avg_launch_us": 1e3 * r["ms"] / r["launches"]}
+        if r["flops"]:
+            k["gflop_per_frame"] = r["flops"] / nf / 1e9
+            k["tflops"] = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            k["frac_of_mfma_peak"] = k["tflops"] / PEAK_TFLOPS[precision]
+        if r["bytes"]:
+            k["mb_per_frame"] = r["bytes"] / nf / 1e6
+            k["gbs"] = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+            k["frac_of_hbm_peak"] = k["gbs"] / PEAK_HBM_GBS
+        kernels[name] = k
+    out = {"kernels": kernels, "gpu_busy_ms_per_step": sum(k["ms_per_step"] for k in kernels.values())}
+    dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
+    kd = kernels[dom]
+    if "tflops" in kd:
+        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kd["tflops"], "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+                           "frac": kd["frac_of_mfma_peak"], "traffic": None,
+                           "flop_per_launch": 1e9 * kd["gflop_per_frame"] * B / kd["launches_per_step"], "avg_launch_us": kd["avg_launch_us"]}
+    else:
+        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kd.get("gbs"), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": kd.get("frac_of_hbm_peak"), "traffic": None, "avg_launch_us": kd["avg_launch_us"]}
+    if "stereo_warp" in kernels:
+        kw = kernels["stereo_warp"]
+        out["roofline_warp"] = {"kernel": "stereo_warp", "bound": "hbm", "achieved": kw["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": kw["frac_of_hbm_peak"], "traffic": None, "bytes_per_launch": 1e6 * kw["mb_per_frame"] * B,
+                                "avg_launch_us": kw["avg_launch_us"]}
+    out["model_gflop_per_frame_counted"] = sum(k.get("gflop_per_frame", 0.0) for k in kernels.values())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU (configs[1]: 1)")
+    ap.add_argument("--also-batch", type=int, default=16, help="extra batched measurement at N=1 (0 = off)")
     ap.add_argument("--model", default="vitb")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--res", type=int, default=518)
@@ -98,97 +143,78 @@ def main():
 
     cfg = MODELS[args.model]
     H, W, B = args.height, args.width, args.batch
+    B2 = args.also_batch if (world == 1 and args.also_batch > B) else 0
     p = PipelineParams(depth_resolution=args.res, display_mode=args.mode)
     h, w, _ = engine_shape(H, W, args.res)
     weights = make_weights(cfg, 0)
-    eng = ops.Engine(cfg, weights, h, w, max_batch=B, precision=args.precision, device=local_rank)
+    eng = ops.Engine(cfg, weights, h, w, max_batch=max(B, B2), precision=args.precision, device=local_rank)
     sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, args.mode, p.fill_16_9)
     oh, ow = ops.sbs_shape(H, W, sp)
-    # a small pool of distinct batches, resident in HBM before the timed region
-    pool = [torch.from_numpy(np.stack([synth.noise_frame(H, W, 1000 * rank + 10 * j + i) for i in range(B)])).to(dev)
-            for j in range(4)]
-    out = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=dev)
 
-    def step(i):
-        eng.pipeline(pool[i & 3], p, sp, use_ema=False, out=out)
+    def make_step(nb):
+        # a small pool of distinct batches, resident in HBM before the timed region
+        pool = [torch.from_numpy(np.stack([synth.noise_frame(H, W, 1000 * rank + 100 * j + i) for i in range(nb)])).to(dev)
+                for j in range(4 if nb <= 4 else 2)]
+        out = torch.empty((nb, oh, ow, 3), dtype=torch.uint8, device=dev)
+        return lambda i: eng.pipeline(pool[i % len(pool)], p, sp, use_ema=False, out=out)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        dist.barrier()
-    frames_total = args.steps * B * world
-    value = frames_total / dt
+    def timed(step, warmup, steps):
+        for i in range(warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            dist.barrier()
+        return dt
+
+    step = make_step(B)
+    dt = timed(step, args.warmup, args.steps)
+    value = args.steps * B * world / dt
+
+    def workload(nb):
+        return (f"DepthAnything-v2-{cfg.name} {args.precision}, {W}x{H} uint8 RGB noise frames, batch {nb} per GPU, "
+                f"Depth Resolution {args.res} (model input {h}x{w}), {args.mode} uint8 output {ow}x{oh}, "
+                f"predict_depth + make_sbs fused (d2s_pipeline), EMA off, seeded synthetic weights")
 
     result = {
         "metric": "stereo frames/sec @1080p DepthAnything-v2-ViT-B", "value": value, "unit": "stereo frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"DepthAnything-v2-{cfg.name} {args.precision}, {W}x{H} uint8 RGB noise frames, batch {B} per GPU, "
-                               f"Depth Resolution {args.res} (model input {h}x{w}), {args.mode} uint8 output {ow}x{oh}, "
-                               f"predict_depth + make_sbs fused (d2s_pipeline), EMA off, seeded synthetic weights",
-                   "frames_per_step_per_gpu": B, "parallelism": f"frame-sharded dp{world}, no data-path collective"},
+        "config": {"workload": workload(B), "frames_per_step_per_gpu": B,
+                   "parallelism": f"frame-sharded dp{world}, no data-path collective"},
     }
     if args.model != "vitb" or (H, W) != (1080, 1920):
         result["metric"] = f"stereo frames/sec @{W}x{H} DepthAnything-v2-{cfg.name}"
 
     if rank == 0 and not args.no_profile:
-        eng.profile(True)
-        for i in range(args.profile_steps):
-            step(i)
-        torch.cuda.synchronize()
-        prof = eng.profile_read()
-        eng.profile(False)
-        nf = args.profile_steps * B
-        kernels = {}
-        for name, r in prof.items():
-            if not r["launches"]:
-                continue
-            k = {"launches_per_step": r["launches"] / args.profile_steps, "ms_per_step": r["ms"] / args.profile_steps,
-                 "avg_launch_us": 1e3 * r["ms"] / r["launches"]}
-            if r["flops"]:
-                k["gflop_per_frame"] = r["flops"] / nf / 1e9
-                k["tflops"] = r["flops"] / (r["ms"] * 1e-3) / 1e12
-                k["frac_of_mfma_peak"] = k["tflops"] / PEAK_TFLOPS[args.precision]
-            if r["bytes"]:
-                k["mb_per_frame"] = r["bytes"] / nf / 1e6
-                k["gbs"] = r["bytes"] / (r["ms"] * 1e-3) / 1e9
-                k["frac_of_hbm_peak"] = k["gbs"] / PEAK_HBM_GBS
-            kernels[name] = k
-        result["kernels"] = kernels
-        gpu_ms = sum(k["ms_per_step"] for k in kernels.values())
-        result["gpu_busy_ms_per_step"] = gpu_ms
-        dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
-        kd = kernels[dom]
-        if "tflops" in kd:
-            result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kd["tflops"], "peak": PEAK_TFLOPS[args.precision],
-                                  "unit": "TFLOP/s", "frac": kd["frac_of_mfma_peak"], "traffic": None,
-                                  "flop_per_launch": 1e9 * kd["gflop_per_frame"] * B / kd["launches_per_step"],
-                                  "avg_launch_us": kd["avg_launch_us"]}
-        else:
-            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kd.get("gbs"), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": kd.get("frac_of_hbm_peak"), "traffic": None, "avg_launch_us": kd["avg_launch_us"]}
-        if "stereo_warp" in kernels:
-            kw = kernels["stereo_warp"]
-            result["roofline_warp"] = {"kernel": "stereo_warp", "bound": "hbm", "achieved": kw["gbs"], "peak": PEAK_HBM_GBS,
-                                       "unit": "GB/s", "frac": kw["frac_of_hbm_peak"], "traffic": None,
-                                       "bytes_per_launch": 1e6 * kw["mb_per_frame"] * B, "avg_launch_us": kw["avg_launch_us"]}
-        mf = sum(k.get("gflop_per_frame", 0.0) for k in kernels.values())
-        result["model_gflop_per_frame"] = {"counted": mf, "survey": SURVEY_GF_PER_FRAME.get((args.model, args.res))}
-        result["model_stage_tflops_at_measured_fps"] = value / world * mf / 1e3
+        result.update(profile_pass(eng, step, args.profile_steps, B, args.precision))
+        result["model_gflop_per_frame"] = {"counted": result.pop("model_gflop_per_frame_counted"),
+                                           "survey": SURVEY_GF_PER_FRAME.get((args.model, args.res))}
+        result["model_stage_tflops_at_measured_fps"] = value / world * result["model_gflop_per_frame"]["counted"] / 1e3
+
+    if B2:
+        step2 = make_step(B2)
+        steps2 = max(10, args.steps // B2)
+        dt2 = timed(step2, max(3, args.warmup // 4), steps2)
+        batched = {"value": steps2 * B2 / dt2, "unit": "stereo frames/s", "frames_per_step": B2, "steps": steps2,
+                   "ms_per_step": 1e3 * dt2 / steps2, "workload": workload(B2)}
+        if not args.no_profile:
+            pr = profile_pass(eng, step2, 3, B2, args.precision)
+            pr.pop("model_gflop_per_frame_counted", None)
+            batched.update(pr)
+        result["batched"] = batched
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, weights, p, H, W, args.mode)

@@ -108,21 +108,26 @@ def _cubic_coeffs(t: np.ndarray, A: float = -0.75):
     return c2(t + F32(1)), c1(t), c1(F32(1) - t), c2(F32(2) - t)
 
 
-def bicubic_resize(x: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
-    """F.interpolate(mode='bicubic', align_corners=False) on [C,H,W] float32 (no antialias)."""
+def bicubic_resize(x: np.ndarray, out_h: int, out_w: int, scale_factor=None) -> np.ndarray:
+    """F.interpolate(mode='bicubic', align_corners=False) on [C,H,W] float32 (no antialias).
+    scale_factor=(sy, sx): the caller-supplied factors enter the coordinate map as float32(1/s)
+    (ATen area_pixel_compute_scale with `scales`), as in the vendored DINOv2 of Video-Depth-Anything
+    (reference models/video_depth_anything/dinov2.py:179-210)."""
     x = np.asarray(x, dtype=F32)
     C, H, W = x.shape
+    fh = F32(1.0 / scale_factor[0]) if scale_factor is not None else None
+    fw = F32(1.0 / scale_factor[1]) if scale_factor is not None else None
 
-    def taps(n_in, n_out):
-        scale = F32(n_in) / F32(n_out)
+    def taps(n_in, n_out, forced=None):
+        scale = forced if forced is not None else F32(n_in) / F32(n_out)
         src = scale * (np.arange(n_out, dtype=F32) + F32(0.5)) - F32(0.5)
         i = np.floor(src)
         t = (src - i).astype(F32)
         i = i.astype(np.int64)
         idx = np.stack([np.clip(i + k, 0, n_in - 1) for k in (-1, 0, 1, 2)], 0)
         return idx, np.stack(_cubic_coeffs(t), 0).astype(F32)
-    iy, cy = taps(H, out_h)
-    ix, cx = taps(W, out_w)
+    iy, cy = taps(H, out_h, fh)
+    ix, cx = taps(W, out_w, fw)
     # ATen order: for each of 4 rows interpolate along x, then along y
     rows = []
     for k in range(4):
@@ -171,15 +176,17 @@ def gelu_erf(x):
     return (F32(0.5) * x * (F32(1.0) + _erf(x * F32(0.7071067811865476)).astype(F32))).astype(F32)
 
 
-def interpolate_pos_embed(pos: np.ndarray, gh: int, gw: int, grid: int = 37) -> np.ndarray:
+def interpolate_pos_embed(pos: np.ndarray, gh: int, gw: int, grid: int = 37, offset: float = 0.0) -> np.ndarray:
     """HF Dinov2Embeddings.interpolate_pos_encoding: bicubic (align_corners=False) resample of
-    the [grid,grid,D] patch position table to [gh,gw,D]; cls row kept.  pos: [1, 1+grid*grid, D]."""
+    the [grid,grid,D] patch position table to [gh,gw,D]; cls row kept.  pos: [1, 1+grid*grid, D].
+    offset=0.1: the vendored DINOv2 variant (scale_factor=((gh+0.1)/grid, (gw+0.1)/grid))."""
     D = pos.shape[-1]
     if gh == grid and gw == grid:
         return pos[0].astype(F32)
     cls = pos[0, :1]
     tab = pos[0, 1:].reshape(grid, grid, D).transpose(2, 0, 1)     # [D,grid,grid]
-    tab = bicubic_resize(tab, gh, gw)                                # [D,gh,gw]
+    sf = ((gh + offset) / grid, (gw + offset) / grid) if offset else None
+    tab = bicubic_resize(tab, gh, gw, sf)                            # [D,gh,gw]
     tab = tab.transpose(1, 2, 0).reshape(gh * gw, D)
     return np.concatenate([cls, tab], 0).astype(F32)
 
@@ -239,7 +246,8 @@ class DepthAnythingOracle:
         pw = w["backbone.embeddings.patch_embeddings.projection.weight"].reshape(cfg.hidden, -1)
         tok = patches @ pw.T + w["backbone.embeddings.patch_embeddings.projection.bias"]
         tok = np.concatenate([w["backbone.embeddings.cls_token"][0], tok], 0)
-        pos = interpolate_pos_embed(w["backbone.embeddings.position_embeddings"], gh, gw, cfg.pos_grid)
+        pos = interpolate_pos_embed(w["backbone.embeddings.position_embeddings"], gh, gw, cfg.pos_grid,
+                                    getattr(self, "pos_offset", 0.0))
         return (tok + pos).astype(F32)
 
     def layer(self, i: int, x: np.ndarray) -> np.ndarray:
@@ -290,7 +298,7 @@ class DepthAnythingOracle:
         h = conv2d(relu(h), w[p + "convolution2.weight"], w[p + "convolution2.bias"], 1, 1)
         return h + x
 
-    def neck_head(self, feats, gh: int, gw: int, taps: Optional[dict] = None) -> np.ndarray:
+    def neck_head(self, feats, gh: int, gw: int, taps: Optional[dict] = None, hooks: Optional[dict] = None) -> np.ndarray:
         cfg, w = self.cfg, self.w
         maps = []
         for i, f in enumerate(feats):
@@ -301,6 +309,8 @@ class DepthAnythingOracle:
                 x = conv_transpose_k_eq_s(x, w[p + "resize.weight"], w[p + "resize.bias"])
             elif i == 3:
                 x = conv2d(x, w[p + "resize.weight"], w[p + "resize.bias"], stride=2, pad=1)
+            if hooks and f"layer_{i + 1}" in hooks:                # VDA: temporal module on layer_3 / layer_4
+                x = hooks[f"layer_{i + 1}"](x)
             x = conv2d(x, w[f"neck.convs.{i}.weight"], None, 1, 1)
             if taps is not None:
                 taps[f"neck_feat{i}"] = x
@@ -320,6 +330,8 @@ class DepthAnythingOracle:
                 oh, ow = h.shape[1] * 2, h.shape[2] * 2
             h = bilinear_resize(h, oh, ow, align_corners=True)
             fused = conv2d(h, w[p + "projection.weight"], w[p + "projection.bias"])
+            if hooks and f"path_{4 - idx}" in hooks:               # VDA: temporal module on path_4 / path_3
+                fused = hooks[f"path_{4 - idx}"](fused)
             if taps is not None:
                 taps[f"fused{idx}"] = fused
         h = conv2d(fused, w["head.conv1.weight"], w["head.conv1.bias"], 1, 1)
@@ -328,12 +340,12 @@ class DepthAnythingOracle:
         h = relu(conv2d(h, w["head.conv3.weight"], w["head.conv3.bias"]))
         return h[0].astype(F32)
 
-    def forward(self, x: np.ndarray, taps: Optional[dict] = None) -> np.ndarray:
+    def forward(self, x: np.ndarray, taps: Optional[dict] = None, hooks: Optional[dict] = None) -> np.ndarray:
         """x: normalised [3,h,w] float32 -> predicted_depth [h,w]."""
         p = self.cfg.patch
         gh, gw = x.shape[1] // p, x.shape[2] // p
         feats = self.backbone(x, taps)
-        return self.neck_head(feats, gh, gw, taps)
+        return self.neck_head(feats, gh, gw, taps, hooks)
 
 
 # ----------------------------------------------------------------------------------------------
