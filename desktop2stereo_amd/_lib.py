@@ -21,7 +21,7 @@ class ModelDesc(C.Structure):
     _fields_ = [("hidden", C.c_int32), ("heads", C.c_int32), ("layers", C.c_int32),
                 ("out_indices", C.c_int32 * 4), ("neck", C.c_int32 * 4), ("fusion", C.c_int32),
                 ("head_hidden", C.c_int32), ("mlp", C.c_int32), ("patch", C.c_int32),
-                ("pos_grid", C.c_int32), ("ln_eps", C.c_float), ("precision", C.c_int32)]
+                ("pos_grid", C.c_int32), ("ln_eps", C.c_float), ("precision", C.c_int32), ("temporal", C.c_int32)]
 
 
 class PostParams(C.Structure):

@@ -61,6 +61,17 @@ struct d2s_engine {
     void* scr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float* splitk_ws = nullptr;                    // fp32 partials for split-K launches (tiny-M, long-K DPT convs)
     size_t splitk_elems = 0;
+    // Video-Depth-Anything temporal modules (desc.temporal): layer_3, layer_4, path_4, path_3
+    struct TMod {
+        int C = 0, sites = 0;
+        float *gn_g = nullptr, *gn_b = nullptr, *pe = nullptr;
+        float *ln_g[2] = {nullptr, nullptr}, *ln_b[2] = {nullptr, nullptr}, *ffn_g = nullptr, *ffn_b = nullptr;
+        PackedW proj_in, proj_out, to_q[2], to_kv[2], to_out[2], ff1, ff2;
+        void* cache[2] = {nullptr, nullptr};       // ring [31][sites][C] T per attention block
+    } tm[4];
+    int tm_head = 0, tm_init = 0;                  // oldest ring slot; 0 until the first frame has filled the rings
+    float* tm_hs = nullptr;                        // [sites_max, C_max] fp32 residual of the temporal transformer
+    void *tm_a = nullptr, *tm_b = nullptr, *tm_kvin = nullptr, *tm_kv = nullptr, *tm_u = nullptr, *tm_g = nullptr, *tm_out = nullptr;
     // pipeline buffers
     float *pre_x = nullptr, *depth_small = nullptr;
     void* post_ws = nullptr;
@@ -193,11 +204,14 @@ void cubic_coeffs(float t, float c[4]) {
     c[0] = c2(t + 1.f); c[1] = c1(t); c[2] = c1(1.f - t); c[3] = c2(2.f - t);
 }
 
-void interp_pos(const float* pos, int grid, int D, int gh, int gw, std::vector<float>& out) {
+void interp_pos(const float* pos, int grid, int D, int gh, int gw, std::vector<float>& out, double offset = 0.0) {
     out.assign((size_t)(1 + gh * gw) * D, 0.f);
     std::memcpy(out.data(), pos, D * sizeof(float));
     if (gh == grid && gw == grid) { std::memcpy(out.data() + D, pos + D, (size_t)grid * grid * D * sizeof(float)); return; }
     float sy = (float)grid / (float)gh, sx = (float)grid / (float)gw;
+    if (offset != 0.0) {   // vendored DINOv2 (VDA): scale_factor = (g + 0.1) / grid enters as float(1 / scale_factor), dinov2.py:179-210
+        sy = (float)(1.0 / (((double)gh + offset) / (double)grid)); sx = (float)(1.0 / (((double)gw + offset) / (double)grid));
+    }
     for (int oy = 0; oy < gh; ++oy) {
         float fy = sy * ((float)oy + 0.5f) - 0.5f;
         float iyf = floorf(fy);
@@ -252,6 +266,46 @@ int conv3(d2s_engine* e, const void* in, int B, int Hi, int Wi, int C, int strid
     GemmEpi ep = rowsE(out, OUT_T, w.N, w.bias);
     ep.act = act; ep.res1 = res1; ep.res2 = res2;
     return gemm(e, a, w, B * Ho * Wo, ep, st);
+}
+
+// One streaming TemporalModule on an NHWC map x [sites, C] -> out; reads then updates its ring caches.
+// (reference motion_module.py:102-134, 164-196, 242-321; cache semantics vda2_s.py:177-218)
+int run_temporal(d2s_engine* e, int m, const void* x, void* out, hipStream_t st) {
+    d2s_engine::TMod& t = e->tm[m];
+    const int C = t.C, S = t.sites, prec = e->prec;
+    const int Tw = e->tm_init ? 32 : 1;                 // first frame: a window of one (the frame itself at position 0)
+    const size_t es = elem_size(prec);
+    PROF(PC_ELT, 0, 0, launch_groupnorm(prec, x, t.gn_g, t.gn_b, e->tm_a, S, C, 32, 1e-6f, st));
+    RC(gemm(e, plainA(e->tm_a, C), t.proj_in, S, rowsE(e->tm_hs, OUT_F32, C, t.proj_in.bias), st));
+    for (int a = 0; a < 2; ++a) {
+        PROF(PC_LN, 0, 0, launch_layernorm(prec, e->tm_hs, t.ln_g[a], t.ln_b[a], e->tm_a, S, C, 1e-5f, 0, 0, 0, st));
+        PROF(PC_ELT, 0, 0, launch_gather_pe(prec, t.cache[a], e->tm_a, t.pe, e->tm_kvin, S, C, Tw, 31, e->tm_head, st));
+        RC(gemm(e, plainA(e->tm_kvin, C), t.to_kv[a], S * Tw, rowsE(e->tm_kv, OUT_T, 2 * C, nullptr), st));
+        RC(gemm(e, plainA((const char*)e->tm_kvin + (size_t)(Tw - 1) * C * es, (long)Tw * C), t.to_q[a], S, rowsE(e->tm_b, OUT_T, C, nullptr), st));
+        PROF(PC_ATTN, 4.0 * S * Tw * C, 0, launch_temporal_attn(prec, e->tm_b, e->tm_kv, e->tm_out, S, C, Tw, st));
+        {
+            GemmEpi ep = rowsE(e->tm_hs, OUT_F32, C, t.to_out[a].bias);
+            ep.res1 = e->tm_hs;
+            RC(gemm(e, plainA(e->tm_out, C), t.to_out[a], S, ep, st));
+        }
+        // the normed hidden state joins the window: first frame fills all 31 slots, later frames replace the oldest
+        PROF(PC_ELT, 0, 0, launch_cache_store(prec, t.cache[a], e->tm_a, S, C, e->tm_init ? e->tm_head : 0, e->tm_init ? 1 : 31, st));
+    }
+    PROF(PC_LN, 0, 0, launch_layernorm(prec, e->tm_hs, t.ffn_g, t.ffn_b, e->tm_a, S, C, 1e-5f, 0, 0, 0, st));
+    RC(gemm(e, plainA(e->tm_a, C), t.ff1, S, rowsE(e->tm_u, OUT_T, 8 * C, t.ff1.bias), st));
+    PROF(PC_ELT, 0, 0, launch_geglu(prec, e->tm_u, e->tm_g, S, 4 * C, st));
+    {
+        GemmEpi ep = rowsE(e->tm_hs, OUT_F32, C, t.ff2.bias);
+        ep.res1 = e->tm_hs;
+        RC(gemm(e, plainA(e->tm_g, 4 * C), t.ff2, S, ep, st));
+    }
+    PROF(PC_ELT, 0, 0, launch_cast_f32(prec, e->tm_hs, e->tm_a, (long)S * C, st));
+    {
+        GemmEpi ep = rowsE(out, OUT_T, C, t.proj_out.bias);
+        ep.res1 = x;
+        RC(gemm(e, plainA(e->tm_a, C), t.proj_out, S, ep, st));
+    }
+    return D2S_OK;
 }
 
 int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) {
@@ -317,6 +371,8 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
             RC(conv3(e, e->rproj[i], B, gh, gw, c, 2, 0, e->re[i].resize, e->rres[i], ACT_NONE, nullptr, nullptr, st));
             src = e->rres[i]; Hs = (gh - 1) / 2 + 1; Ws = (gw - 1) / 2 + 1;
         }
+        if (d.temporal && i == 2) { RC(run_temporal(e, 0, src, e->rres[2], st)); src = e->rres[2]; }     // layer_3
+        if (d.temporal && i == 3) { RC(run_temporal(e, 1, src, e->scr[0], st)); src = e->scr[0]; }       // layer_4
         RC(conv3(e, src, B, Hs, Ws, c, 1, 0, e->re[i].conv, e->feat[i], ACT_NONE, nullptr, nullptr, st));
     }
     // ---- fusion, deep -> shallow (HF DepthAnythingFeatureFusionStage)
@@ -342,6 +398,11 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         void* pout = e->scr[3 + (idx & 1)];
         RC(gemm(e, plainA(Z, F), e->fu[idx].proj, B * Hc * Wc, rowsE(X, OUT_T, F, e->fu[idx].proj.bias), st));
         PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, X, pout, B, Hc, Wc, Ho, Wo, F, st));
+        if (d.temporal && idx < 2) {                     // path_4 / path_3 (dpt_temporal.py:98-103)
+            void* alt = e->scr[3 + ((idx + 1) & 1)];
+            RC(run_temporal(e, 2 + idx, pout, alt, st));
+            pout = alt;
+        }
         fused = pout; Hc = Ho; Wc = Wo;
     }
     // ---- head (HF DepthAnythingDepthEstimationHead)
@@ -361,6 +422,10 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
             RC(conv3(e, Y, B, e->h, e->w, F / 2, 1, 0, e->head2, Z, ACT_RELU, nullptr, nullptr, st));
             PROF(PC_ELT, 0, 0, launch_head_final(prec, Z, e->w3, e->b3, depth, (long)B * e->h * e->w, d.head_hidden, st));
         }
+    }
+    if (d.temporal) {                                    // one window step per frame (vda2_s.py:177-187, 214-221)
+        if (e->tm_init) e->tm_head = (e->tm_head + 1) % 31;
+        e->tm_init = 1;
     }
     e->last_batch = B;
     return D2S_OK;
@@ -416,7 +481,7 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
         if (!pt) return D2S_E_MISSING;
         if (pt->data.size() != (size_t)(d.pos_grid * d.pos_grid + 1) * D) { set_error("position_embeddings: wrong shape"); return D2S_E_MISSING; }
         std::vector<float> pos;
-        interp_pos(pt->data.data(), d.pos_grid, D, e->gh, e->gw, pos);
+        interp_pos(pt->data.data(), d.pos_grid, D, e->gh, e->gw, pos, d.temporal ? 0.1 : 0.0);
         RC(dev_alloc(e, (void**)&e->pos, pos.size() * 4));
         D2S_HIP(hipMemcpy(e->pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
     }
@@ -464,8 +529,6 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
     RC(pack_conv3(e, "head.conv2.weight", "head.conv2.bias", d.head_hidden, F / 2, e->head2));
     RC(upload_f32(e, "head.conv3.weight", d.head_hidden, &e->w3));
     { const HostT* b3 = find(e, "head.conv3.bias"); if (!b3) return D2S_E_MISSING; e->b3 = b3->data[0]; }
-    e->host.clear();
-
     // ---- workspaces
     const size_t M = (size_t)B * N, Mp = (size_t)B * P;
     RC(dev_alloc(e, (void**)&e->resid, M * D * 4));
@@ -488,6 +551,53 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
     for (int i = 0; i < 5; ++i) RC(dev_alloc(e, &e->scr[i], scr_elems * es));
     e->splitk_elems = (size_t)B * 16 * e->fH[2] * e->fW[2] * std::max(F, d.neck[3]);
     RC(dev_alloc(e, (void**)&e->splitk_ws, e->splitk_elems * 4));
+    if (d.temporal) {
+        // ---- Video-Depth-Anything temporal modules (reference dpt_temporal.py:50-60): layer_3, layer_4, path_4, path_3
+        const int tC[4] = {d.neck[2], d.neck[3], F, F};
+        const int tS[4] = {e->fH[2] * e->fW[2], e->fH[3] * e->fW[3], e->fH[2] * e->fW[2], e->fH[1] * e->fW[1]};
+        size_t sc_max = 0;
+        for (int m = 0; m < 4; ++m) {
+            d2s_engine::TMod& t = e->tm[m];
+            t.C = tC[m]; t.sites = tS[m];
+            const int C = t.C;
+            D2S_REQUIRE(C % 32 == 0 && C <= 1024, "temporal module channels must be a multiple of 32 (GroupNorm) and <= 1024");
+            sc_max = std::max(sc_max, (size_t)t.sites * C);
+            std::string p = "head.motion_modules." + std::to_string(m) + ".temporal_transformer.";
+            std::string b = p + "transformer_blocks.0.";
+            RC(upload_f32(e, p + "norm.weight", C, &t.gn_g)); RC(upload_f32(e, p + "norm.bias", C, &t.gn_b));
+            RC(pack_linear(e, p + "proj_in.weight", p + "proj_in.bias", C, C, t.proj_in));
+            RC(pack_linear(e, p + "proj_out.weight", p + "proj_out.bias", C, C, t.proj_out));
+            for (int a = 0; a < 2; ++a) {
+                std::string q = b + "attention_blocks." + std::to_string(a) + ".";
+                RC(upload_f32(e, b + "norms." + std::to_string(a) + ".weight", C, &t.ln_g[a]));
+                RC(upload_f32(e, b + "norms." + std::to_string(a) + ".bias", C, &t.ln_b[a]));
+                RC(pack_linear(e, q + "to_q.weight", "", C, C, t.to_q[a]));
+                const HostT *wk = find(e, q + "to_k.weight"), *wv = find(e, q + "to_v.weight");
+                if (!wk || !wv) return D2S_E_MISSING;
+                if (wk->data.size() != (size_t)C * C || wv->data.size() != (size_t)C * C) { set_error("to_k/to_v: wrong shape"); return D2S_E_MISSING; }
+                const float* kv[2] = {wk->data.data(), wv->data.data()};
+                RC(pack_matrix(e, 2 * C, C, [&](int n, int k) { return kv[n / C][(size_t)(n % C) * C + k]; }, nullptr, t.to_kv[a]));
+                RC(pack_linear(e, q + "to_out.0.weight", q + "to_out.0.bias", C, C, t.to_out[a]));
+                RC(dev_alloc(e, &t.cache[a], (size_t)31 * t.sites * C * es, true));
+            }
+            RC(upload_f32(e, b + "ff_norm.weight", C, &t.ffn_g)); RC(upload_f32(e, b + "ff_norm.bias", C, &t.ffn_b));
+            RC(pack_linear(e, b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", 8 * C, C, t.ff1));
+            RC(pack_linear(e, b + "ff.net.2.weight", b + "ff.net.2.bias", C, 4 * C, t.ff2));
+            // sinusoidal APE over the 32-frame window (motion_module.py:214-222), float32 like torch
+            std::vector<float> pe((size_t)32 * C);
+            for (int i = 0; i < C / 2; ++i) {
+                float div = expf((float)(2 * i) * (float)(-std::log(10000.0) / C));
+                for (int pos = 0; pos < 32; ++pos) { pe[(size_t)pos * C + 2 * i] = sinf((float)pos * div); pe[(size_t)pos * C + 2 * i + 1] = cosf((float)pos * div); }
+            }
+            RC(dev_alloc(e, (void**)&t.pe, pe.size() * 4));
+            D2S_HIP(hipMemcpy(t.pe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
+        }
+        RC(dev_alloc(e, (void**)&e->tm_hs, sc_max * 4));
+        RC(dev_alloc(e, &e->tm_a, sc_max * es)); RC(dev_alloc(e, &e->tm_b, sc_max * es)); RC(dev_alloc(e, &e->tm_out, sc_max * es));
+        RC(dev_alloc(e, &e->tm_kvin, sc_max * 32 * es)); RC(dev_alloc(e, &e->tm_kv, sc_max * 64 * es));
+        RC(dev_alloc(e, &e->tm_u, sc_max * 8 * es)); RC(dev_alloc(e, &e->tm_g, sc_max * 4 * es));
+    }
+    e->host.clear();
     RC(dev_alloc(e, (void**)&e->pre_x, (size_t)B * 3 * h * w * 4));
     RC(dev_alloc(e, (void**)&e->depth_small, (size_t)B * h * w * 4));
     e->post_ws_bytes = d2s_post_process_workspace(B, h, w);
@@ -516,12 +626,14 @@ extern "C" int d2s_model_forward(d2s_engine* e, const float* x, float* depth, in
     D2S_REQUIRE(e && x && depth, "null pointer");
     if (!e->finalized) { set_error("d2s_model_forward before d2s_engine_finalize"); return D2S_E_STATE; }
     D2S_REQUIRE(batch >= 1 && batch <= e->maxB, "batch exceeds max_batch");
+    D2S_REQUIRE(!e->d.temporal || batch == 1, "a Video-Depth-Anything engine is one stream: batch must be 1");
     return forward(e, x, depth, batch, (hipStream_t)stream);
 }
 
 extern "C" int d2s_engine_reset_stream(d2s_engine* e) {
     D2S_REQUIRE(e, "null engine");
     e->ema_init = 0;
+    e->tm_init = 0; e->tm_head = 0;                     // VDA: drop the temporal window (next frame re-seeds it)
     return D2S_OK;
 }
 
@@ -531,6 +643,7 @@ extern "C" int d2s_pipeline(d2s_engine* e, const uint8_t* frames, int batch, int
     D2S_REQUIRE(e && frames && pp && sp && out, "null pointer");
     if (!e->finalized) { set_error("d2s_pipeline before d2s_engine_finalize"); return D2S_E_STATE; }
     D2S_REQUIRE(batch >= 1 && batch <= e->maxB, "batch exceeds max_batch");
+    D2S_REQUIRE(!e->d.temporal || batch == 1, "a Video-Depth-Anything engine is one stream: batch must be 1");
     // model-input shape of this frame size must be the engine's (reference: fixed at first frame, depth.py:1951-1953)
     D2S_REQUIRE(H > 0 && W > 0 && depth_resolution > 0, "bad frame shape");
     int longest = H > W ? H : W;

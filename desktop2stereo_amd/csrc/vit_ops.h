@@ -18,6 +18,14 @@ int launch_to_f32(int prec, const void* in, float* out, long n, hipStream_t st);
 // vt: V transposed [B, heads, 64, Npad] (Npad = N rounded up to 64, zero beyond N), see MAP_QKV in gemm.h.
 int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B, int N, int Npad, int heads, hipStream_t st);
 
+// Video-Depth-Anything temporal-module kernels (temporal.hip)
+int launch_groupnorm(int prec, const void* x, const float* g, const float* b, void* out, int sites, int C, int groups, float eps, hipStream_t st);
+int launch_gather_pe(int prec, const void* cache, const void* cur, const float* pe, void* kvin, int sites, int C, int Tw, int slots, int head, hipStream_t st);
+int launch_cache_store(int prec, void* cache, const void* cur, int sites, int C, int slot0, int nslots, hipStream_t st);
+int launch_temporal_attn(int prec, const void* q, const void* kv, void* out, int sites, int C, int Tw, hipStream_t st);
+int launch_geglu(int prec, const void* u, void* g, long rows, int C4, hipStream_t st);
+int launch_cast_f32(int prec, const float* in, void* out, long n, hipStream_t st);
+
 // engine-internal (post.hip)
 int ema_batch(float* depth, float* state, int initialised, int nframes, int hw, float alpha, hipStream_t st);
 

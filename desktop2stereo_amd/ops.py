@@ -138,7 +138,8 @@ class Engine:
     backend (reference depth.py:1539-1781).  ``__call__(tensor[B,3,h,w]) -> tensor[B,h,w]``."""
 
     def __init__(self, cfg: ModelConfig, weights: Dict[str, np.ndarray], h: int, w: int, max_batch: int = 1,
-                 precision: str = "bf16", device: int = 0):
+                 precision: str = "bf16", device: int = 0, temporal: bool = False):
+        """temporal=True: streaming Video-Depth-Anything (weights from vda_weights; one stream, batch 1)."""
         if not torch.cuda.is_available():
             raise _lib.D2SError("no ROCm device: the HIP engine cannot run (and there is no fallback)")
         self.lib = _lib.load()
@@ -147,7 +148,7 @@ class Engine:
         self.device = torch.device("cuda", device)
         desc = ModelDesc(cfg.hidden, cfg.heads, cfg.layers, (C.c_int32 * 4)(*cfg.out_indices), (C.c_int32 * 4)(*cfg.neck),
                          cfg.fusion, cfg.head_hidden, cfg.mlp, cfg.patch, cfg.pos_grid, cfg.ln_eps,
-                         PREC_BF16 if precision == "bf16" else PREC_FP32)
+                         PREC_BF16 if precision == "bf16" else PREC_FP32, int(bool(temporal)))
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
         self._h = C.c_void_p()

@@ -66,6 +66,8 @@ typedef struct d2s_model_desc {
     int32_t pos_grid;          /* 37 */
     float   ln_eps;            /* 1e-6 */
     int32_t precision;         /* D2S_PREC_* */
+    int32_t temporal;          /* 1: Video-Depth-Anything streaming head (4 temporal modules, 32-frame window; reference
+                                  models/video_depth_anything/vda2_s.py, dpt_temporal.py); batch must be 1 */
 } d2s_model_desc;
 
 /* Post-process constants (reference utils.py:858-859, depth.py:775, 816, 1889). */

@@ -1,0 +1,85 @@
+"""GPU: streaming Video-Depth-Anything engine (A17) against goldens captured from the reference's own
+VideoDepthAnything (tests/golden/make_golden_vda.py) and against the numpy oracle.
+fp32 engine: every frame of the stream within 2e-4 of the range; bf16 engine: bf16-class tolerance."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu test selected but no ROCm device is visible")
+    return torch.device("cuda", 0)
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 0.05)])
+def test_vda_tiny_stream(dev, golden_dir, prec, tol):
+    from desktop2stereo_amd import ops
+    from desktop2stereo_amd.config import MODELS
+    from desktop2stereo_amd.vda_weights import make_vda_weights
+    cfg = MODELS["tiny"]
+    z = np.load(os.path.join(golden_dir, "vda_tiny.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "vda_tiny.json")))
+    eng = ops.Engine(cfg, make_vda_weights(cfg, 0), 42, 84, 1, prec, temporal=True)
+    for rep in range(2):                                      # second pass after reset_stream must reproduce the first
+        eng.reset_stream()
+        for fi in range(len(meta["frames"])):
+            d = eng(_t(z[f"f{fi}_x"], dev)).cpu().numpy()[0]
+            ref = z[f"f{fi}_depth"]
+            err = np.abs(d - ref).max() / max(1.0, float(ref.max()))
+            assert err <= tol, (prec, rep, fi, err)
+    with pytest.raises(Exception):
+        eng(_t(np.stack([z["f0_x"], z["f1_x"]]), dev))       # a VDA engine is one stream: batch must be 1
+    eng.close()
+
+
+def test_vda_longer_than_window_vs_oracle(dev):
+    """40 frames (> 32-frame window: the ring wraps) against the numpy oracle, fp32."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS
+    from desktop2stereo_amd.vda_weights import make_vda_weights
+    from oracle import d2s_oracle as O
+    from oracle.vda_oracle import VideoDepthOracle
+    cfg = MODELS["tiny"]
+    w = make_vda_weights(cfg, 0)
+    eng = ops.Engine(cfg, w, 42, 84, 1, "fp32", temporal=True)
+    orc = VideoDepthOracle(cfg, w)
+    for fi in range(40):
+        frame = synth.structured_frame(90, 160, 200 + fi)
+        x = O.normalise(O.resize_patch_aligned(np.ascontiguousarray(frame.transpose(2, 0, 1)), 84))
+        d = eng(_t(x, dev)).cpu().numpy()[0]
+        ref = orc.forward(x)
+        err = np.abs(d - ref).max() / max(1.0, float(ref.max()))
+        assert err <= 3e-4, (fi, err)
+    eng.close()
+
+
+def test_vda_vits_stream(dev, golden_dir):
+    """ViT-S VDA at 196x336 (BASELINE config 4 shape), 3 frames, reference goldens."""
+    path = os.path.join(golden_dir, "vda_vits.npz")
+    if not os.path.exists(path):
+        pytest.skip("vda_vits golden not generated")
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS
+    from desktop2stereo_amd.vda_weights import make_vda_weights
+    cfg = MODELS["vits"]
+    z = np.load(path)
+    meta = json.load(open(os.path.join(golden_dir, "vda_vits.json")))
+    eng = ops.Engine(cfg, make_vda_weights(cfg, 0), 196, 336, 1, "fp32", temporal=True)
+    for fi, fr in enumerate(meta["frames"]):
+        x = ops.preprocess(_t(synth.structured_frame(fr["h"], fr["w"], fr["seed"]), dev), meta["depth_resolution"])
+        d = eng(x).cpu().numpy()[0]
+        ref = z[f"f{fi}_depth"]
+        err = np.abs(d - ref).max() / max(1.0, float(ref.max()))
+        assert err <= 3e-4, (fi, err)
+    eng.close()
