@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--mode", default="Full-SBS")
     ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--vda", action="store_true",
+                    help="streaming Video-Depth-Anything (BASELINE config 4): one stream per GPU, batch 1, 32-frame window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -146,8 +148,15 @@ def main():
     B2 = args.also_batch if (world == 1 and args.also_batch > B) else 0
     p = PipelineParams(depth_resolution=args.res, display_mode=args.mode)
     h, w, _ = engine_shape(H, W, args.res)
-    weights = make_weights(cfg, 0)
-    eng = ops.Engine(cfg, weights, h, w, max_batch=max(B, B2), precision=args.precision, device=local_rank)
+    if args.vda:
+        from desktop2stereo_amd.vda_weights import make_vda_weights
+        if B != 1:
+            raise SystemExit("--vda is one stream per GPU: --batch must be 1")
+        B2 = 0
+        weights = make_vda_weights(cfg, 0)
+    else:
+        weights = make_weights(cfg, 0)
+    eng = ops.Engine(cfg, weights, h, w, max_batch=max(B, B2), precision=args.precision, device=local_rank, temporal=args.vda)
     sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, args.mode, p.fill_16_9)
     oh, ow = ops.sbs_shape(H, W, sp)
 
@@ -197,6 +206,10 @@ def main():
     }
     if args.model != "vitb" or (H, W) != (1080, 1920):
         result["metric"] = f"stereo frames/sec @{W}x{H} DepthAnything-v2-{cfg.name}"
+    if args.vda:
+        result["metric"] = f"stereo frames/sec @{W}x{H} VideoDepthAnything-{cfg.name} (streaming, window 32)"
+        result["config"]["workload"] = result["config"]["workload"].replace("DepthAnything-v2", "VideoDepthAnything(stream, window 32)")
+        args.no_cpu_baseline = True                      # the CPU leg times the DA-v2 oracle only
 
     if rank == 0 and not args.no_profile:
         result.update(profile_pass(eng, step, args.profile_steps, B, args.precision))

@@ -42,16 +42,34 @@ def configure(model="vitb", weights: Optional[Dict[str, np.ndarray]] = None, par
     `model`: "vits" | "vitb" | "vitl" | "tiny" | a reference MODEL_ID | a ModelConfig.
     `weights`: HF-keyed float arrays, a path to model.safetensors, or None (seeded synthetic)."""
     from .weights import load_safetensors, make_weights
+    # Video-Depth-Anything ids (reference utils.py model map; depth.py:875-893): streaming temporal head, one stream
+    vda = {"depth-anything/Video-Depth-Anything-Small": "vits", "depth-anything/Video-Depth-Anything-Base": "vitb",
+           "depth-anything/Video-Depth-Anything-Large": "vitl", "vda_tiny": "tiny", "vda_vits": "vits", "vda_vitb": "vitb",
+           "vda_vitl": "vitl"}
+    temporal = isinstance(model, str) and model in vda
+    if temporal:
+        model = vda[model]
     cfg = model if isinstance(model, ModelConfig) else MODELS[MODEL_IDS.get(model, model)]
     if weights is None:
-        weights = make_weights(cfg, seed)
+        if temporal:
+            from .vda_weights import make_vda_weights
+            weights = make_vda_weights(cfg, seed)
+        else:
+            weights = make_weights(cfg, seed)
     elif isinstance(weights, str):
-        weights = load_safetensors(weights, cfg)
+        if temporal:                                    # reference .pth layout (pretrained.* / head.*) -> engine names
+            from .vda_weights import vda_to_hf
+            sd = torch.load(weights, map_location="cpu", weights_only=True)
+            weights = vda_to_hf({k: v.float().numpy() for k, v in sd.items()}, cfg)
+        else:
+            weights = load_safetensors(weights, cfg)
+    if temporal and max_batch != 1:
+        raise _lib.D2SError("a Video-Depth-Anything engine is one stream: max_batch must be 1")
     with lock:
         if _state["engine"] is not None:
             _state["engine"].close()
         _state.update(cfg=cfg, weights=weights, params=params or PipelineParams(), precision=precision, device=device,
-                      engine=None, engine_key=None, max_batch=max_batch)
+                      engine=None, engine_key=None, max_batch=max_batch, temporal=temporal)
     depth_stabilizer.prev = None
 
 
@@ -72,7 +90,7 @@ def _ensure_engine_built(engine_h: int, engine_w: int) -> ops.Engine:
         if _state["engine"] is not None:
             _state["engine"].close()
         _state["engine"] = ops.Engine(_state["cfg"], _state["weights"], engine_h, engine_w, _state["max_batch"],
-                                      _state["precision"], _state["device"])
+                                      _state["precision"], _state["device"], temporal=_state.get("temporal", False))
         _state["engine_key"] = key
     return _state["engine"]
 
