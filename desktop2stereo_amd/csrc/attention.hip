@@ -12,7 +12,8 @@
 //   fragment are loaded in a permuted order so that a lane group's values are 8 (bf16) / 4 (f32)
 //   CONSECUTIVE keys, i.e. exactly one 16-byte chunk of a V^T row;
 //   O^T[d, q] += mfma(V^T rows, P^T)           lane: 4 consecutive d for 1 query -> vector stores.
-// K / V^T tiles: global -> registers -> XOR-swizzled LDS, double buffered, one barrier per tile.
+// K / V^T tiles: global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a 3-stage ring; the XOR swizzle is
+// applied on the source address (LDS-DMA writes lane-linear), counted vmcnt + one raw barrier per tile.
 // Softmax in fp32 (exp2 with the scale folded in).
 #include "vit_ops.h"
 
