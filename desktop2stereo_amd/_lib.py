@@ -21,12 +21,14 @@ class ModelDesc(C.Structure):
     _fields_ = [("hidden", C.c_int32), ("heads", C.c_int32), ("layers", C.c_int32),
                 ("out_indices", C.c_int32 * 4), ("neck", C.c_int32 * 4), ("fusion", C.c_int32),
                 ("head_hidden", C.c_int32), ("mlp", C.c_int32), ("patch", C.c_int32),
-                ("pos_grid", C.c_int32), ("ln_eps", C.c_float), ("precision", C.c_int32), ("temporal", C.c_int32)]
+                ("pos_grid", C.c_int32), ("ln_eps", C.c_float), ("precision", C.c_int32), ("temporal", C.c_int32),
+                ("max_depth", C.c_float)]
 
 
 class PostParams(C.Structure):
     _fields_ = [("percentile", C.c_float), ("subsample_cap", C.c_int32), ("gamma", C.c_float),
-                ("foreground_scale", C.c_float), ("aa_strength", C.c_float), ("ema_alpha", C.c_float)]
+                ("foreground_scale", C.c_float), ("aa_strength", C.c_float), ("ema_alpha", C.c_float),
+                ("metric", C.c_int32)]
 
 
 class SbsParams(C.Structure):
@@ -46,6 +48,9 @@ SYMBOLS = {
     "d2s_engine_memory": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "d2s_preprocess": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
+    "d2s_process_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "d2s_process": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "d2s_overlay_text": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_char_p, _P]),
     "d2s_model_forward": (C.c_int, [_P, _P, _P, C.c_int, _P]),
     "d2s_post_process": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(PostParams), _P, C.c_uint64, _P]),
     "d2s_post_process_workspace": (C.c_uint64, [C.c_int, C.c_int, C.c_int]),

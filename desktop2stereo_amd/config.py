@@ -58,6 +58,18 @@ MODEL_IDS = {
     "depth-anything/Depth-Anything-V2-Base-hf": "vitb",
     "depth-anything/Depth-Anything-V2-Large-hf": "vitl",
 }
+# metric variants (reference utils.py:761-769): same architecture, head ends in sigmoid * max_depth
+# (HF config.json: depth_estimation_type "metric", max_depth 20 indoor / 80 outdoor)
+METRIC_MODEL_IDS = {
+    f"depth-anything/Depth-Anything-V2-Metric-{scene}-{size}-hf": (arch, max_depth)
+    for scene, max_depth in (("Indoor", 20.0), ("Outdoor", 80.0))
+    for size, arch in (("Small", "vits"), ("Base", "vitb"), ("Large", "vitl"))
+}
+
+
+def is_metric_id(model_id: str) -> bool:
+    """reference depth.py:666: inversion in normalize() is keyed off the model id."""
+    return any(k in model_id.lower() for k in ("metric", "kitti", "nyu", "depth-ai", "da3"))
 
 
 @dataclass
@@ -75,6 +87,7 @@ class PipelineParams:
     convergence: float = 0.0           # utils.py:852
     display_mode: str = "Half-SBS"     # utils.py:840
     fill_16_9: bool = True             # utils.py:900
+    metric: bool = False               # is_metric(), depth.py:666-669 (1/d inversion in normalize)
     mean: Tuple[float, float, float] = IMAGENET_MEAN
     std: Tuple[float, float, float] = IMAGENET_STD
 

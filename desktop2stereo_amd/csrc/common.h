@@ -40,6 +40,12 @@ __host__ __device__ static inline float bf2f(bf16_t h) {
     union { float f; uint32_t u; } v; v.u = ((uint32_t)h) << 16; return v.f;
 }
 
+// last activation of the DPT head (HF DepthAnythingDepthEstimationHead.forward): ReLU for relative models,
+// sigmoid(x) * max_depth for metric ones (depth_estimation_type == "metric")
+__device__ static inline float head_activation(float v, float max_depth) {
+    return max_depth > 0.f ? (1.0f / (1.0f + expf(-v))) * max_depth : fmaxf(v, 0.f);
+}
+
 // ---- bilinear source taps, torch semantics (ATen area_pixel_compute_source_index) -------------
 struct Tap { int i0, i1; float w0, w1; };
 

@@ -416,11 +416,11 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
             // which launch_gemm's auto rule picks for exactly this shape)
             GemmA a = convA(Y, e->h, e->w, F / 2, e->h, e->w, 1, 0);
             GemmEpi ep = rowsE(depth, OUT_F32, 1, e->head2.bias);
-            ep.map = MAP_HEAD; ep.scale = e->w3; ep.head_b3 = e->b3;
+            ep.map = MAP_HEAD; ep.scale = e->w3; ep.head_b3 = e->b3; ep.head_max_depth = d.max_depth;
             PROF(PC_CONV, 2.0 * Mh * Nh * e->head2.K, 0, launch_gemm(prec, bn == 32 ? 25632 : 25664, a, e->head2.w, Mh, Nh, e->head2.K, e->head2.Kpad, ep, st));
         } else {
             RC(conv3(e, Y, B, e->h, e->w, F / 2, 1, 0, e->head2, Z, ACT_RELU, nullptr, nullptr, st));
-            PROF(PC_ELT, 0, 0, launch_head_final(prec, Z, e->w3, e->b3, depth, (long)B * e->h * e->w, d.head_hidden, st));
+            PROF(PC_ELT, 0, 0, launch_head_final(prec, Z, e->w3, e->b3, d.max_depth, depth, (long)B * e->h * e->w, d.head_hidden, st));
         }
     }
     if (d.temporal) {                                    // one window step per frame (vda2_s.py:177-187, 214-221)
@@ -441,6 +441,8 @@ extern "C" int d2s_engine_create(const d2s_model_desc* desc, int device_id, d2s_
     D2S_REQUIRE(desc->precision == D2S_PREC_FP32 || desc->precision == D2S_PREC_BF16, "bad precision");
     for (int i = 0; i < 4; ++i) D2S_REQUIRE(desc->neck[i] % 8 == 0 && desc->out_indices[i] >= 1 && desc->out_indices[i] <= desc->layers, "bad neck / out_indices");
     D2S_REQUIRE(desc->head_hidden % 4 == 0 && desc->mlp % 8 == 0, "bad head_hidden / mlp");
+    D2S_REQUIRE(desc->max_depth >= 0.f && !(desc->temporal && desc->max_depth > 0.f),
+                "max_depth must be >= 0, and 0 for a Video-Depth-Anything engine (its head ends in ReLU, dpt_temporal.py:136)");
     D2S_HIP(hipSetDevice(device_id));
     d2s_engine* e = new d2s_engine();
     e->d = *desc; e->device = device_id; e->prec = desc->precision;

@@ -40,6 +40,7 @@ struct GemmEpi {
     float* part; size_t part_elems; int ksplit;
     // MAP_HEAD: out = float depth[M]; bias = conv2 bias, scale = conv3 weights [N], head_b3 = conv3 bias
     float head_b3;
+    float head_max_depth;                  // 0: ReLU; > 0: sigmoid * max_depth (metric head)
 };
 
 // precision: D2S_PREC_FP32 (T = float) / D2S_PREC_BF16 (T = bf16).  tile: 0 = auto, 64, 128, 256128, 256256.

@@ -425,7 +425,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
                 });
                 s += __shfl_xor(s, 16);
                 s += __shfl_xor(s, 32);
-                if (fg == 0 && m < M) ((float*)e.out)[m] = fmaxf(s + e.head_b3, 0.f);
+                if (fg == 0 && m < M) ((float*)e.out)[m] = head_activation(s + e.head_b3, e.head_max_depth);
             });
             return;
         }

@@ -23,8 +23,15 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 // One block per frame: v = depth.flatten()[::step] (m <= cap values, held in registers), then an exact
 // radix select (4 passes x 8 bits, LDS histograms) of the two order statistics
 //   bounds[b] = { s[tail-1], s[m-tail] }   (the tail-th smallest / largest; no lerp, depth.py:784-794).
+//
+// METRIC (is_metric(), depth.py:844-847): the values are inv = 1/max(d,1e-12) of the VALID pixels (d > 0) only, in
+// row-major order, so the subsample positions depend on the data: a block-wide scan ranks the valid pixels, the
+// step / m / tail follow from the valid count, and the r-th valid pixel is sample r/step iff r % step == 0.
+__device__ __forceinline__ float metric_inverse(float d) { return d > 0.f ? 1.0f / fmaxf(d, 1e-12f) : d; }
+
+template <bool METRIC>
 __global__ void __launch_bounds__(SORT_THREADS)
-percentile_bounds_kernel(const float* __restrict__ depth, int n, int step, int m, int tail,
+percentile_bounds_kernel(const float* __restrict__ depth, int n, int step, int m, int tail, int cap, double lo_q,
                          float* __restrict__ bounds) {
     constexpr int PER = SORT_N / SORT_THREADS;
     __shared__ unsigned hist[2][256];
@@ -32,8 +39,41 @@ percentile_bounds_kernel(const float* __restrict__ depth, int n, int step, int m
     const float* d = depth + (long)blockIdx.x * n;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     uint32_t key[PER];
+    int nvalid = n;
+    if constexpr (METRIC) {
+        __shared__ uint32_t samp[SORT_N];
+        __shared__ int wave_cnt[SORT_THREADS / 64];
+        __shared__ int s_nv;
+        const int chunk = (n + SORT_THREADS - 1) / SORT_THREADS;
+        const int i0 = min(n, tid * chunk), i1 = min(n, i0 + chunk);
+        int cnt = 0;
+        for (int i = i0; i < i1; ++i) cnt += d[i] > 0.f;
+        int incl = cnt;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) { int idx = tid + i * SORT_THREADS; key[i] = idx < m ? f2key(d[(long)idx * step]) : 0u; }
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) wave_cnt[wid] = incl;
+        __syncthreads();
+        int base = incl - cnt;
+        for (int w = 0; w < wid; ++w) base += wave_cnt[w];
+        if (tid == SORT_THREADS - 1) s_nv = base + cnt;
+        __syncthreads();
+        nvalid = s_nv;
+        step = nvalid > cap ? (nvalid + cap - 1) / cap : 1;
+        m = (nvalid + step - 1) / step;
+        tail = (int)nearbyint(lo_q * (double)(m - 1)) + 1;
+        tail = max(1, min(tail, m));
+        int r = base;
+        for (int i = i0; i < i1; ++i) {
+            float v = d[i];
+            if (v > 0.f) { if (r % step == 0) samp[r / step] = f2key(metric_inverse(v)); ++r; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { int idx = tid + i * SORT_THREADS; key[i] = idx < m ? samp[idx] : 0u; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { int idx = tid + i * SORT_THREADS; key[i] = idx < m ? f2key(d[(long)idx * step]) : 0u; }
+    }
     if (tid == 0) {
         bool all = tail >= m;                                   // depth.py:790-791: (min, max)
         sel_rank[0] = all ? 0 : tail - 1; sel_rank[1] = all ? m - 1 : m - tail;
@@ -71,7 +111,7 @@ percentile_bounds_kernel(const float* __restrict__ depth, int n, int step, int m
     }
     if (tid == 0) {
         float lo = key2f(sel_prefix[0]), hi = key2f(sel_prefix[1]);
-        if (n <= 10) { lo = 0.f; hi = 0.f; }                     // depth.py:852-854
+        if (nvalid <= 10) { lo = 0.f; hi = 0.f; }                // depth.py:852-854
         bounds[2 * blockIdx.x] = lo;
         bounds[2 * blockIdx.x + 1] = hi;
     }
@@ -96,7 +136,7 @@ struct GaussTaps { int k; float w[MAX_TAPS]; };
 // shaped row staged in LDS (zero padded), k taps out of LDS.
 __global__ void __launch_bounds__(256)
 shape_hblur_kernel(const float* __restrict__ depth, const float* __restrict__ bounds, float* __restrict__ tmp,
-                   int h, int w, float gamma, float fg_exp, int fg_on, GaussTaps taps) {
+                   int h, int w, float gamma, float fg_exp, int fg_on, int metric, GaussTaps taps) {
     extern __shared__ float row[];                       // w + 2r
     int y = blockIdx.x % h, b = blockIdx.x / h;
     int r = taps.k / 2;
@@ -104,7 +144,13 @@ shape_hblur_kernel(const float* __restrict__ depth, const float* __restrict__ bo
     const float* src = depth + ((long)b * h + y) * w;
     for (int i = threadIdx.x; i < w + 2 * r; i += 256) {
         int x = i - r;
-        row[i] = (x >= 0 && x < w) ? shape_depth(src[x], dmin, dmax, gamma, fg_exp, fg_on != 0) : 0.f;
+        float v = 0.f;
+        if (x >= 0 && x < w) {
+            v = src[x];
+            if (metric) v = metric_inverse(v);                                     // depth.py:844-846
+            v = shape_depth(v, dmin, dmax, gamma, fg_exp, fg_on != 0);
+        }
+        row[i] = v;
     }
     __syncthreads();
     float* dst = tmp + ((long)b * h + y) * w;
@@ -173,7 +219,12 @@ extern "C" int d2s_post_process(float* depth, int batch, int h, int w, const d2s
     int tail = (int)nearbyint(lo_q * (m - 1)) + 1;
     if (tail < 1) tail = 1;
     if (tail > m) tail = m;
-    hipLaunchKernelGGL(percentile_bounds_kernel, dim3(batch), dim3(SORT_THREADS), 0, st, depth, n, step, m, tail, bounds);
+    if (p->metric)
+        hipLaunchKernelGGL(percentile_bounds_kernel<true>, dim3(batch), dim3(SORT_THREADS), 0, st, depth, n, step, m, tail,
+                           p->subsample_cap, lo_q, bounds);
+    else
+        hipLaunchKernelGGL(percentile_bounds_kernel<false>, dim3(batch), dim3(SORT_THREADS), 0, st, depth, n, step, m, tail,
+                           p->subsample_cap, lo_q, bounds);
     // Gaussian taps: k = int(3 s) | 1, sigma = 0.5 s, float32 like the reference (depth.py:746-758)
     GaussTaps taps;
     int k = ((int)(3.0f * p->aa_strength)) | 1;
@@ -188,7 +239,7 @@ extern "C" int d2s_post_process(float* depth, int batch, int h, int w, const d2s
     float fg_exp = 1.0f / (1.0f + p->foreground_scale);
     int r = taps.k / 2;
     hipLaunchKernelGGL(shape_hblur_kernel, dim3(batch * h), dim3(256), (w + 2 * r) * sizeof(float), st,
-                       depth, bounds, tmp, h, w, p->gamma, fg_exp, fg_on, taps);
+                       depth, bounds, tmp, h, w, p->gamma, fg_exp, fg_on, p->metric != 0, taps);
     hipLaunchKernelGGL(vblur_kernel, dim3(cdiv((long)batch * h * w, 256)), dim3(256), 0, st, tmp, depth, batch, h, w, taps);
     D2S_CHECK_LAUNCH();
     return D2S_OK;

@@ -3,7 +3,7 @@
 //   cls_rows        cls token + pos[0] rows of the residual stream  (HF Dinov2Embeddings.forward)
 //   layernorm       fp32 residual -> T, eps 1e-6, optional cls drop (HF Dinov2Layer norm1/norm2, Dinov2Backbone.layernorm)
 //   bilinear_nhwc   align_corners=True up-sample of NHWC maps       (HF DepthAnythingFeatureFusionLayer / head)
-//   head_final      conv3 (1x1, C->1) + ReLU                        (HF DepthAnythingDepthEstimationHead)
+//   head_final      conv3 (1x1, C->1) + ReLU | sigmoid*max_depth                      (HF DepthAnythingDepthEstimationHead)
 #include "vit_ops.h"
 
 namespace d2s {
@@ -126,14 +126,14 @@ bilinear_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-head_final_kernel(const T* __restrict__ x, const float* __restrict__ w3, float b3, float* __restrict__ depth,
+head_final_kernel(const T* __restrict__ x, const float* __restrict__ w3, float b3, float max_depth, float* __restrict__ depth,
                   long npix, int C) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix) return;
     const T* p = x + idx * C;
     float acc = 0.f;
     for (int c = 0; c < C; ++c) acc += tof(p[c]) * w3[c];
-    depth[idx] = fmaxf(acc + b3, 0.f);
+    depth[idx] = head_activation(acc + b3, max_depth);
 }
 
 template <typename T>
@@ -184,10 +184,10 @@ int launch_bilinear_nhwc(int prec, const void* in, void* out, int B, int Hi, int
     return D2S_OK;
 }
 
-int launch_head_final(int prec, const void* x, const float* w3, float b3, float* depth, long npix, int C, hipStream_t st) {
+int launch_head_final(int prec, const void* x, const float* w3, float b3, float max_depth, float* depth, long npix, int C, hipStream_t st) {
     dim3 grid(cdiv(npix, 256)), block(256);
-    DISPATCH_T(prec, hipLaunchKernelGGL(head_final_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, w3, b3, depth, npix, C),
-                     hipLaunchKernelGGL(head_final_kernel<float>, grid, block, 0, st, (const float*)x, w3, b3, depth, npix, C));
+    DISPATCH_T(prec, hipLaunchKernelGGL(head_final_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, w3, b3, max_depth, depth, npix, C),
+                     hipLaunchKernelGGL(head_final_kernel<float>, grid, block, 0, st, (const float*)x, w3, b3, max_depth, depth, npix, C));
     D2S_CHECK_LAUNCH();
     return D2S_OK;
 }

@@ -17,11 +17,12 @@ plus ``predict`` / ``to_stereo`` (the names BASELINE.json's north_star uses) and
   * every computation is a HIP kernel behind the C-ABI; if the library or a GPU is missing the
     call raises -- there is no eager-PyTorch fallback (the reference degrades silently,
     depth.py:1597-1631);
-  * BGR(A)->RGB ``process`` keeps only the channel swizzle + optional area down-scale contract
-    for uint8 frames (the capture side is out of scope).
+  * ``process`` implements the torch branch of the reference (the one a ROCm device takes,
+    depth.py:540-566), not the cv2/UMat branch of CPU-only hosts (depth.py:570-629).
 """
 from __future__ import annotations
 
+import dataclasses
 from threading import Lock
 from typing import Dict, Optional
 
@@ -29,7 +30,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from .config import MODELS, MODEL_IDS, ModelConfig, PipelineParams, engine_shape
+from .config import METRIC_MODEL_IDS, MODELS, MODEL_IDS, ModelConfig, PipelineParams, engine_shape, is_metric_id
 
 _state = {"cfg": None, "weights": None, "params": PipelineParams(), "precision": "bf16", "device": 0,
           "engine": None, "engine_key": None, "max_batch": 1}
@@ -46,10 +47,19 @@ def configure(model="vitb", weights: Optional[Dict[str, np.ndarray]] = None, par
     vda = {"depth-anything/Video-Depth-Anything-Small": "vits", "depth-anything/Video-Depth-Anything-Base": "vitb",
            "depth-anything/Video-Depth-Anything-Large": "vitl", "vda_tiny": "tiny", "vda_vits": "vits", "vda_vitb": "vitb",
            "vda_vitl": "vitl"}
+    vda.update({k.replace("/Video-", "/Metric-Video-"): v for k, v in list(vda.items()) if "/Video-" in k})
+    # metric ids (reference depth.py:666: is_metric() is keyed off the id): normalize() inverts 1/d; the HF
+    # Metric-Indoor/Outdoor checkpoints additionally end in sigmoid * max_depth
+    metric = isinstance(model, str) and is_metric_id(model)
+    max_depth = 0.0
+    if isinstance(model, str) and model in METRIC_MODEL_IDS:
+        model, max_depth = METRIC_MODEL_IDS[model]
     temporal = isinstance(model, str) and model in vda
     if temporal:
         model = vda[model]
     cfg = model if isinstance(model, ModelConfig) else MODELS[MODEL_IDS.get(model, model)]
+    if metric:
+        params = dataclasses.replace(params or PipelineParams(), metric=True)
     if weights is None:
         if temporal:
             from .vda_weights import make_vda_weights
@@ -69,7 +79,7 @@ def configure(model="vitb", weights: Optional[Dict[str, np.ndarray]] = None, par
         if _state["engine"] is not None:
             _state["engine"].close()
         _state.update(cfg=cfg, weights=weights, params=params or PipelineParams(), precision=precision, device=device,
-                      engine=None, engine_key=None, max_batch=max_batch, temporal=temporal)
+                      engine=None, engine_key=None, max_batch=max_batch, temporal=temporal, max_depth=max_depth)
     depth_stabilizer.prev = None
 
 
@@ -90,20 +100,31 @@ def _ensure_engine_built(engine_h: int, engine_w: int) -> ops.Engine:
         if _state["engine"] is not None:
             _state["engine"].close()
         _state["engine"] = ops.Engine(_state["cfg"], _state["weights"], engine_h, engine_w, _state["max_batch"],
-                                      _state["precision"], _state["device"], temporal=_state.get("temporal", False))
+                                      _state["precision"], _state["device"], temporal=_state.get("temporal", False),
+                                      max_depth=_state.get("max_depth", 0.0))
         _state["engine_key"] = key
     return _state["engine"]
 
 
-def process(img, height: int):
-    """BGR(A) -> RGB, optional down-scale to `height` rows (reference depth.py:570-629, numpy path).
-    Only the uint8 numpy swizzle is provided host-side; frames normally arrive as RGB already."""
-    a = np.asarray(img)
-    rgb = np.ascontiguousarray(a[..., 2::-1] if a.shape[-1] >= 3 else a)
-    h0, w0 = rgb.shape[:2]
-    if height < h0:
-        raise _lib.D2SError("process(): OUTPUT_RESOLUTION down-scaling is outside the implemented hot path (SURVEY.md 8f4)")
-    return rgb
+def process(img_uint8, target_height: int) -> torch.Tensor:
+    """HWC uint8 BGR / BGRA capture frame (numpy or tensor) -> CHW float32 RGB 0..255 on the device, down-scaled to
+    `target_height` rows (even dims, bilinear + antialias) when the frame is taller: the branch of the reference's
+    process() a ROCm device takes (reference depth.py:540-566).  The result feeds predict_depth / make_sbs."""
+    t = torch.from_numpy(np.ascontiguousarray(img_uint8)) if isinstance(img_uint8, np.ndarray) else img_uint8
+    return ops.process(t.to(device=_device()), target_height)
+
+
+_FPS_MASK_CACHE = {"text": None, "frame": 0, "interval": 10}      # reference depth.py:2054-2059
+
+
+def overlay_fps(rgb: torch.Tensor, fps: float) -> torch.Tensor:
+    """Paint "FPS: %.1f" on a frame (reference depth.py:2061-2103).  Like the reference's cached mask, the
+    text is rebuilt only every 10th call; unlike it, the frame is painted in place (callers pass a private copy)."""
+    cache = _FPS_MASK_CACHE
+    cache["frame"] += 1
+    if cache["text"] is None or cache["frame"] % cache["interval"] == 0:
+        cache["text"] = f"FPS: {fps:.1f}"
+    return ops.overlay_text(rgb, cache["text"])
 
 
 class DepthStabilizer:
@@ -168,10 +189,8 @@ def make_sbs_core(rgb: torch.Tensor, depth: torch.Tensor, ipd_uv=0.064, depth_ra
 
 
 def make_sbs(rgb_c, depth, ipd_uv=0.064, depth_ratio=2.0, convergence=0.0, fill_16_9=False, display_mode="Half-SBS", fps=None):
-    """-> HWC float32 numpy 0..255, like the reference (depth.py:2186-2231).  `fps` overlay is not
-    part of the hot path (reference depth.py:2061-2103) and is rejected rather than ignored."""
-    if fps is not None:
-        raise _lib.D2SError("make_sbs(fps=...) overlay is outside the implemented hot path")
+    """-> HWC float32 numpy 0..255, like the reference (depth.py:2186-2231); `fps` paints the reference's
+    FPS overlay on the source frame before the warp (depth.py:2216-2218)."""
     if isinstance(depth, np.ndarray):
         depth = torch.from_numpy(depth)
     depth = depth.to(device=_device())
@@ -183,6 +202,11 @@ def make_sbs(rgb_c, depth, ipd_uv=0.064, depth_ratio=2.0, convergence=0.0, fill_
         rgb = rgb_c.to(device=_device())
         if rgb.dtype != torch.uint8:
             rgb = rgb.float()
+    if fps is not None:
+        rgb = rgb.contiguous()
+        if isinstance(rgb_c, torch.Tensor) and rgb.data_ptr() == rgb_c.data_ptr():
+            rgb = rgb.clone()                                   # never paint the caller's frame
+        rgb = overlay_fps(rgb, fps)
     sp = ops.sbs_params(ipd_uv, depth_ratio, convergence, display_mode, fill_16_9)
     return ops.make_sbs(rgb, depth, sp, _lib.FMT_F32_HWC).cpu().numpy()
 

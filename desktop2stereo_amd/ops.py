@@ -33,7 +33,8 @@ def _need_cuda(t: torch.Tensor, what: str):
 
 
 def post_params(p: PipelineParams) -> PostParams:
-    return PostParams(p.percentile, p.subsample_cap, p.gamma, p.foreground_scale, p.aa_strength, p.ema_alpha)
+    return PostParams(p.percentile, p.subsample_cap, p.gamma, p.foreground_scale, p.aa_strength, p.ema_alpha,
+                      int(bool(p.metric)))
 
 
 def sbs_params(ipd_uv=0.064, depth_ratio=2.0, convergence=0.0, display_mode="Half-SBS", fill_16_9=False) -> SbsParams:
@@ -60,6 +61,37 @@ def _frame_fmt(t: torch.Tensor) -> Tuple[int, int, int, int]:
         if t.dtype == torch.float32:
             return FMT_F32_CHW, b, t.shape[-2], t.shape[-1]
     raise ValueError(f"unsupported frame tensor {tuple(t.shape)} {t.dtype}: want uint8 [..,H,W,3], uint8/float32 [..,3,H,W]")
+
+
+def process(img_bgr: torch.Tensor, target_height: int) -> torch.Tensor:
+    """A1 (reference depth.py:540-566): uint8 HWC BGR(A) device tensor -> float32 CHW RGB 0..255, anti-aliased
+    bilinear down-scale to even dims when target_height < H0."""
+    _need_cuda(img_bgr, "img")
+    if img_bgr.dtype != torch.uint8 or img_bgr.dim() != 3 or img_bgr.shape[-1] not in (3, 4):
+        raise ValueError(f"process(): want uint8 [H,W,3|4] (BGR / BGRA), got {tuple(img_bgr.shape)} {img_bgr.dtype}")
+    img_bgr = img_bgr.contiguous()
+    H0, W0, ch = img_bgr.shape
+    lib = _lib.load()
+    oh, ow = C.c_int(), C.c_int()
+    check(lib.d2s_process_shape(H0, W0, int(target_height), C.byref(oh), C.byref(ow)), "d2s_process_shape")
+    out = torch.empty((3, oh.value, ow.value), dtype=torch.float32, device=img_bgr.device)
+    check(lib.d2s_process(_ptr(img_bgr), ch, H0, W0, int(target_height), _ptr(out), _stream()), "d2s_process")
+    return out
+
+
+def overlay_text(frame: torch.Tensor, text: str) -> torch.Tensor:
+    """A15 (reference depth.py:2061-2103): paint `text` in the reference's 5x3 font, green, IN PLACE on one frame."""
+    _need_cuda(frame, "frame")
+    if not frame.is_contiguous():
+        raise ValueError("overlay_text paints in place: the frame must be contiguous")
+    if frame.dtype == torch.float32 and frame.dim() == 3 and frame.shape[-1] == 3 and frame.shape[0] != 3:
+        fmt, H, W = FMT_F32_HWC, frame.shape[0], frame.shape[1]
+    else:
+        fmt, B, H, W = _frame_fmt(frame)
+        if B != 1:
+            raise ValueError("overlay_text takes one frame")
+    check(_lib.load().d2s_overlay_text(_ptr(frame), fmt, H, W, text.encode(), _stream()), "d2s_overlay_text")
+    return frame
 
 
 def preprocess(frames: torch.Tensor, target: int, patch: int = 14, mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
@@ -138,8 +170,9 @@ class Engine:
     backend (reference depth.py:1539-1781).  ``__call__(tensor[B,3,h,w]) -> tensor[B,h,w]``."""
 
     def __init__(self, cfg: ModelConfig, weights: Dict[str, np.ndarray], h: int, w: int, max_batch: int = 1,
-                 precision: str = "bf16", device: int = 0, temporal: bool = False):
-        """temporal=True: streaming Video-Depth-Anything (weights from vda_weights; one stream, batch 1)."""
+                 precision: str = "bf16", device: int = 0, temporal: bool = False, max_depth: float = 0.0):
+        """temporal=True: streaming Video-Depth-Anything (weights from vda_weights; one stream, batch 1).
+        max_depth > 0: metric head, sigmoid * max_depth (HF depth_estimation_type "metric")."""
         if not torch.cuda.is_available():
             raise _lib.D2SError("no ROCm device: the HIP engine cannot run (and there is no fallback)")
         self.lib = _lib.load()
@@ -148,7 +181,7 @@ class Engine:
         self.device = torch.device("cuda", device)
         desc = ModelDesc(cfg.hidden, cfg.heads, cfg.layers, (C.c_int32 * 4)(*cfg.out_indices), (C.c_int32 * 4)(*cfg.neck),
                          cfg.fusion, cfg.head_hidden, cfg.mlp, cfg.patch, cfg.pos_grid, cfg.ln_eps,
-                         PREC_BF16 if precision == "bf16" else PREC_FP32, int(bool(temporal)))
+                         PREC_BF16 if precision == "bf16" else PREC_FP32, int(bool(temporal)), float(max_depth))
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
         self._h = C.c_void_p()

@@ -68,6 +68,9 @@ typedef struct d2s_model_desc {
     int32_t precision;         /* D2S_PREC_* */
     int32_t temporal;          /* 1: Video-Depth-Anything streaming head (4 temporal modules, 32-frame window; reference
                                   models/video_depth_anything/vda2_s.py, dpt_temporal.py); batch must be 1 */
+    float   max_depth;         /* 0: relative head (conv3 -> ReLU).  > 0: metric head, sigmoid(conv3) * max_depth
+                                  (HF depth_estimation_type="metric": 20 indoor / 80 outdoor; reference model ids
+                                  utils.py:761-769) */
 } d2s_model_desc;
 
 /* Post-process constants (reference utils.py:858-859, depth.py:775, 816, 1889). */
@@ -78,6 +81,8 @@ typedef struct d2s_post_params {
     float   foreground_scale;  /* FOREGROUND_SCALE = yaml/10 */
     float   aa_strength;       /* AA_STRENGTH = yaml*2 */
     float   ema_alpha;         /* 0.9 */
+    int32_t metric;            /* is_metric() (reference depth.py:666-669): normalize() first inverts 1/d on d > 0
+                                  and takes the order statistics over the valid values only (depth.py:844-847) */
 } d2s_post_params;
 
 /* Stereo parameters of make_sbs_core (reference depth.py:2122-2129). */
@@ -113,6 +118,18 @@ int d2s_engine_memory(const d2s_engine* e, uint64_t* bytes);
 /* ---------------------------------------------------------------------------------------------
  * Stages.  Each mirrors one reference function; all device pointers, stream-ordered.
  * ------------------------------------------------------------------------------------------- */
+
+/* A1: process(img, height)  (reference depth.py:540-566, the torch branch a ROCm/CUDA device takes):
+ * bgr: uint8 HWC [H0,W0,channels], channels 3 (BGR) or 4 (BGRA) -> out: float RGB CHW [3,h,w], 0..255.
+ * target_height >= H0: swizzle only ((h,w) = (H0,W0)); else F.interpolate(bilinear, align_corners=False,
+ * antialias=True) to (h,w) = ((target//2)*2, (int(W0*target/H0)//2)*2) -- d2s_process_shape gives (h,w). */
+int d2s_process_shape(int H0, int W0, int target_height, int* out_h, int* out_w);
+int d2s_process(const uint8_t* bgr, int channels, int H0, int W0, int target_height, float* out, void* stream);
+
+/* A15: overlay_fps  (reference depth.py:2061-2103, glyphs depth.py:641-658): paints `text` (the reference's
+ * "FPS: %.1f"; characters outside its 16-glyph table render as blanks) in green (0,255,0) with the 5x3 font scaled
+ * by max(1,min(8,H//60)) at margin 2*scale, IN PLACE on one frame in any D2S_FMT_* layout. */
+int d2s_overlay_text(void* rgb, int fmt, int H, int W, const char* text, void* stream);
 
 /* A2-A4: ingest + _resize_patch_aligned_t CPU branch (strided decimation, bilinear
  * align_corners=False) + /255 + (x-mean)/std  (reference depth.py:676-706, 1916-1948).

@@ -229,10 +229,13 @@ def relu(x):
 
 
 class DepthAnythingOracle:
-    """float32 numpy forward of HF DepthAnythingForDepthEstimation (relative depth)."""
+    """float32 numpy forward of HF DepthAnythingForDepthEstimation.
+    max_depth == 0: relative head (conv3 -> ReLU); max_depth > 0: metric head, sigmoid(conv3) * max_depth
+    (HF DepthAnythingDepthEstimationHead with depth_estimation_type == "metric")."""
 
-    def __init__(self, cfg, weights: Dict[str, np.ndarray]):
+    def __init__(self, cfg, weights: Dict[str, np.ndarray], max_depth: float = 0.0):
         self.cfg = cfg
+        self.max_depth = float(max_depth)
         self.w = {k: np.asarray(v, dtype=F32) for k, v in weights.items()}
 
     # -- backbone ------------------------------------------------------------------------------
@@ -337,7 +340,11 @@ class DepthAnythingOracle:
         h = conv2d(fused, w["head.conv1.weight"], w["head.conv1.bias"], 1, 1)
         h = bilinear_resize(h, gh * cfg.patch, gw * cfg.patch, align_corners=True)
         h = relu(conv2d(h, w["head.conv2.weight"], w["head.conv2.bias"], 1, 1))
-        h = relu(conv2d(h, w["head.conv3.weight"], w["head.conv3.bias"]))
+        h = conv2d(h, w["head.conv3.weight"], w["head.conv3.bias"])
+        if getattr(self, "max_depth", 0.0) > 0.0:
+            h = (F32(1) / (F32(1) + np.exp(-h.astype(F32)))).astype(F32) * F32(self.max_depth)
+        else:
+            h = relu(h)
         return h[0].astype(F32)
 
     def forward(self, x: np.ndarray, taps: Optional[dict] = None, hooks: Optional[dict] = None) -> np.ndarray:
@@ -369,10 +376,17 @@ def percentile_bounds(d: np.ndarray, percentile=2.0, subsample_cap=6144):
     return s[tail - 1], s[n - tail]
 
 
-def normalize_depth(d: np.ndarray, percentile=2.0, subsample_cap=6144) -> np.ndarray:
-    """reference depth.py:816-867, non-metric branch."""
+def normalize_depth(d: np.ndarray, percentile=2.0, subsample_cap=6144, metric=False) -> np.ndarray:
+    """reference depth.py:816-867.  metric (is_metric(), :844-847): inv = 1/max(d,1e-12) on d > 0 (others keep d),
+    order statistics over the valid values only (row-major compaction), <= 10 valid values -> bounds (0, 0)."""
     d = np.asarray(d, dtype=F32)
-    dmin, dmax = percentile_bounds(d, percentile, subsample_cap)
+    if metric:
+        valid = d > 0
+        with np.errstate(divide="ignore"):
+            d = np.where(valid, F32(1) / np.maximum(d, F32(1e-12)), d).astype(F32)
+        dmin, dmax = percentile_bounds(d[valid], percentile, subsample_cap)
+    else:
+        dmin, dmax = percentile_bounds(d, percentile, subsample_cap)
     denom = np.maximum(F32(dmax) - F32(dmin), F32(1e-6))
     return np.clip((d - F32(dmin)) / denom, F32(0), F32(1)).astype(F32)
 
@@ -421,9 +435,9 @@ def anti_alias(d: np.ndarray, strength: float) -> np.ndarray:
     return v
 
 
-def post_process_depth(d, foreground_scale=0.05, aa_strength=4.0, gamma=1.45):
+def post_process_depth(d, foreground_scale=0.05, aa_strength=4.0, gamma=1.45, metric=False):
     """reference depth.py:806-814."""
-    d = normalize_depth(d)
+    d = normalize_depth(d, metric=metric)
     d = apply_gamma(d, gamma)
     d = apply_foreground_scale(d, foreground_scale)
     return anti_alias(d, aa_strength)
@@ -559,14 +573,88 @@ def to_u8(x: np.ndarray) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------------------------
+# A1 process() / A15 overlay_fps(): the rows either side of the path
+# ----------------------------------------------------------------------------------------------
+def _aa_weights(in_size: int, out_size: int):
+    """ATen _upsample_bilinear2d_aa per-output taps (third-party torch; UpSampleKernel.cpp
+    _compute_indices_min_size_weights_aa with the triangle filter): scale = in/out, support = scale (>= 1),
+    center = scale*(i+0.5), taps [xmin, xmin+xsize), weights normalised to sum 1."""
+    scale = F32(in_size) / F32(out_size)
+    support = scale if scale >= 1 else F32(1)
+    invscale = F32(1) / scale if scale >= 1 else F32(1)
+    taps = []
+    for i in range(out_size):
+        center = F32(scale * F32(i + 0.5))
+        xmin = max(int(float(F32(center - support)) + 0.5), 0)
+        xsize = min(int(float(F32(center + support)) + 0.5), in_size) - xmin
+        x = np.abs(((np.arange(xsize, dtype=F32) + F32(xmin)) - center + F32(0.5)) * invscale).astype(F32)
+        w = np.where(x < 1, F32(1) - x, F32(0)).astype(F32)
+        taps.append((xmin, (w / w.sum(dtype=F32)).astype(F32)))
+    return taps
+
+
+def process_frame(img_bgr: np.ndarray, target_height: int) -> np.ndarray:
+    """reference depth.py:540-566 (torch branch): HWC uint8 BGR(A) -> CHW float32 RGB 0..255; if target_height < H0,
+    F.interpolate(bilinear, align_corners=False, antialias=True) to ((t//2)*2, (int(W0*t/H0)//2)*2): separable,
+    horizontal pass then vertical pass."""
+    x = np.ascontiguousarray(img_bgr[..., :3][..., ::-1].transpose(2, 0, 1)).astype(F32)
+    _, H0, W0 = x.shape
+    if target_height >= H0:
+        return x
+    nh = (target_height // 2) * 2
+    nw = (int(W0 * target_height / H0) // 2) * 2
+    tx, ty = _aa_weights(W0, nw), _aa_weights(H0, nh)
+    hpass = np.empty((3, H0, nw), F32)
+    for j, (x0, w) in enumerate(tx):
+        acc = np.zeros((3, H0), F32)
+        for k in range(len(w)):
+            acc += w[k] * x[:, :, x0 + k]
+        hpass[:, :, j] = acc
+    out = np.empty((3, nh, nw), F32)
+    for i, (y0, w) in enumerate(ty):
+        acc = np.zeros((3, nw), F32)
+        for k in range(len(w)):
+            acc += w[k] * hpass[:, y0 + k, :]
+        out[:, i, :] = acc
+    return out
+
+
+_FONT = {  # reference depth.py:641-658 (5x3 glyphs)
+    "0": "111101101101111", "1": "010110010010111", "2": "111001111100111", "3": "111001111001111",
+    "4": "101101111001001", "5": "111100111001111", "6": "111100111101111", "7": "111001010100100",
+    "8": "111101111101111", "9": "111101111001111", "F": "111100110100100", "P": "110101110100100",
+    "S": "111100111001111", ":": "000010000010000", ".": "000000000000010", " ": "000000000000000",
+}
+
+
+def overlay_text(rgb_chw: np.ndarray, text: str) -> np.ndarray:
+    """reference depth.py:2061-2103 for one freshly built mask: glyphs scaled by max(1,min(8,H//60)), margin 2*scale,
+    spacing scale, clipped to the frame; rgb*(1-mask) + (0,255,0)*mask."""
+    _, H, W = rgb_chw.shape
+    scale = max(1, min(8, H // 60))
+    cw, ch = 3 * scale, 5 * scale
+    mask = np.zeros((H, W), F32)
+    for i, c in enumerate(text):
+        g = np.array([int(b) for b in _FONT.get(c, _FONT[" "])], F32).reshape(5, 3)
+        g = np.repeat(np.repeat(g, scale, 0), scale, 1)
+        x0, y0 = 2 * scale + i * (cw + scale), 2 * scale
+        x1, y1 = min(W, x0 + cw), min(H, y0 + ch)
+        if x0 < W and y0 < H:
+            mask[y0:y1, x0:x1] = np.maximum(mask[y0:y1, x0:x1], g[:y1 - y0, :x1 - x0])
+    color = np.array([0, 255, 0], F32).reshape(3, 1, 1)
+    return (rgb_chw.astype(F32) * (1 - mask) + color * mask).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------------
 # whole path
 # ----------------------------------------------------------------------------------------------
 class PipelineOracle:
     """predict_depth + make_sbs of the reference, CPU branch, float32 (autocast disabled)."""
 
     def __init__(self, cfg, weights, depth_resolution=518, foreground_scale=0.05, aa_strength=4.0,
-                 ema_alpha=0.9):
-        self.model = DepthAnythingOracle(cfg, weights)
+                 ema_alpha=0.9, metric=False, max_depth=0.0):
+        self.model = DepthAnythingOracle(cfg, weights, max_depth)
+        self.metric = metric
         self.target = depth_resolution
         self.fg = foreground_scale
         self.aa = aa_strength
@@ -582,7 +670,7 @@ class PipelineOracle:
         H, W = img_hwc_u8.shape[:2]
         x = self.model_input(img_hwc_u8)
         raw = self.model.forward(x, taps)
-        d = post_process_depth(raw, self.fg, self.aa)
+        d = post_process_depth(raw, self.fg, self.aa, metric=self.metric)
         if taps is not None:
             taps["model_input"] = x
             taps["raw_depth"] = raw

@@ -38,15 +38,31 @@ def _versions():
             "numpy": np.__version__, "reference_pins": "transformers==4.56.2, torch 2.7.1"}
 
 
-def gen_model(model: str, res: int, frames, store_inputs: bool, full_taps: bool, out: str, fp32=True):
+def gen_model(model: str, res: int, frames, store_inputs: bool, full_taps: bool, out: str, fp32=True, metric=""):
     """predict_depth taps for one (model, depth_resolution)."""
     import torch
     from ref_harness import load_reference
     from desktop2stereo_amd import synth
-    D = load_reference(model, res, seed=0, fp32=fp32)
+    D = load_reference(model, res, seed=0, fp32=fp32, metric=metric)
     data = {}
-    meta = {"model": model, "depth_resolution": res, "weights_seed": 0, "fp32": fp32,
+    meta = {"model": model, "depth_resolution": res, "weights_seed": 0, "fp32": fp32, "metric": metric,
+            "max_depth": {"": 0.0, "Indoor": 20.0, "Outdoor": 80.0}[metric],
             "frames": [], "versions": _versions()}
+    if metric:
+        # normalize()'s metric branch on a map WITH invalid pixels (d <= 0): the order statistics run over the
+        # compacted valid values (depth.py:844-847), which the model outputs (sigmoid > 0) never exercise
+        assert D.is_metric()
+        rng = np.random.default_rng(5)
+        dm = (synth.smooth_depth(120, 200, 3) * 19.0 + 0.5).astype(np.float32)
+        hole = rng.random(dm.shape) < 0.13
+        dm[hole] = np.where(rng.random(int(hole.sum())) < 0.5, 0.0, -1.5).astype(np.float32)
+        data["normcase_in"] = dm
+        data["normcase_norm"] = D.normalize(torch.from_numpy(dm.copy())).numpy()
+        data["normcase_post"] = D.post_process_depth(torch.from_numpy(dm.copy())).numpy()
+        few = np.zeros((4, 8), np.float32)
+        few.reshape(-1)[:7] = np.linspace(1, 7, 7)                      # 7 valid values (<= 10) -> bounds (0, 0)
+        data["fewcase_in"] = few
+        data["fewcase_norm"] = D.normalize(torch.from_numpy(few.copy())).numpy()
     D.depth_stabilizer.prev = None
     for fi, (kind, h, w, seed) in enumerate(frames):
         img = synth.structured_frame(h, w, seed) if kind == "S2" else synth.noise_frame(h, w, seed)
@@ -124,6 +140,50 @@ def gen_warp(out: str):
     print("wrote", out, len(data), "arrays")
 
 
+INGEST_CASES = [  # (name, H0, W0, channels, target_height, stored row stride)
+    ("bgra_1080_to_720", 1080, 1920, 4, 720, 45), ("bgr_270_to_100", 270, 480, 3, 100, 1),
+    ("bgr_90_keep", 90, 160, 3, 90, 1), ("bgra_101_to_33", 101, 75, 4, 33, 1), ("bgr_2160_to_1080", 2160, 3840, 3, 1080, 120),
+]
+OVERLAY_CASES = [("h90", 90, 160, 59.9), ("h270", 270, 480, 123.4), ("h1080", 1080, 1920, 7.0), ("narrow", 120, 30, 60.0)]
+
+
+def gen_ingest(out: str):
+    """A1 process() and A15 overlay_fps().  process(): a CPU-only container imports the reference's cv2 branch
+    (depth.py:570-629; cv2 is absent), so the torch branch a ROCm device takes (depth.py:540-566) is reproduced
+    with the same torch call, F.interpolate(bilinear, align_corners=False, antialias=True).  overlay_fps() is the
+    reference's own function."""
+    import torch
+    import torch.nn.functional as F
+    from ref_harness import load_reference
+    from desktop2stereo_amd import synth
+    D = load_reference("tiny", 84, seed=0, fp32=True)
+    data, meta = {}, {"process": [], "overlay": [], "versions": _versions()}
+    for name, H0, W0, ch, target, rs in INGEST_CASES:
+        img = np.random.default_rng([11, H0, W0]).integers(0, 256, (H0, W0, ch), dtype=np.uint8)
+        t = torch.from_numpy(img)[..., :3].flip(-1).permute(2, 0, 1).contiguous()
+        if target < H0:
+            nh, nw = (target // 2) * 2, (int(W0 * target / H0) // 2) * 2
+            t = F.interpolate(t.float().unsqueeze(0), size=(nh, nw), mode="bilinear", align_corners=False,
+                              antialias=nh < H0).squeeze(0)
+        res = t.float().numpy()
+        data["process_" + name] = res[:, ::rs]
+        meta["process"].append({"name": name, "H0": H0, "W0": W0, "channels": ch, "target": target, "row_stride": rs,
+                                "out_shape": list(res.shape), "seed": [11, H0, W0]})
+    for name, H, W, fps in OVERLAY_CASES:
+        rgb = torch.from_numpy(synth.structured_frame(H, W, 4)).permute(2, 0, 1).float()
+        D._FPS_MASK_CACHE.update(mask=None, frame=0)
+        res = D.overlay_fps(rgb, fps).numpy()
+        box_h, box_w = min(H, 60), min(W, 420)
+        data["overlay_" + name] = res[:, :box_h, :box_w]
+        meta["overlay"].append({"name": name, "H": H, "W": W, "fps": fps, "seed": 4, "box": [box_h, box_w],
+                                "changed_outside_box": bool((res[:, box_h:] != rgb.numpy()[:, box_h:]).any()
+                                                            or (res[:, :, box_w:] != rgb.numpy()[:, :, box_w:]).any())})
+    np.savez_compressed(out + ".npz", **data)
+    with open(out + ".json", "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote", out, {k: v.shape for k, v in data.items()})
+
+
 JOBS = {
     # KAT-tiny: every tap, 3 frames (EMA chain), inputs stored
     "tiny_r84": lambda o: gen_model("tiny", 84, [("S2", 90, 160, 0), ("S2", 90, 160, 1), ("S1", 90, 160, 2)],
@@ -136,7 +196,12 @@ JOBS = {
     "vits_r518_bf16": lambda o: gen_model("vits", 518, [("S2", 1080, 1920, 0)], False, False, o, fp32=False),
     # config 3 shapes: ViT-L, 3840x2160 frame (CPU branch decimates ::3 before the bilinear resize)
     "vitl_r518_4k": lambda o: gen_model("vitl", 518, [("S2", 2160, 3840, 0)], False, False, o),
+    # metric head + metric normalize (reference ids Depth-Anything-V2-Metric-{Indoor,Outdoor}-*)
+    "tiny_r84_metric": lambda o: gen_model("tiny", 84, [("S2", 90, 160, 0), ("S2", 90, 160, 1), ("S1", 90, 160, 2)],
+                                           True, True, o, metric="Indoor"),
+    "vits_r518_metric": lambda o: gen_model("vits", 518, [("S2", 1080, 1920, 0)], False, False, o, metric="Outdoor"),
     "warp": gen_warp,
+    "ingest": gen_ingest,
 }
 
 if __name__ == "__main__":

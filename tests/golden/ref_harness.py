@@ -23,7 +23,7 @@ _HF_NAME = {"vits": "Depth-Anything-V2-Small", "vitb": "Depth-Anything-V2-Base",
 
 
 def load_reference(model: str = "tiny", depth_resolution: int = 518, seed: int = 0,
-                   fp32: bool = True, aa: int = 2, fg: float = 0.5):
+                   fp32: bool = True, aa: int = 2, fg: float = 0.5, metric: str = ""):
     """Returns the reference ``depth`` module, model built with our weights.
 
     fp32=True patches depth.maybe_autocast -> nullcontext (reference depth.py:661-664), giving
@@ -44,7 +44,11 @@ def load_reference(model: str = "tiny", depth_resolution: int = 518, seed: int =
     scratch = tempfile.mkdtemp(prefix="d2s_ref_")
     with open(os.path.join(REF, "settings.yaml")) as f:
         st = yaml.safe_load(f)
-    st.update({"Depth Model": _HF_NAME[model], "FP16": False, "Depth Resolution": depth_resolution,
+    # metric = "Indoor" | "Outdoor": the reference's Depth-Anything-V2-Metric-* ids (utils.py:761-769): is_metric()
+    # becomes true (depth.py:666) and the HF head is built with depth_estimation_type="metric"
+    name = _HF_NAME[model].replace("V2-", f"V2-Metric-{metric}-") if metric else _HF_NAME[model]
+    max_depth = {"": None, "Indoor": 20, "Outdoor": 80}[metric]
+    st.update({"Depth Model": name, "FP16": False, "Depth Resolution": depth_resolution,
                "Run Mode": "Legacy Streamer", "torch.compile": False, "TensorRT": False,
                "CoreML": False, "OpenVINO": False, "MIGraphX": False,
                "Anti-aliasing": aa, "Foreground Scale": fg})
@@ -74,7 +78,8 @@ def load_reference(model: str = "tiny", depth_resolution: int = 518, seed: int =
                                  image_size=518, patch_size=14, out_indices=list(cfg.out_indices),
                                  apply_layernorm=True, reshape_hidden_states=False),
             reassemble_hidden_size=cfg.hidden, neck_hidden_sizes=list(cfg.neck),
-            fusion_hidden_size=cfg.fusion, head_hidden_size=cfg.head_hidden)
+            fusion_hidden_size=cfg.fusion, head_hidden_size=cfg.head_hidden,
+            **({"depth_estimation_type": "metric", "max_depth": max_depth} if metric else {}))
         m = DepthAnythingForDepthEstimation(hf)
         sd = {k: torch.from_numpy(v) for k, v in make_weights(cfg, seed).items()}
         missing, unexpected = m.load_state_dict(sd, strict=False)

@@ -33,8 +33,8 @@ def test_header_symbols_exported(lib):
 
 
 def test_struct_layout_matches_header():
-    assert C.sizeof(_lib.ModelDesc) == 4 * (3 + 4 + 4 + 5) + 4 + 4 + 4      # ... ln_eps, precision, temporal
-    assert C.sizeof(_lib.PostParams) == 24
+    assert C.sizeof(_lib.ModelDesc) == 4 * (3 + 4 + 4 + 5) + 4 + 4 + 4 + 4  # ... ln_eps, precision, temporal, max_depth
+    assert C.sizeof(_lib.PostParams) == 28 and _lib.PostParams.metric.offset == 24
     assert C.sizeof(_lib.SbsParams) == 24 and _lib.SbsParams.ipd_uv.offset == 0 and _lib.SbsParams.depth_ratio.offset == 8
 
 

@@ -55,6 +55,41 @@ def test_preprocess_matches_oracle(dev):
         assert np.abs(got - want).max() <= 2e-5
 
 
+def test_process_and_overlay_match_golden(dev, golden_dir):
+    """A1 process() vs torch's anti-aliased bilinear called as the reference calls it (<= 2e-4 of 255), A15
+    overlay_fps() vs the reference's function (exact), all four frame layouts."""
+    from desktop2stereo_amd import ops, synth
+    from oracle import d2s_oracle as O
+    z, meta = _golden(golden_dir, "ingest")
+    for c in meta["process"]:
+        img = np.random.default_rng(c["seed"]).integers(0, 256, (c["H0"], c["W0"], c["channels"]), dtype=np.uint8)
+        got = ops.process(_t(img, dev), c["target"]).cpu().numpy()
+        assert list(got.shape) == c["out_shape"], c
+        err = np.abs(got[:, ::c["row_stride"]] - z["process_" + c["name"]]).max()
+        assert err <= 2e-4, (c["name"], err)
+    img = np.random.default_rng(1).integers(0, 256, (333, 517, 3), dtype=np.uint8)      # odd sizes vs the oracle
+    for target in (332, 200, 77, 2, 400):
+        got = ops.process(_t(img, dev), target).cpu().numpy()
+        want = O.process_frame(img, target)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 2e-4, target
+    for c in meta["overlay"]:
+        hwc = synth.structured_frame(c["H"], c["W"], c["seed"])
+        chw = np.ascontiguousarray(hwc.transpose(2, 0, 1))
+        text = f"FPS: {c['fps']:.1f}"
+        bh, bw = c["box"]
+        ref = z["overlay_" + c["name"]]
+        full = O.overlay_text(chw.astype(np.float32), text)
+        outs = {
+            "f32_chw": ops.overlay_text(_t(chw.astype(np.float32), dev), text).cpu().numpy(),
+            "u8_chw": ops.overlay_text(_t(chw, dev), text).cpu().numpy().astype(np.float32),
+            "u8_hwc": ops.overlay_text(_t(hwc, dev), text).cpu().numpy().transpose(2, 0, 1).astype(np.float32),
+            "f32_hwc": ops.overlay_text(_t(hwc.astype(np.float32), dev), text).cpu().numpy().transpose(2, 0, 1),
+        }
+        for k, o in outs.items():
+            assert np.array_equal(o[:, :bh, :bw], ref), (c["name"], k)
+            assert np.array_equal(o, full), (c["name"], k)
+
+
 def test_post_process_matches_golden(dev, golden_dir):
     from desktop2stereo_amd import ops
     from desktop2stereo_amd.config import PipelineParams
@@ -282,6 +317,59 @@ def test_full_size_predict_depth(dev, golden_dir, name, model, res):
     print(f"[{name}] bf16 engine post-depth vs fp32 reference: max {d.max():.4f} mean {d.mean():.5f}")
     assert d.max() <= 0.06 and d.mean() <= 0.006, (d.max(), d.mean())
     eng.close()
+
+
+def test_metric_models(dev, golden_dir):
+    """Depth-Anything-V2-Metric-* (reference utils.py:761-769): sigmoid * max_depth head and normalize()'s
+    is_metric() branch (1/d on valid pixels, order statistics over the compacted valid values, depth.py:844-847)."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS, PipelineParams, engine_shape
+    from desktop2stereo_amd.weights import make_weights
+    from oracle import d2s_oracle as O
+    pm = PipelineParams(metric=True)
+    z, meta = _golden(golden_dir, "tiny_r84_metric")
+    # post-process alone: golden maps with holes (d <= 0), the <= 10-valid rule, model outputs
+    for key_in, key_out in [("normcase_in", "normcase_post"), ("f0_raw_depth", "f0_post_depth"), ("f2_raw_depth", "f2_post_depth")]:
+        got = ops.post_process_depth(_t(z[key_in], dev), pm).cpu().numpy()
+        assert np.abs(got - z[key_out]).max() <= 5e-6, key_in
+    few = ops.post_process_depth(_t(z["fewcase_in"], dev), pm).cpu().numpy()
+    assert np.abs(few - O.post_process_depth(z["fewcase_in"], pm.foreground_scale, pm.aa_strength, metric=True)).max() <= 5e-6
+    rng = np.random.default_rng(2)
+    for shape, frac in [((200, 311), 0.5), ((294, 518), 0.02), ((64, 64), 0.999), ((33, 47), 1.0)]:   # incl. all-invalid
+        d = rng.uniform(0.2, 80, shape).astype(np.float32)
+        d[rng.random(shape) < frac] = 0.0
+        got = ops.post_process_depth(_t(np.stack([d, d[::-1].copy()]), dev), pm).cpu().numpy()       # batched
+        for b, src in enumerate((d, d[::-1])):
+            want = O.post_process_depth(src, pm.foreground_scale, pm.aa_strength, metric=True)
+            assert np.abs(got[b] - want).max() <= 5e-6, (shape, frac, b)
+    # metric head, tiny engine (every frame) and ViT-S at 294x518
+    cfg = MODELS["tiny"]
+    eng = ops.Engine(cfg, make_weights(cfg, 0), 42, 84, 1, "fp32", max_depth=meta["max_depth"])
+    for fi in range(3):
+        raw = eng(_t(z[f"f{fi}_model_input"], dev))
+        assert np.abs(raw.cpu().numpy()[0] - z[f"f{fi}_raw_depth"]).max() <= 2e-3            # logit noise x slope <= 5
+        post = ops.post_process_depth(raw, pm).cpu().numpy()[0]
+        assert np.abs(post - z[f"f{fi}_post_depth"]).max() <= 1e-3
+    eng.close()
+    z, meta = _golden(golden_dir, "vits_r518_metric")
+    cfg = MODELS["vits"]
+    fr = meta["frames"][0]
+    h, w, _ = engine_shape(fr["h"], fr["w"], 518)
+    x = ops.preprocess(_t(synth.structured_frame(fr["h"], fr["w"], fr["seed"]), dev), 518)
+    for prec in ("fp32", "bf16"):
+        eng = ops.Engine(cfg, make_weights(cfg, 0), h, w, 1, prec, max_depth=meta["max_depth"])
+        raw = eng(x)
+        post = ops.post_process_depth(raw, pm).cpu().numpy()[0]
+        e_raw = np.abs(raw.cpu().numpy()[0] - z["f0_raw_depth"]) / meta["max_depth"]
+        e_post = np.abs(post - z["f0_post_depth"])
+        print(f"[metric vits {prec}] raw/max_depth: max {e_raw.max():.5f} mean {e_raw.mean():.6f}; post: max {e_post.max():.5f} mean {e_post.mean():.6f}")
+        if prec == "fp32":
+            assert e_raw.max() <= 2e-4 and e_post.max() <= 1e-3, (e_raw.max(), e_post.max())
+        else:
+            # seeded random weights drive the logits to +-15, so the sigmoid is a near-binary map and a bf16-sized logit
+            # error flips single pixels at its transitions: grade the mean, not the max
+            assert e_raw.mean() <= 0.01 and e_post.mean() <= 0.01, (e_raw.mean(), e_post.mean())
+        eng.close()
 
 
 def test_pipeline_end_to_end(dev):

@@ -90,6 +90,46 @@ def test_full_size_model(golden_dir, name, model, res):
     assert np.abs(taps["post_depth"] - z["f0_post_depth"]).max() <= 1e-4
 
 
+def test_metric_model_and_normalize(golden_dir, tiny):
+    """Depth-Anything-V2-Metric-* ids: sigmoid * max_depth head (HF) and normalize()'s is_metric() branch
+    (reference depth.py:844-847) incl. maps with invalid pixels and the <= 10-valid-values rule."""
+    cfg, w = tiny
+    z, meta = _load(golden_dir, "tiny_r84_metric")
+    assert meta["metric"] == "Indoor" and meta["max_depth"] == 20.0
+    orc = O.PipelineOracle(cfg, w, 84, metric=True, max_depth=meta["max_depth"])
+    for fi in range(len(meta["frames"])):
+        p = f"f{fi}_"
+        raw = orc.model.forward(z[p + "model_input"])
+        # logits carry the usual ~2e-5 * |logit| float32 noise; the sigmoid * 20 has slope up to 5
+        assert np.abs(raw - z[p + "raw_depth"]).max() <= 1.5e-3
+        np.testing.assert_allclose(O.normalize_depth(z[p + "raw_depth"], metric=True), z[p + "norm"], atol=2e-6)
+        np.testing.assert_allclose(O.post_process_depth(z[p + "raw_depth"], metric=True), z[p + "post_depth"], atol=3e-6)
+        d = orc.predict_depth(z[p + "img"], use_temporal_smooth=True)
+        np.testing.assert_allclose(d, z[p + "depth_ema_full"], atol=3e-4)       # 1/d amplifies the 2e-5 model noise
+    np.testing.assert_allclose(O.normalize_depth(z["normcase_in"], metric=True), z["normcase_norm"], atol=1e-6)
+    np.testing.assert_allclose(O.post_process_depth(z["normcase_in"], metric=True), z["normcase_post"], atol=2e-6)
+    np.testing.assert_allclose(O.normalize_depth(z["fewcase_in"], metric=True), z["fewcase_norm"], atol=1e-6)
+
+
+def test_process_and_overlay(golden_dir):
+    """A1 process() (BGR(A) swizzle + anti-aliased bilinear down-scale, depth.py:540-566) against torch's own kernel
+    called the way the reference calls it, and A15 overlay_fps() against the reference's function."""
+    z, meta = _load(golden_dir, "ingest")
+    for c in meta["process"]:
+        img = np.random.default_rng(c["seed"]).integers(0, 256, (c["H0"], c["W0"], c["channels"]), dtype=np.uint8)
+        got = O.process_frame(img, c["target"])
+        assert list(got.shape) == c["out_shape"], c
+        err = np.abs(got[:, ::c["row_stride"]] - z["process_" + c["name"]]).max()
+        assert err <= 2e-4, (c["name"], err)                 # of 255: float32 weight rounding of the separable filter
+    for c in meta["overlay"]:
+        assert not c["changed_outside_box"]
+        rgb = synth.structured_frame(c["H"], c["W"], c["seed"]).transpose(2, 0, 1).astype(np.float32)
+        got = O.overlay_text(rgb, f"FPS: {c['fps']:.1f}")
+        bh, bw = c["box"]
+        assert np.array_equal(got[:, :bh, :bw], z["overlay_" + c["name"]]), c["name"]
+        assert np.array_equal(got[:, bh:], rgb[:, bh:]) and np.array_equal(got[:, :, bw:], rgb[:, :, bw:])
+
+
 def test_warp_all_cases(golden_dir):
     """make_sbs with a given depth: all display modes x fill_16_9 x convergence, several aspect
     ratios (pads), 1080p rows.  Values within the reference's own float32 coordinate noise, and
