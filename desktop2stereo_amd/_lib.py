@@ -36,6 +36,13 @@ class SbsParams(C.Structure):
                 ("display_mode", C.c_int32), ("fill_16_9", C.c_int32)]
 
 
+class DibrParams(C.Structure):
+    _fields_ = [("ipd_uv", C.c_double), ("depth_strength", C.c_float), ("convergence", C.c_float), ("roll", C.c_float),
+                ("search_radius", C.c_float), ("depth_tolerance", C.c_float), ("blur_radius", C.c_float),
+                ("res_w", C.c_float), ("res_h", C.c_float), ("display_mode", C.c_int32),
+                ("feather_enabled", C.c_int32), ("feather_width", C.c_float)]
+
+
 # every symbol include/d2s.h declares: (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -59,6 +66,8 @@ SYMBOLS = {
     "d2s_make_sbs": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.POINTER(SbsParams), _P, C.c_int, _P]),
     "d2s_sbs_shape": (C.c_int, [C.c_int, C.c_int, C.POINTER(SbsParams), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "d2s_dibr_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "d2s_dibr_warp": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(DibrParams), _P, C.c_int, _P]),
     "d2s_pipeline": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(PostParams),
                                C.POINTER(SbsParams), C.c_int, _P, C.c_int, _P, _P]),
     "d2s_engine_reset_stream": (C.c_int, [_P]),

@@ -188,9 +188,26 @@ def make_sbs_core(rgb: torch.Tensor, depth: torch.Tensor, ipd_uv=0.064, depth_ra
     return ops.make_sbs(rgb, depth.to(device=_device()), sp, _lib.FMT_F32_CHW)
 
 
-def make_sbs(rgb_c, depth, ipd_uv=0.064, depth_ratio=2.0, convergence=0.0, fill_16_9=False, display_mode="Half-SBS", fps=None):
+def make_sbs(rgb_c, depth, ipd_uv=0.064, depth_ratio=2.0, convergence=0.0, fill_16_9=False, display_mode="Half-SBS", fps=None,
+             inpaint=False):
     """-> HWC float32 numpy 0..255, like the reference (depth.py:2186-2231); `fps` paints the reference's
-    FPS overlay on the source frame before the warp (depth.py:2216-2218)."""
+    FPS overlay on the source frame before the warp (depth.py:2216-2218).
+    inpaint=True (north_star's to_stereo(..., inpaint=True)) renders the reference's OTHER warp instead: the GLSL DIBR
+    shader with disocclusion in-painting of its Viewer modes (viewer.py:386-631), where the parallax is
+    viewer.depth_strength (0.1) * depth_ratio in uv units and fill_16_9 is a window-layout matter that does not apply."""
+    if inpaint:
+        if fps is not None or fill_16_9:
+            raise _lib.D2SError("make_sbs(inpaint=True): fps overlay / fill_16_9 belong to the torch warp (depth.py), "
+                                "not to the viewer shader path")
+        rgb = torch.from_numpy(np.ascontiguousarray(rgb_c)) if isinstance(rgb_c, np.ndarray) else rgb_c
+        rgb = rgb.to(device=_device())
+        if rgb.dim() == 3 and rgb.shape[0] == 3 and rgb.shape[-1] != 3:
+            rgb = rgb.permute(1, 2, 0)
+        if rgb.dtype != torch.uint8:                                   # viewer.py:2417: clamp(0,255).to(uint8)
+            rgb = rgb.clamp(0, 255).to(torch.uint8)
+        d = torch.from_numpy(depth) if isinstance(depth, np.ndarray) else depth
+        dp = ops.dibr_params(ipd_uv, depth_ratio, convergence, display_mode)
+        return ops.dibr_warp(rgb.contiguous(), d.to(device=_device()), dp, out_u8=False).cpu().numpy()
     if isinstance(depth, np.ndarray):
         depth = torch.from_numpy(depth)
     depth = depth.to(device=_device())

@@ -165,6 +165,40 @@ def make_sbs(frames: torch.Tensor, depth: torch.Tensor, sp: SbsParams, out_fmt: 
     return out if batched else out[0]
 
 
+def dibr_params(ipd_uv=0.064, depth_ratio=1.0, convergence=0.0, display_mode="Full-SBS", roll=0.0, feather=False,
+                viewer_depth_strength=0.1, search_radius=12.0, depth_tolerance=0.012, blur_radius=2.5,
+                feather_width=0.02, resolution=(0.0, 0.0)) -> _lib.DibrParams:
+    """Uniform block of the reference's DIBR shader with the viewer's defaults (viewer.py:1333-1343, 402-404)."""
+    if display_mode not in MODE:
+        raise ValueError(f"display_mode must be one of {list(MODE)}")
+    return _lib.DibrParams(float(ipd_uv), float(viewer_depth_strength * depth_ratio), float(convergence), float(roll),
+                           float(search_radius), float(depth_tolerance), float(blur_radius), float(resolution[0]),
+                           float(resolution[1]), MODE[display_mode], int(bool(feather)), float(feather_width))
+
+
+def dibr_warp(frames: torch.Tensor, depth: torch.Tensor, dp: "_lib.DibrParams", out_u8: bool = True) -> torch.Tensor:
+    """f1 (reference viewer.py:386-631): uint8 HWC frames [B,H,W,3] or [H,W,3] + full-resolution depth -> both eyes
+    with disocclusion in-painting, packed per dp.display_mode."""
+    _need_cuda(frames, "frames")
+    _need_cuda(depth, "depth")
+    if frames.dtype != torch.uint8 or frames.shape[-1] != 3 or frames.dim() not in (3, 4):
+        raise ValueError("dibr_warp: frames must be uint8 [B,H,W,3] or [H,W,3]")
+    batched = frames.dim() == 4
+    f = frames.contiguous() if batched else frames.contiguous().unsqueeze(0)
+    d = depth.to(torch.float32).contiguous()
+    d = d if d.dim() == 3 else d.unsqueeze(0)
+    B, H, W, _ = f.shape
+    if tuple(d.shape) != (B, H, W):
+        raise ValueError(f"dibr_warp: depth must be full resolution {(B, H, W)}, got {tuple(d.shape)}")
+    lib = _lib.load()
+    oh, ow = C.c_int(), C.c_int()
+    check(lib.d2s_dibr_shape(H, W, dp.display_mode, C.byref(oh), C.byref(ow)), "d2s_dibr_shape")
+    out = torch.empty((B, oh.value, ow.value, 3), dtype=torch.uint8 if out_u8 else torch.float32, device=f.device)
+    check(lib.d2s_dibr_warp(_ptr(f), _ptr(d), B, H, W, C.byref(dp), _ptr(out), FMT_U8_HWC if out_u8 else FMT_F32_HWC,
+                            _stream()), "d2s_dibr_warp")
+    return out if batched else out[0]
+
+
 class Engine:
     """The native depth engine: what DepthModelWrapper holds in ``self.model`` for an accelerated
     backend (reference depth.py:1539-1781).  ``__call__(tensor[B,3,h,w]) -> tensor[B,h,w]``."""

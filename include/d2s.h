@@ -94,6 +94,22 @@ typedef struct d2s_sbs_params {
     int32_t fill_16_9;         /* 0/1 */
 } d2s_sbs_params;
 
+/* Uniforms of the reference's GLSL DIBR fragment shader (viewer.py:393-411) for d2s_dibr_warp. */
+typedef struct d2s_dibr_params {
+    double  ipd_uv;            /* viewer.ipd_uv (0.064): u_eye_offset = -/+ ipd_uv/2 for the left/right eye (viewer.py:2701, 2714) */
+    float   depth_strength;    /* u_depth_strength = viewer.depth_strength (0.1) * depth_ratio (viewer.py:1334, 2686) */
+    float   convergence;       /* u_convergence (viewer.py:1470) */
+    float   roll;              /* u_roll, radians (xr_viewer/effects.py:1113); 0 in the desktop viewer */
+    float   search_radius;     /* u_search_radius = 12 */
+    float   depth_tolerance;   /* u_depth_tolerance = 0.012 */
+    float   blur_radius;       /* u_blur_radius = 2.5 */
+    float   res_w, res_h;      /* u_resolution; the reference never assigns it (pixel_size = 1/0, viewer.py:413):
+                                  0 -> the source frame size, i.e. pixel_size = one texel */
+    int32_t display_mode;      /* D2S_MODE_*: how the two eye viewports are packed */
+    int32_t feather_enabled;   /* u_feather_enabled */
+    float   feather_width;     /* u_feather_width = 0.02 (viewer.py:1343) */
+} d2s_dibr_params;
+
 const char* d2s_last_error(void);
 int d2s_version(void);
 
@@ -170,6 +186,15 @@ int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, int dh, int d
                  void* out, int out_fmt, void* stream);
 /* output frame size of make_sbs_core for an H x W input (pad_to_aspect_tensor, depth.py:2106-2119) */
 int d2s_sbs_shape(int H, int W, const d2s_sbs_params* p, int* out_h, int* out_w);
+
+/* f1: the GLSL DIBR warp with disocclusion in-painting the reference's Viewer / OpenXR modes render
+ * (FRAGMENT_SHADER, viewer.py:386-631): rgb uint8 HWC [batch,H,W,3], depth float [batch,H,W] (full resolution, as
+ * uploaded to tex_depth, viewer.py:2386, 2456) -> both eyes, each rendered into an H x W viewport (Half modes:
+ * W/2 columns resp. H/2 rows per eye) and packed left|right (SBS) or left over right (TAB); colour * alpha over
+ * black.  out_fmt: D2S_FMT_U8_HWC (round-half-even) or D2S_FMT_F32_HWC (0..255); shape from d2s_dibr_shape. */
+int d2s_dibr_shape(int H, int W, int display_mode, int* out_h, int* out_w);
+int d2s_dibr_warp(const uint8_t* rgb, const float* depth, int batch, int H, int W, const d2s_dibr_params* p,
+                  void* out, int out_fmt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused frame pipeline: predict_depth + make_sbs for a batch of frames
