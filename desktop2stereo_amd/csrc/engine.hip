@@ -244,6 +244,9 @@ GemmA plainA(const void* p, long lda) { GemmA a = {}; a.ptr = p; a.mode = A_PLAI
 GemmA convA(const void* p, int Hi, int Wi, int C, int Ho, int Wo, int stride, int relu) {
     GemmA a = {}; a.ptr = p; a.mode = A_CONV3; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.relu = relu; return a;
 }
+// tile of the fused head launch: MAP_HEAD needs a tile whose waves own all N columns of their rows (WN == 1)
+int head_tile(int bn) { return bn == 32 ? 912832 : 9256648; }
+
 GemmEpi rowsE(void* out, int out_type, long ldc, const float* bias) {
     GemmEpi e = {}; e.out = out; e.out_type = out_type; e.ldc = ldc; e.bias = bias; return e;
 }
@@ -412,12 +415,11 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         const int Mh = B * e->h * e->w, Nh = d.head_hidden;
         const int bn = Nh <= 32 ? 32 : 64;
         if (Nh <= 64 && (long)cdiv(Mh, 256) * cdiv(Nh, bn) >= 224) {
-            // conv2 + ReLU + conv3 (1x1 -> 1 channel) + ReLU in one launch (MAP_HEAD; needs the 256 x 32|64 tile,
-            // which launch_gemm's auto rule picks for exactly this shape)
+            // conv2 + ReLU + conv3 (1x1 -> 1 channel) + ReLU | sigmoid in one launch (MAP_HEAD, WN == 1 tiles)
             GemmA a = convA(Y, e->h, e->w, F / 2, e->h, e->w, 1, 0);
             GemmEpi ep = rowsE(depth, OUT_F32, 1, e->head2.bias);
             ep.map = MAP_HEAD; ep.scale = e->w3; ep.head_b3 = e->b3; ep.head_max_depth = d.max_depth;
-            PROF(PC_CONV, 2.0 * Mh * Nh * e->head2.K, 0, launch_gemm(prec, bn == 32 ? 25632 : 25664, a, e->head2.w, Mh, Nh, e->head2.K, e->head2.Kpad, ep, st));
+            PROF(PC_CONV, 2.0 * Mh * Nh * e->head2.K, 0, launch_gemm(prec, head_tile(bn), a, e->head2.w, Mh, Nh, e->head2.K, e->head2.Kpad, ep, st));
         } else {
             RC(conv3(e, Y, B, e->h, e->w, F / 2, 1, 0, e->head2, Z, ACT_RELU, nullptr, nullptr, st));
             PROF(PC_ELT, 0, 0, launch_head_final(prec, Z, e->w3, e->b3, d.max_depth, depth, (long)B * e->h * e->w, d.head_hidden, st));
@@ -717,11 +719,17 @@ extern "C" int d2s_engine_profile_read(d2s_engine* e, int max_classes, double* m
                                        int64_t* launches, int* n_classes) {
     D2S_REQUIRE(e && ms && flops && bytes && launches && n_classes && max_classes >= PC_N, "bad argument");
     for (int c = 0; c < PC_N; ++c) { ms[c] = 0; flops[c] = 0; bytes[c] = 0; launches[c] = 0; }
+    const char* dump = getenv("D2S_PROF_DUMP");             // tuning aid: one line per recorded launch on stderr
+    int idx = 0;
     for (auto& r : e->prof_recs) {
         D2S_HIP(hipEventSynchronize(r.b));
         float t = 0.f;
         D2S_HIP(hipEventElapsedTime(&t, r.a, r.b));
         ms[r.cls] += t; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes; launches[r.cls] += 1;
+        if (dump && atoi(dump))
+            fprintf(stderr, "[d2s-prof] %4d %-12s %8.2f us %9.3f GF %7.1f TF/s\n", idx, PC_NAMES[r.cls], t * 1e3, r.flops * 1e-9,
+                    t > 0.f ? r.flops / (t * 1e-3) * 1e-12 : 0.0);
+        ++idx;
     }
     *n_classes = PC_N;
     return D2S_OK;

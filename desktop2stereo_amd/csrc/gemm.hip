@@ -288,9 +288,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // chunk XOR for a row of CPR chunks: conflict-free ds_read_b128 for 128-byte (CPR 8) and 256-byte (CPR 16) rows
 template <int CPR> __device__ __forceinline__ int swz_row(int r) { return CPR == 8 ? ((r >> 1) & 7) : (r & 15); }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR>
+// STG = true: register-staged variant of the same tile.  The K tile travels global -> VGPRs (global_load_dwordx4)
+// -> LDS (ds_write_b128, same lane-linear slots as the LDS-DMA path, so fragment reads are unchanged) with TWO LDS
+// stages: at the top of iteration t (after the barrier) the registers holding tile t+1 -- loaded during compute(t-1)
+// -- are written to the stage compute(t-1) just released, the loads of tile t+2 are issued, then tile t is computed.
+// Measured on this chip (tools/ubench/l2_to_lds): L2-resident data reaches LDS at ~27 TB/s through VGPRs vs
+// ~13-16 TB/s by LDS-DMA, and the freed LDS (2 stages instead of 3) admits the 256 x 256 tile.
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, int STG = 0>
 __global__ void __launch_bounds__(64 * WM * WN)
 gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
+    static_assert(STG == 0 || (STG == 1 && NS == 2), "the register-staged variant uses two LDS stages");
     constexpr int CE = Prec<T>::CE;
     constexpr int BK = CPR * CE;                    // K tile: CPR 16-byte chunks per row (8 -> 128 B, 16 -> 256 B)
     constexpr int RPI = 64 / CPR;                   // rows covered by one 1-KiB LDS-DMA wave-instruction
@@ -334,16 +341,22 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     const T* wrow = W + (long)(bn0 + lrow) * Kpad + src_chunk * CE;
     const float inv_c = a.mode == A_CONV3 ? 1.0f / (float)a.C : 0.f;
 
-#define D2S_GLDS(SRC, DST) \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
-#define D2S_ISSUE_TILE(KT)                                                                                       \
+    // D2S_MOVE(slot index, source, LDS destination): LDS-DMA straight into the ring, or a load into staging registers
+    u32x4 stg[1][STG ? LPT : 1];
+#define D2S_MOVE(S, IDX, SRC, DST)                                                                                \
+    do {                                                                                                         \
+        if constexpr (STG != 0) stg[S][IDX] = *(const u32x4*)(SRC);                                                 \
+        else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),             \
+                                              (__attribute__((address_space(3))) void*)(DST), 16, 0, 0);         \
+    } while (0)
+#define D2S_ISSUE_TILE(KT, S)                                                                                    \
     {                                                                                                            \
         u32x4* st_ = lds + ((KT) % NS) * STAGE;                                                                  \
         const int k_ = ((KT) + kt0) * BK + src_chunk * CE;                                                       \
         if (a.mode == A_PLAIN) {                                                                                 \
             _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                     \
                 const T* s_ = (aok[i] && k_ < K) ? arow[i] + k_ : zero;                                          \
-                D2S_GLDS(s_, st_ + (i * NW + wid) * 64);                                                          \
+                D2S_MOVE(S, i, s_, st_ + (i * NW + wid) * 64);                                                    \
             }                                                                                                    \
         } else {                                                                                                 \
             int tap_ = (int)(((float)k_ + 0.5f) * inv_c);                                                        \
@@ -353,11 +366,18 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
                 int iy_ = aiy[i] + ky_, ix_ = aix[i] + kx_;                                                      \
                 bool ok_ = aok[i] && k_ < K && iy_ >= 0 && iy_ < a.Hi && ix_ >= 0 && ix_ < a.Wi;                 \
                 const T* s_ = ok_ ? arow[i] + ((long)iy_ * a.Wi + ix_) * a.C + c0_ : zero;                       \
-                D2S_GLDS(s_, st_ + (i * NW + wid) * 64);                                                          \
+                D2S_MOVE(S, i, s_, st_ + (i * NW + wid) * 64);                                                    \
             }                                                                                                    \
         }                                                                                                        \
         _Pragma("unroll") for (int i = 0; i < BI; ++i)                                                           \
-            D2S_GLDS(wrow + (long)(RPI * NW * i) * Kpad + ((KT) + kt0) * BK, st_ + BM * CPR + (i * NW + wid) * 64);       \
+            D2S_MOVE(S, AI + i, wrow + (long)(RPI * NW * i) * Kpad + ((KT) + kt0) * BK, st_ + BM * CPR + (i * NW + wid) * 64); \
+    }
+    // staging registers -> LDS, the same lane-linear slots the LDS-DMA path fills
+#define D2S_STORE_STG(KT, S)                                                                                     \
+    {                                                                                                            \
+        u32x4* st_ = lds + ((KT) % NS) * STAGE;                                                                  \
+        _Pragma("unroll") for (int i = 0; i < AI; ++i) st_[(i * NW + wid) * 64 + lane] = stg[S][i];              \
+        _Pragma("unroll") for (int i = 0; i < BI; ++i) st_[BM * CPR + (i * NW + wid) * 64 + lane] = stg[S][AI + i]; \
     }
 
     f32x4 acc[FM][FN];
@@ -371,38 +391,53 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     const int ksplit = e.ksplit > 1 ? e.ksplit : 1;
     const int kt0 = (int)(((long)nkt_all * blockIdx.y) / ksplit);
     const int nkt = (int)(((long)nkt_all * (blockIdx.y + 1)) / ksplit) - kt0;
-#pragma unroll
-    for (int t = 0; t < PD; ++t)
-        if (t < nkt) D2S_ISSUE_TILE(t)
     const int fr = lane & 15, fg = lane >> 4;
     const int relu_floor = a.relu ? 0 : -32768;
-    for (int kt = 0; kt < nkt; ++kt) {
-        // tiles kt .. min(kt+PD-1, nkt-1) are in flight; let all but tile kt stay in flight
-        if (kt + PD - 1 < nkt) wait_vmcnt<(PD - 1) * LPT>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + PD < nkt) D2S_ISSUE_TILE(kt + PD)
-        const u32x4* A_l = lds + (kt % NS) * STAGE + (wave_m * (BM / WM)) * CPR;
-        const u32x4* B_l = lds + (kt % NS) * STAGE + BM * CPR + (wave_n * (BN / WN)) * CPR;
+#define D2S_COMPUTE(KT)                                                                                          \
+    {                                                                                                            \
+        const u32x4* A_l = lds + ((KT) % NS) * STAGE + (wave_m * (BM / WM)) * CPR;                               \
+        const u32x4* B_l = lds + ((KT) % NS) * STAGE + BM * CPR + (wave_n * (BN / WN)) * CPR;                    \
+        _Pragma("unroll") for (int ks = 0; ks < CPR / 4; ++ks) {                                                 \
+            /* W fragments stay live for the k-step; A fragments stream through one at a time */                 \
+            /* (keeps the 8-wave 256-row tiles inside the 256-register budget) */                                \
+            u32x4 fb[FN];                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                     \
+                int r = j * 16 + fr; fb[j] = B_l[r * CPR + ((ks * 4 + fg) ^ swz_row<CPR>(r))];                   \
+            }                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                                     \
+                int r = i * 16 + fr;                                                                             \
+                u32x4 fa = A_l[r * CPR + ((ks * 4 + fg) ^ swz_row<CPR>(r))];                                     \
+                fa = relu_frag(fa, relu_floor, T());     /* branch-free: floor = 0 (ReLU) or lowest (identity) */ \
+                _Pragma("unroll") for (int j = 0; j < FN; ++j) mma_chunk(acc[i][j], fb[j], fa, T());             \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
+    if constexpr (STG == 1) {
+        if (nkt > 0) { D2S_ISSUE_TILE(0, 0) D2S_STORE_STG(0, 0) }
+        if (nkt > 1) D2S_ISSUE_TILE(1, 0)
+        for (int kt = 0; kt < nkt; ++kt) {
+            __syncthreads();                                   // tile kt visible, stage (kt+1)&1 released, my loads of kt+1 landed
+            if (kt + 1 < nkt) D2S_STORE_STG(kt + 1, 0)
+            if (kt + 2 < nkt) D2S_ISSUE_TILE(kt + 2, 0)
+            D2S_COMPUTE(kt)
+        }
+    } else {
 #pragma unroll
-        for (int ks = 0; ks < CPR / 4; ++ks) {
-            // W fragments stay live for the k-step; A fragments stream through one at a time
-            // (keeps the 8-wave 256-row tiles inside the 256-register budget)
-            u32x4 fb[FN];
-#pragma unroll
-            for (int j = 0; j < FN; ++j) { int r = j * 16 + fr; fb[j] = B_l[r * CPR + ((ks * 4 + fg) ^ swz_row<CPR>(r))]; }
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                int r = i * 16 + fr;
-                u32x4 fa = A_l[r * CPR + ((ks * 4 + fg) ^ swz_row<CPR>(r))];
-                fa = relu_frag(fa, relu_floor, T());           // branch-free: floor = 0 (ReLU) or lowest (identity)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) mma_chunk(acc[i][j], fb[j], fa, T());
-            }
+        for (int t = 0; t < PD; ++t)
+            if (t < nkt) D2S_ISSUE_TILE(t, 0)
+        for (int kt = 0; kt < nkt; ++kt) {
+            // tiles kt .. min(kt+PD-1, nkt-1) are in flight; let all but tile kt stay in flight
+            if (kt + PD - 1 < nkt) wait_vmcnt<(PD - 1) * LPT>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + PD < nkt) D2S_ISSUE_TILE(kt + PD, 0)
+            D2S_COMPUTE(kt)
         }
     }
+#undef D2S_COMPUTE
 #undef D2S_ISSUE_TILE
-#undef D2S_GLDS
+#undef D2S_STORE_STG
+#undef D2S_MOVE
 
     // MAP_HEAD: the DPT head's tail fused into conv2 -- depth[m] = relu(b3 + sum_n w3[n] * relu(acc[m][n] + bias[n]))
     // (HF DepthAnythingDepthEstimationHead: conv2 -> ReLU -> conv3 (1x1, C->1) -> ReLU).  One wave owns all N
@@ -489,7 +524,7 @@ static int pick_xn(int tiles_m, int tiles_n, int BN, int Kpad, size_t es, unsign
 }
 
 // tile codes: 64 (64x64), 128 (128x128), 256128 / 256256 (8 waves), 25664 / 25632 (256 x 64|32, 4 waves); 0 = auto
-template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR = 8>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR = 8, int STG = 0>
 static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
     unsigned grid = 0;
     int xn = pick_xn(cdiv(M, BM), cdiv(N, BN), BN, Kpad, sizeof(T), grid);
@@ -503,12 +538,12 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
     }
     if (ks > 1) {
         GemmEpi e2 = e; e2.ksplit = ks;
-        hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR>), dim3(grid, ks), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e2, xn);
+        hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid, ks), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e2, xn);
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(cdiv((long)M * (N / 4), 256)), dim3(256), 0, st, e2, M, N);
         return;
     }
     GemmEpi e1 = e; e1.ksplit = 1;
-    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR>), dim3(grid), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn);
 }
 
 template <typename T>
@@ -517,12 +552,19 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     static const int force_tile = getenv("D2S_GEMM_TILE") ? atoi(getenv("D2S_GEMM_TILE")) : 0;
     if (tile == 0) tile = force_tile;
     if (tile == 0) {
-        // 256-row tiles (intensity >= 85 flop/byte of L2 traffic) once they fill the chip, with the
-        // N extent matched to the layer (DPT head: 64 / 32 output channels); 64x64 otherwise.
-        int bn = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
-        long blocks = (long)cdiv(M, 256) * cdiv(N, bn);
-        if (blocks >= 224) tile = bn == 128 ? 256128 : (bn == 64 ? 25664 : 25632);
-        else if ((long)cdiv(M, 64) * cdiv(N, 64) >= 384) tile = 64;
+        // Measured on the ViT-B shapes at batch 1..32 (tools/gemm_bench.py, profiles/r1_05): what matters most is ~16
+        // resident waves per CU in DIFFERENT phases of the K loop, then tile intensity.  128 x 128 with 8 waves
+        // (2 blocks / CU, register-staged) wins once it fills the chip; below that, smaller staged tiles, and the
+        // LDS-DMA ring (deeper prefetch, shorter prologue) for the launches with the fewest blocks.
+        const long b128 = (long)cdiv(M, 128) * cdiv(N, 128), b64 = (long)cdiv(M, 64) * cdiv(N, 64);
+        if (N <= 64) {                              // DPT head: 64 / 32 output channels, M = pixels
+            if ((long)cdiv(M, 256) >= 224) tile = N <= 32 ? 912832 : 9256648;
+            else tile = 3264;
+        }
+        else if (b128 >= 280) tile = 91288;
+        else if (b64 >= 800) tile = 964128;
+        else if (b64 >= 560) tile = 964;
+        else if (b64 >= 384) tile = 64;
         else tile = 3264;                           // skinny launches (batch 1, N = 768): more, smaller blocks
     }
     if (v1 && (tile == 128 || tile == 64)) {
@@ -532,19 +574,22 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
         else { int xn = pick_xn(cdiv(M, 64), cdiv(N, 64), 64, Kpad, sizeof(T), grid);
             hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), dim3(grid), dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn); }
     }
-    else if (tile == 256256) launch_glds<T, 256, 256, 2, 4, 2>(a, W, M, N, K, Kpad, e, st);
+    // LDS-DMA ring (NS stages)
     else if (tile == 256128) launch_glds<T, 256, 128, 4, 2, 3>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 25664) launch_glds<T, 256, 64, 4, 1, 3>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 25632) launch_glds<T, 256, 32, 4, 1, 3>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 128) launch_glds<T, 128, 128, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 64) launch_glds<T, 64, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 3264) launch_glds<T, 32, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
-    else if (tile == 648) launch_glds<T, 64, 64, 2, 2, 8>(a, W, M, N, K, Kpad, e, st);           // 8-stage ring: 112 KB in flight per block
-    else if (tile == 32648) launch_glds<T, 32, 64, 2, 2, 8>(a, W, M, N, K, Kpad, e, st);
-    else if (tile == 646) launch_glds<T, 64, 64, 2, 2, 6>(a, W, M, N, K, Kpad, e, st);
-    else if (tile == 6416) launch_glds<T, 64, 64, 2, 2, 3, 16>(a, W, M, N, K, Kpad, e, st);      // 256-byte K tiles
-    else if (tile == 326416) launch_glds<T, 32, 64, 2, 2, 3, 16>(a, W, M, N, K, Kpad, e, st);
-    else if (tile == 12812816) launch_glds<T, 128, 128, 2, 2, 2, 16>(a, W, M, N, K, Kpad, e, st);
+    // register-staged variants (STG), code = 9 <BM> <BN> [waves]; the losers of the round-1 sweep (256 x 128 / 256 x 256
+    // with 8 waves, 128 x 128 with 4 or 16 waves, deeper rings, 256-byte K tiles, two register sets) were removed
+    else if (tile == 964) launch_glds<T, 64, 64, 2, 2, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 93264) launch_glds<T, 32, 64, 2, 2, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 964128) launch_glds<T, 64, 128, 2, 2, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 91288) launch_glds<T, 128, 128, 4, 2, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);       // 8 waves, 2 blocks / CU
+    else if (tile == 912832) launch_glds<T, 128, 32, 4, 1, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);       // WN == 1: MAP_HEAD capable
+    else if (tile == 9256648) launch_glds<T, 256, 64, 8, 1, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);      // WN == 1, 8 waves
+    else if (tile == 925625616) launch_glds<T, 256, 256, 4, 4, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);   // 16 waves (batch >= 32 shapes)
     else { set_error("launch_gemm: bad tile code"); return D2S_E_INVALID; }
     D2S_CHECK_LAUNCH();
     return D2S_OK;
