@@ -48,13 +48,20 @@ __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b
     for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bf[t], acc, 0, 0, 0);
 }
 
+// two floats -> packed bf16 pair, round-to-nearest-even: v_cvt_pk_bf16_f32 (gfx950) instead of ~5 VALU ops per value
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 // pack the P values a lane group contributes to one V^T chunk
 __device__ __forceinline__ u32x4 pack_p(const f32x4& lo, const f32x4& hi, bf16_t) {
     u32x4 r;
-    r.x = (uint32_t)f2bf(lo[0]) | ((uint32_t)f2bf(lo[1]) << 16);
-    r.y = (uint32_t)f2bf(lo[2]) | ((uint32_t)f2bf(lo[3]) << 16);
-    r.z = (uint32_t)f2bf(hi[0]) | ((uint32_t)f2bf(hi[1]) << 16);
-    r.w = (uint32_t)f2bf(hi[2]) | ((uint32_t)f2bf(hi[3]) << 16);
+    r.x = pk_bf16(lo[0], lo[1]);
+    r.y = pk_bf16(lo[2], lo[3]);
+    r.z = pk_bf16(hi[0], hi[1]);
+    r.w = pk_bf16(hi[2], hi[3]);
     return r;
 }
 __device__ __forceinline__ u32x4 pack_p(const f32x4& lo, const f32x4&, float) {
@@ -66,8 +73,8 @@ __device__ __forceinline__ u32x4 pack_p(const f32x4& lo, const f32x4&, float) {
 __device__ __forceinline__ void store_o4(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ void store_o4(bf16_t* p, const float v[4]) {
     uint2 t;
-    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    t.x = pk_bf16(v[0], v[1]);
+    t.y = pk_bf16(v[2], v[3]);
     *(uint2*)p = t;
 }
 
@@ -185,17 +192,27 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][j][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float m_new = fmaxf(m_run[f], mx);
-            float alpha = exp2f((m_run[f] - m_new) * scale_log2e);
+            // p = 2^((s - m) * c) as one FMA + one raw v_exp_f32 per value (arguments are <= 0: no range handling needed)
+            const float m_new = fmaxf(m_run[f], mx);
+            const float mc = m_new * scale_log2e;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[f] * scale_log2e - mc);
+            const bool grew = m_new > m_run[f];
             m_run[f] = m_new;
             float ps = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { float p = exp2f((s[f][j][r] - m_new) * scale_log2e); s[f][j][r] = p; ps += p; }
+                for (int r = 0; r < 4; ++r) {
+                    // fp32 parity class: subtract first (exact for nearby values), then scale
+                    float arg = sizeof(T) == 4 ? (s[f][j][r] - m_new) * scale_log2e : fmaf(s[f][j][r], scale_log2e, -mc);
+                    float p = __builtin_amdgcn_exp2f(arg);
+                    s[f][j][r] = p; ps += p;
+                }
             l_run[f] = l_run[f] * alpha + ps;          // per-lane partial; groups are summed at the end
+            if (__any(grew)) {                          // the running maximum settles after the first tiles: skip the O rescale then
 #pragma unroll
-            for (int d = 0; d < 4; ++d) { o[f][d][0] *= alpha; o[f][d][1] *= alpha; o[f][d][2] *= alpha; o[f][d][3] *= alpha; }
+                for (int d = 0; d < 4; ++d) { o[f][d][0] *= alpha; o[f][d][1] *= alpha; o[f][d][2] *= alpha; o[f][d][3] *= alpha; }
+            }
         }
         // ---- O^T += V^T P^T
 #pragma unroll

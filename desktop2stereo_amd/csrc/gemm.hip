@@ -68,10 +68,17 @@ __device__ __forceinline__ void load4(const bf16_t* p, float v[4]) {
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
 __device__ __forceinline__ void store4(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+// two floats -> packed bf16 pair (round-to-nearest-even) in one v_cvt_pk_bf16_f32
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
     uint2 t;
-    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    t.x = pk_bf16(v[0], v[1]);
+    t.y = pk_bf16(v[2], v[3]);
     *(uint2*)p = t;
 }
 
@@ -294,23 +301,33 @@ template <int CPR> __device__ __forceinline__ int swz_row(int r) { return CPR ==
 // -- are written to the stage compute(t-1) just released, the loads of tile t+2 are issued, then tile t is computed.
 // Measured on this chip (tools/ubench/l2_to_lds): L2-resident data reaches LDS at ~27 TB/s through VGPRs vs
 // ~13-16 TB/s by LDS-DMA, and the freed LDS (2 stages instead of 3) admits the 256 x 256 tile.
-template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, int STG = 0>
-__global__ void __launch_bounds__(64 * WM * WN)
+//
+// KG > 1: intra-block split-K for the launches with too few tiles to fill the chip (batch 1: 300-470 blocks of 4
+// waves on 256 CUs).  The block holds KG independent wave groups of WM x WN waves; group g runs the whole pipeline
+// (its own LDS ring, its own loads) over K tiles g, g+KG, ... of the SAME output tile, all groups meet at the same
+// barriers, and the groups' accumulators are summed through LDS before the (single) epilogue.  KG x the waves and
+// loads in flight per CU without more blocks, no partials in HBM, no second launch.
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, int STG = 0, int KG = 1>
+__global__ void __launch_bounds__(64 * WM * WN * KG)
 gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
     static_assert(STG == 0 || (STG == 1 && NS == 2), "the register-staged variant uses two LDS stages");
     constexpr int CE = Prec<T>::CE;
     constexpr int BK = CPR * CE;                    // K tile: CPR 16-byte chunks per row (8 -> 128 B, 16 -> 256 B)
     constexpr int RPI = 64 / CPR;                   // rows covered by one 1-KiB LDS-DMA wave-instruction
-    constexpr int NW = WM * WN;                     // waves per block
+    constexpr int NW = WM * WN;                     // waves per group
     constexpr int AI = BM / (RPI * NW), BI = BN / (RPI * NW);   // LDS-DMA instructions per thread per tile (A / W)
     constexpr int LPT = AI + BI;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;   // 16x16 fragments per wave
     constexpr int PD = NS - 1;
     constexpr int STAGE = (BM + BN) * CPR;          // chunks per stage
-    __shared__ __attribute__((aligned(16))) u32x4 lds[NS * STAGE];
+    static_assert(KG == 1 || (KG - 1) * NW * FM * FN * 64 <= KG * NS * STAGE, "reduction scratch must fit in the rings");
+    __shared__ __attribute__((aligned(16))) u32x4 lds_all[KG * NS * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wid_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = KG == 1 ? 0 : wid_all / NW;     // K group of this wave
+    const int wid = KG == 1 ? wid_all : wid_all % NW;
+    u32x4* const lds = lds_all + grp * (NS * STAGE);
     const int wave_m = wid / WN, wave_n = wid % WN;
     int tm_, tn_;
     if (!tile_of_block(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, xn, tm_, tn_)) return;
@@ -352,7 +369,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
 #define D2S_ISSUE_TILE(KT, S)                                                                                    \
     {                                                                                                            \
         u32x4* st_ = lds + ((KT) % NS) * STAGE;                                                                  \
-        const int k_ = ((KT) + kt0) * BK + src_chunk * CE;                                                       \
+        const int k_ = ((KT) * KG + grp + kt0) * BK + src_chunk * CE;                                            \
         if (a.mode == A_PLAIN) {                                                                                 \
             _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                     \
                 const T* s_ = (aok[i] && k_ < K) ? arow[i] + k_ : zero;                                          \
@@ -370,7 +387,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
             }                                                                                                    \
         }                                                                                                        \
         _Pragma("unroll") for (int i = 0; i < BI; ++i)                                                           \
-            D2S_MOVE(S, AI + i, wrow + (long)(RPI * NW * i) * Kpad + ((KT) + kt0) * BK, st_ + BM * CPR + (i * NW + wid) * 64); \
+            D2S_MOVE(S, AI + i, wrow + (long)(RPI * NW * i) * Kpad + ((KT) * KG + grp + kt0) * BK, st_ + BM * CPR + (i * NW + wid) * 64); \
     }
     // staging registers -> LDS, the same lane-linear slots the LDS-DMA path fills
 #define D2S_STORE_STG(KT, S)                                                                                     \
@@ -390,7 +407,9 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     const int nkt_all = (K + BK - 1) / BK;
     const int ksplit = e.ksplit > 1 ? e.ksplit : 1;
     const int kt0 = (int)(((long)nkt_all * blockIdx.y) / ksplit);
-    const int nkt = (int)(((long)nkt_all * (blockIdx.y + 1)) / ksplit) - kt0;
+    const int nkt_blk = (int)(((long)nkt_all * (blockIdx.y + 1)) / ksplit) - kt0;
+    const int nkt = KG == 1 ? nkt_blk : (nkt_blk > grp ? (nkt_blk - grp + KG - 1) / KG : 0);   // K tiles of this group
+    const int nit = KG == 1 ? nkt_blk : (nkt_blk + KG - 1) / KG;                               // barrier count, same for all groups
     const int fr = lane & 15, fg = lane >> 4;
     const int relu_floor = a.relu ? 0 : -32768;
 #define D2S_COMPUTE(KT)                                                                                          \
@@ -415,29 +434,49 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     if constexpr (STG == 1) {
         if (nkt > 0) { D2S_ISSUE_TILE(0, 0) D2S_STORE_STG(0, 0) }
         if (nkt > 1) D2S_ISSUE_TILE(1, 0)
-        for (int kt = 0; kt < nkt; ++kt) {
+        for (int kt = 0; kt < nit; ++kt) {
             __syncthreads();                                   // tile kt visible, stage (kt+1)&1 released, my loads of kt+1 landed
             if (kt + 1 < nkt) D2S_STORE_STG(kt + 1, 0)
             if (kt + 2 < nkt) D2S_ISSUE_TILE(kt + 2, 0)
-            D2S_COMPUTE(kt)
+            if (KG == 1 || kt < nkt) D2S_COMPUTE(kt)
         }
     } else {
 #pragma unroll
         for (int t = 0; t < PD; ++t)
             if (t < nkt) D2S_ISSUE_TILE(t, 0)
-        for (int kt = 0; kt < nkt; ++kt) {
+        for (int kt = 0; kt < nit; ++kt) {
             // tiles kt .. min(kt+PD-1, nkt-1) are in flight; let all but tile kt stay in flight
             if (kt + PD - 1 < nkt) wait_vmcnt<(PD - 1) * LPT>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (kt + PD < nkt) D2S_ISSUE_TILE(kt + PD, 0)
-            D2S_COMPUTE(kt)
+            if (KG == 1 || kt < nkt) D2S_COMPUTE(kt)
         }
     }
 #undef D2S_COMPUTE
 #undef D2S_ISSUE_TILE
 #undef D2S_STORE_STG
 #undef D2S_MOVE
+
+    if constexpr (KG > 1) {
+        // sum the groups' accumulators through LDS (the rings are free after the barrier); group 0 runs the epilogue
+        f32x4* red = (f32x4*)lds_all;
+        __syncthreads();
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) red[(((grp - 1) * NW + wid) * (FM * FN) + i * FN + j) * 64 + lane] = acc[i][j];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 0; g < KG - 1; ++g)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] += red[((g * NW + wid) * (FM * FN) + i * FN + j) * 64 + lane];
+    }
 
     // MAP_HEAD: the DPT head's tail fused into conv2 -- depth[m] = relu(b3 + sum_n w3[n] * relu(acc[m][n] + bias[n]))
     // (HF DepthAnythingDepthEstimationHead: conv2 -> ReLU -> conv3 (1x1, C->1) -> ReLU).  One wave owns all N
@@ -524,7 +563,7 @@ static int pick_xn(int tiles_m, int tiles_n, int BN, int Kpad, size_t es, unsign
 }
 
 // tile codes: 64 (64x64), 128 (128x128), 256128 / 256256 (8 waves), 25664 / 25632 (256 x 64|32, 4 waves); 0 = auto
-template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR = 8, int STG = 0>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR = 8, int STG = 0, int KG = 1>
 static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
     unsigned grid = 0;
     int xn = pick_xn(cdiv(M, BM), cdiv(N, BN), BN, Kpad, sizeof(T), grid);
@@ -538,12 +577,12 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
     }
     if (ks > 1) {
         GemmEpi e2 = e; e2.ksplit = ks;
-        hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid, ks), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e2, xn);
+        hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG, KG>), dim3(grid, ks), dim3(64 * WM * WN * KG), 0, st, a, (const T*)W, M, N, K, Kpad, e2, xn);
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(cdiv((long)M * (N / 4), 256)), dim3(256), 0, st, e2, M, N);
         return;
     }
     GemmEpi e1 = e; e1.ksplit = 1;
-    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG, KG>), dim3(grid), dim3(64 * WM * WN * KG), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn);
 }
 
 template <typename T>
@@ -565,6 +604,7 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
         else if (b64 >= 800) tile = 964128;
         else if (b64 >= 560) tile = 964;
         else if (b64 >= 384) tile = 64;
+        else if (b64 <= 160 && b64 >= 128 && K >= 2048 && a.mode == A_PLAIN) tile = 74964;   // batch-1 FC2: few tiles, 48 K tiles -> 4 K groups per block
         else tile = 3264;                           // skinny launches (batch 1, N = 768): more, smaller blocks
     }
     if (v1 && (tile == 128 || tile == 64)) {
@@ -590,6 +630,10 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     else if (tile == 912832) launch_glds<T, 128, 32, 4, 1, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);       // WN == 1: MAP_HEAD capable
     else if (tile == 9256648) launch_glds<T, 256, 64, 8, 1, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);      // WN == 1, 8 waves
     else if (tile == 925625616) launch_glds<T, 256, 256, 4, 4, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);   // 16 waves (batch >= 32 shapes)
+    // intra-block split-K (KG wave groups per block), code = 7 <KG> <tile>.  Swept at batch 1-2 over 32 x 64 / 64 x 64,
+    // LDS-DMA / staged, KG 2 / 4: the batch-1 launches turned out L2->LDS-bandwidth-bound (~10 TB/s aggregate), not
+    // latency-bound, so only the longest K loop gains (FC2 at batch 1: 18.4 -> 16.8 us)
+    else if (tile == 74964) launch_glds<T, 64, 64, 2, 2, 2, 8, 1, 4>(a, W, M, N, K, Kpad, e, st);
     else { set_error("launch_gemm: bad tile code"); return D2S_E_INVALID; }
     D2S_CHECK_LAUNCH();
     return D2S_OK;
