@@ -5,7 +5,7 @@
 //          vt   [B, heads, 64, Npad] T  = V transposed (written by the same GEMM's epilogue), zero beyond N.
 // Output:  out  [B*N, D] T.
 //
-// One block = 4 waves, one (batch, head, q-tile); each wave owns QF fragments of 16 query rows.
+// One block = NW (4 | 8) waves, one (batch, head, q-tile); each wave owns QF fragments of 16 query rows.
 // Per 64-key tile:
 //   S^T[key, q] = mfma(K rows, Q rows)         lane: 4 keys x 1 query  -> softmax stats are per lane column
 //   P^T feeds the second MFMA straight from the S registers (no LDS round trip): the K rows of a
@@ -80,7 +80,7 @@ __device__ __forceinline__ void store_o4(bf16_t* p, const float v[4]) {
 
 __device__ u32x4 d2s_attn_zero_page[4];
 
-template <typename T, int QF, int NW>
+template <typename T, int QF, int NW, int NS = 3>
 __global__ void __launch_bounds__(64 * NW)
 attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restrict__ out,
                  int N, int Npad, int heads, float scale_log2e) {
@@ -89,7 +89,7 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
     constexpr int TILE_CHUNKS = 64 * CPR;              // chunks in one 64-row tile
     constexpr int NT = 64 * NW;                        // threads per block
     constexpr int BQ = NW * QF * 16;
-    constexpr int NS = 3, PD = NS - 1;                 // LDS ring stages / prefetch distance
+    constexpr int PD = NS - 1;                         // NS LDS ring stages, prefetch distance PD
     __shared__ __attribute__((aligned(16))) u32x4 lds[NS * 2 * TILE_CHUNKS];   // [stage][K | V^T]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -255,14 +255,16 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
 
 int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B, int N, int Npad, int heads, hipStream_t st) {
     const float scale_log2e = 0.125f * 1.4426950408889634f;          // 64^-0.5 * log2(e)
-    // q rows per block: 128 (4 waves x 2 fragments) when that still fills the chip, else 64, else 32
+    // q rows per block: 128 as 8 waves x 1 fragment once that fills the chip (batch >= ~8), else 64 as 4 waves.
+    // Swept at batch 1 / 16: 4 waves x 2 fragments 80 us, ring depth 2 / 4 within 3 %, 8 x 2 (256 rows) 68 us,
+    // 8 x 1 67 us (444 TFLOP/s); 32-row blocks slower (K/V tile loads not amortised).  D2S_ATTN_BQ forces 128 / 64 / 32.
     static const int force = getenv("D2S_ATTN_BQ") ? atoi(getenv("D2S_ATTN_BQ")) : 0;
     long hb = (long)heads * B;
-    int bq = force ? force : (cdiv(N, 128) * hb >= 512 ? 128 : 64);       // (32-row blocks measured slower: K/V tile loads not amortised)
+    int bq = force ? force : (cdiv(N, 128) * hb >= 512 ? 128 : 64);
 #define D2S_ATT(TT, QF_, NW_) hipLaunchKernelGGL((attention_kernel<TT, QF_, NW_>), dim3(cdiv(N, NW_ * QF_ * 16), heads, B), dim3(64 * NW_), 0, st, \
         (const TT*)qkv, (const TT*)vt, (TT*)out, N, Npad, heads, scale_log2e)
     if (prec == D2S_PREC_BF16) {
-        if (bq == 128) D2S_ATT(bf16_t, 2, 4);
+        if (bq == 128) D2S_ATT(bf16_t, 1, 8);
         else if (bq == 64) D2S_ATT(bf16_t, 1, 4);
         else D2S_ATT(bf16_t, 1, 2);
     } else {
