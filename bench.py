@@ -29,7 +29,7 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp8": 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0                          # HBM3E spec
 SURVEY_GF_PER_FRAME = {("vitb", 518): 176.9, ("vits", 518): 45.8, ("vitl", 518): 635.9,
                        ("vitb", 336): 76.5, ("vits", 336): 19.8, ("vitl", 336): 275.2}
@@ -110,7 +110,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU (configs[1]: 1)")
     ap.add_argument("--also-batch", type=int, default=16, help="extra batched measurement at N=1 (0 = off)")
     ap.add_argument("--model", default="vitb")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="fp8 = BASELINE config 3 (e4m3 encoder linears; try --model vitl --height 2160 --width 3840 --mode Full-TAB)")
     ap.add_argument("--res", type=int, default=518)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
@@ -157,6 +158,8 @@ def main():
     else:
         weights = make_weights(cfg, 0)
     eng = ops.Engine(cfg, weights, h, w, max_batch=max(B, B2), precision=args.precision, device=local_rank, temporal=args.vda)
+    if args.precision == "fp8":     # static activation scales from two structured frames (outside the timed region)
+        eng.calibrate(torch.cat([ops.preprocess(torch.from_numpy(synth.structured_frame(H, W, s)).to(dev), args.res) for s in (0, 1)][:max(B, B2)]))
     sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, args.mode, p.fill_16_9)
     oh, ow = ops.sbs_shape(H, W, sp)
 

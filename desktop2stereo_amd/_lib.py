@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libd2s_hip.so")
 OK = 0
 MODE = {"Half-SBS": 0, "Full-SBS": 1, "Half-TAB": 2, "Full-TAB": 3}
 FMT_U8_HWC, FMT_F32_CHW, FMT_F32_HWC, FMT_U8_CHW = 0, 1, 2, 3
-PREC_FP32, PREC_BF16 = 0, 1
+PREC_FP32, PREC_BF16, PREC_FP8 = 0, 1, 2
 
 
 class ModelDesc(C.Structure):
@@ -59,6 +59,7 @@ SYMBOLS = {
     "d2s_process": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "d2s_overlay_text": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_char_p, _P]),
     "d2s_model_forward": (C.c_int, [_P, _P, _P, C.c_int, _P]),
+    "d2s_engine_calibrate": (C.c_int, [_P, _P, C.c_int, _P]),
     "d2s_post_process": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(PostParams), _P, C.c_uint64, _P]),
     "d2s_post_process_workspace": (C.c_uint64, [C.c_int, C.c_int, C.c_int]),
     "d2s_ema_update": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),

@@ -78,12 +78,20 @@ __device__ __forceinline__ void store_o4(bf16_t* p, const float v[4]) {
     *(uint2*)p = t;
 }
 
+__device__ __forceinline__ void store_o4(fp8_t* p, const float v[4]) {     // values already scaled by 1 / (activation scale)
+    float a = fminf(fmaxf(v[0], -FP8_MAX), FP8_MAX), b = fminf(fmaxf(v[1], -FP8_MAX), FP8_MAX);
+    float c = fminf(fmaxf(v[2], -FP8_MAX), FP8_MAX), d = fminf(fmaxf(v[3], -FP8_MAX), FP8_MAX);
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    *(uint32_t*)p = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+}
+
 __device__ u32x4 d2s_attn_zero_page[4];
 
-template <typename T, int QF, int NW, int NS = 3>
+// OT: output element type (T, or e4m3 when the output projection runs on fp8 operands: out = sat(result * oscale))
+template <typename T, int QF, int NW, int NS = 3, typename OT = T>
 __global__ void __launch_bounds__(64 * NW)
-attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restrict__ out,
-                 int N, int Npad, int heads, float scale_log2e) {
+attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, OT* __restrict__ out,
+                 int N, int Npad, int heads, float scale_log2e, float oscale) {
     using A = AT<T>;
     constexpr int CE = A::CE, CPR = A::CPR, NKS = A::NKS;
     constexpr int TILE_CHUNKS = 64 * CPR;              // chunks in one 64-row tile
@@ -241,9 +249,9 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
         float l = l_run[f];
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
-        float inv = 1.0f / l;
+        float inv = oscale / l;
         if (qrow[f] < N) {
-            T* orow = out + ((long)b * N + qrow[f]) * D + h * 64;
+            OT* orow = out + ((long)b * N + qrow[f]) * D + h * 64;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 float v[4] = {o[f][d][0] * inv, o[f][d][1] * inv, o[f][d][2] * inv, o[f][d][3] * inv};
@@ -253,8 +261,10 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, T* __restr
     }
 }
 
-int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B, int N, int Npad, int heads, hipStream_t st) {
+int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B, int N, int Npad, int heads, hipStream_t st,
+                     float fp8_qscale) {
     const float scale_log2e = 0.125f * 1.4426950408889634f;          // 64^-0.5 * log2(e)
+    if (fp8_qscale > 0.f && prec != D2S_PREC_BF16) { set_error("attention: e4m3 output needs bf16 inputs"); return D2S_E_UNSUPPORTED; }
     // q rows per block: 128 as 8 waves x 1 fragment once that fills the chip (batch >= ~8), else 64 as 4 waves.
     // Swept at batch 1 / 16: 4 waves x 2 fragments 80 us, ring depth 2 / 4 within 3 %, 8 x 2 (256 rows) 68 us,
     // 8 x 1 67 us (444 TFLOP/s); 32-row blocks slower (K/V tile loads not amortised).  D2S_ATTN_BQ forces 128 / 64 / 32.
@@ -262,8 +272,13 @@ int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B
     long hb = (long)heads * B;
     int bq = force ? force : (cdiv(N, 128) * hb >= 512 ? 128 : 64);
 #define D2S_ATT(TT, QF_, NW_) hipLaunchKernelGGL((attention_kernel<TT, QF_, NW_>), dim3(cdiv(N, NW_ * QF_ * 16), heads, B), dim3(64 * NW_), 0, st, \
-        (const TT*)qkv, (const TT*)vt, (TT*)out, N, Npad, heads, scale_log2e)
-    if (prec == D2S_PREC_BF16) {
+        (const TT*)qkv, (const TT*)vt, (TT*)out, N, Npad, heads, scale_log2e, 1.0f)
+#define D2S_ATT8(QF_, NW_) hipLaunchKernelGGL((attention_kernel<bf16_t, QF_, NW_, 3, fp8_t>), dim3(cdiv(N, NW_ * QF_ * 16), heads, B), dim3(64 * NW_), 0, st, \
+        (const bf16_t*)qkv, (const bf16_t*)vt, (fp8_t*)out, N, Npad, heads, scale_log2e, fp8_qscale)
+    if (fp8_qscale > 0.f) {
+        if (bq == 128) D2S_ATT8(1, 8);
+        else D2S_ATT8(1, 4);
+    } else if (prec == D2S_PREC_BF16) {
         if (bq == 128) D2S_ATT(bf16_t, 1, 8);
         else if (bq == 64) D2S_ATT(bf16_t, 1, 4);
         else D2S_ATT(bf16_t, 1, 2);
@@ -272,6 +287,7 @@ int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B
         else D2S_ATT(float, 1, 2);
     }
 #undef D2S_ATT
+#undef D2S_ATT8
     D2S_CHECK_LAUNCH();
     return D2S_OK;
 }

@@ -40,6 +40,37 @@ __host__ __device__ static inline float bf2f(bf16_t h) {
     union { float f; uint32_t u; } v; v.u = ((uint32_t)h) << 16; return v.f;
 }
 
+// ---- fp8: OCP e4m3fn (gfx950's format; bias 7, max 448, no infinities, NaN = 0x7f) ----------------------------
+typedef unsigned char fp8_t;     // raw e4m3 bits
+constexpr float FP8_MAX = 448.0f;
+
+// software encoder (host-side weight packing; also the reference the device path is tested against):
+// round-to-nearest-even, saturating at +-448
+__host__ __device__ static inline fp8_t f2e4m3(float f) {
+    union { float f; uint32_t u; } v; v.f = f;
+    const uint32_t sign = (v.u >> 24) & 0x80u;
+    if ((v.u & 0x7fffffffu) > 0x7f800000u) return (fp8_t)(sign | 0x7fu);
+    v.u &= 0x7fffffffu;
+    float a = v.f;
+    if (a >= FP8_MAX) return (fp8_t)(sign | 0x7eu);
+    if (a < 0.015625f) {                                  // below the smallest normal 2^-6: multiples of 2^-9
+        float q = a * 512.0f + 12582912.0f;               // 1.5 * 2^23: the add rounds to nearest-even integer
+        q -= 12582912.0f;
+        return (fp8_t)(sign | (uint32_t)(int)q);          // 8 is 0x08, the smallest normal
+    }
+    uint32_t u = v.u;
+    u += 0x7ffffu + ((u >> 20) & 1u);                      // RNE to 3 mantissa bits
+    const uint32_t e = (u >> 23) - 127u + 7u, m = (u >> 20) & 7u;
+    return (fp8_t)(sign | (e << 3) | m);
+}
+__host__ __device__ static inline float e4m32f(fp8_t b) {
+    const uint32_t e = (b >> 3) & 15u, m = b & 7u;
+    float a;
+    if (e == 0) a = (float)m * 0.001953125f;               // m * 2^-9
+    else { union { float f; uint32_t u; } v; v.u = ((e - 7u + 127u) << 23) | (m << 20); a = v.f; }
+    return (b & 0x80u) ? -a : a;
+}
+
 // last activation of the DPT head (HF DepthAnythingDepthEstimationHead.forward): ReLU for relative models,
 // sigmoid(x) * max_depth for metric ones (depth_estimation_type == "metric")
 __device__ static inline float head_activation(float v, float max_depth) {

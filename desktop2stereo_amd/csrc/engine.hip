@@ -25,6 +25,11 @@ struct PackedW {           // device: W [Npad][Kpad] T, bias [N] f32 (or null)
 struct Layer {
     float *ln1g, *ln1b, *ln2g, *ln2b, *ls1, *ls2;
     PackedW qkv, proj, fc1, fc2;
+    // D2S_PREC_FP8: e4m3 copies of the four linears (index 0 qkv, 1 proj, 2 fc1, 3 fc2) with per-output-channel weight
+    // scales; deq[i][n] = s_act(site feeding linear i) * s_w[i][n] is filled in by d2s_engine_calibrate
+    PackedW w8[4];
+    std::vector<float> sw[4];
+    float* deq[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 }  // namespace
@@ -82,6 +87,10 @@ struct d2s_engine {
     bool taps = false;
     float* tap_hidden = nullptr;                   // [(layers+1), N, D]
     int last_batch = 0;
+    // D2S_PREC_FP8 (BASELINE config 3): encoder linears on e4m3 operands once calibrated
+    bool fp8 = false, fp8_ready = false, calib = false;
+    float* amax = nullptr;                         // device [layers][4]: max |.| of LN1 out, attention out, LN2 out, GELU out
+    std::vector<float> act_scale;                  // host   [layers][4]: amax / 448
     // per-kernel-class timing with HIP events (d2s_engine_profile): off in the throughput path
     struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
     bool prof_on = false;
@@ -159,6 +168,26 @@ int pack_matrix(d2s_engine* e, int N, int K, F at, const float* bias_host, Packe
         if (rc) return rc;
         D2S_HIP(hipMemcpy(out.bias, bias_host, (size_t)N * sizeof(float), hipMemcpyHostToDevice));
     }
+    return D2S_OK;
+}
+
+// e4m3 copy of a logical [N][K] matrix: row n is divided by s_w[n] = max|row| / 448 and rounded to e4m3 (RNE)
+template <typename F>
+int pack_matrix_fp8(d2s_engine* e, int N, int K, F at, const float* bias_dev, PackedW& out, std::vector<float>& sw) {
+    int Kp = gemm_kpad(K, D2S_PREC_FP8_OPERANDS), Np = gemm_npad(N);
+    std::vector<uint8_t> buf((size_t)Np * Kp, 0);
+    sw.assign(N, 1.f);
+    for (int n = 0; n < N; ++n) {
+        float amax = 0.f;
+        for (int k = 0; k < K; ++k) amax = fmaxf(amax, fabsf(at(n, k)));
+        float s = amax > 0.f ? amax / FP8_MAX : 1.f;
+        sw[n] = s;
+        for (int k = 0; k < K; ++k) buf[(size_t)n * Kp + k] = f2e4m3(at(n, k) / s);
+    }
+    int rc = dev_alloc(e, &out.w, buf.size());
+    if (rc) return rc;
+    D2S_HIP(hipMemcpy(out.w, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    out.N = N; out.K = K; out.Kpad = Kp; out.bias = const_cast<float*>(bias_dev);   // shares the bf16 copy's bias vector
     return D2S_OK;
 }
 
@@ -259,6 +288,12 @@ int gemm(d2s_engine* e, const GemmA& a, const PackedW& w, int M, const GemmEpi& 
     return D2S_OK;
 }
 
+// the same linear on e4m3 operands (A rows are e4m3 bytes, lda in elements); the epilogue de-quantises with ep.deq
+int gemm8(d2s_engine* e, const GemmA& a, const PackedW& w, int M, const GemmEpi& ep, hipStream_t st) {
+    PROF(PC_GEMM, 2.0 * M * w.N * w.K, 0, launch_gemm(D2S_PREC_FP8_OPERANDS, 0, a, w.w, M, w.N, w.K, w.Kpad, ep, st));
+    return D2S_OK;
+}
+
 #define RC(x) do { int _rc = (x); if (_rc != D2S_OK) return _rc; } while (0)
 
 // 3x3 conv (pad 1) as implicit GEMM over NHWC
@@ -315,6 +350,10 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     const d2s_model_desc& d = e->d;
     const int D = d.hidden, N = e->N, P = e->P, M = B * N, Mp = B * P, prec = e->prec;
     const int F = d.fusion;
+    if (e->fp8 && !e->fp8_ready && !e->calib) {
+        set_error("D2S_PREC_FP8 engine: activation scales are not set, call d2s_engine_calibrate first");
+        return D2S_E_STATE;
+    }
     // ---- embeddings (HF Dinov2Embeddings)
     PROF(PC_ELT, 0, 0, launch_patchify(prec, x, e->patchA, B, e->h, e->w, d.patch, e->patch.Kpad, e->cls, e->pos, e->resid, N, D, st));
     {
@@ -326,30 +365,44 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     if (e->taps) D2S_HIP(hipMemcpyAsync(e->tap_hidden, e->resid, (size_t)N * D * 4, hipMemcpyDeviceToDevice, st));
     // ---- encoder (HF Dinov2Layer x L)
     int tap_i = 0;
+    // D2S_PREC_FP8: the producers of the four linears' A operands write e4m3 (x / s_act, saturated); the linears run on
+    // e4m3 operands and de-quantise in their epilogue (deq[n] = s_act * s_w[n]); QKV still emits bf16 for the attention
+    const bool f8 = e->fp8 && !e->calib;
     for (int l = 0; l < d.layers; ++l) {
         const Layer& ly = e->L[l];
-        PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln1g, ly.ln1b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st));
+        const float* sa = f8 ? &e->act_scale[(size_t)l * 4] : nullptr;     // s_act of LN1 out, attention out, LN2 out, GELU out
+        float* am = e->calib ? e->amax + (size_t)l * 4 : nullptr;
+        PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln1g, ly.ln1b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[0] : 0.f));
+        if (am) RC(launch_amax(prec, e->lnbuf, (long)M * D, am + 0, st));
         {
-            GemmEpi ep = rowsE(e->qkv, OUT_T, 3 * D, ly.qkv.bias);
+            GemmEpi ep = rowsE(e->qkv, f8 ? OUT_BF16 : OUT_T, 3 * D, ly.qkv.bias);
             ep.map = MAP_QKV; ep.vt = e->vt; ep.ntok = N; ep.npad = e->Npad; ep.qk_cols = 2 * D; ep.heads = d.heads;
-            RC(gemm(e, plainA(e->lnbuf, D), ly.qkv, M, ep, st));
+            if (f8) { ep.deq = ly.deq[0]; RC(gemm8(e, plainA(e->lnbuf, D), ly.w8[0], M, ep, st)); }
+            else RC(gemm(e, plainA(e->lnbuf, D), ly.qkv, M, ep, st));
         }
-        PROF(PC_ATTN, 4.0 * B * d.heads * (double)N * N * 64, 0, launch_attention(prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st));
+        PROF(PC_ATTN, 4.0 * B * d.heads * (double)N * N * 64, 0,
+             launch_attention(prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st, f8 ? 1.0f / sa[1] : 0.f));
+        if (am) RC(launch_amax(prec, e->attn, (long)M * D, am + 1, st));
         {
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.proj.bias);
             ep.scale = ly.ls1; ep.res1 = e->resid;
-            RC(gemm(e, plainA(e->attn, D), ly.proj, M, ep, st));
+            if (f8) { ep.deq = ly.deq[1]; RC(gemm8(e, plainA(e->attn, D), ly.w8[1], M, ep, st)); }
+            else RC(gemm(e, plainA(e->attn, D), ly.proj, M, ep, st));
         }
-        PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln2g, ly.ln2b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st));
+        PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln2g, ly.ln2b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[2] : 0.f));
+        if (am) RC(launch_amax(prec, e->lnbuf, (long)M * D, am + 2, st));
         {
             GemmEpi ep = rowsE(e->mlp, OUT_T, d.mlp, ly.fc1.bias);
             ep.act = ACT_GELU;
-            RC(gemm(e, plainA(e->lnbuf, D), ly.fc1, M, ep, st));
+            if (f8) { ep.deq = ly.deq[2]; ep.out_qscale = 1.0f / sa[3]; RC(gemm8(e, plainA(e->lnbuf, D), ly.w8[2], M, ep, st)); }
+            else RC(gemm(e, plainA(e->lnbuf, D), ly.fc1, M, ep, st));
         }
+        if (am) RC(launch_amax(prec, e->mlp, (long)M * d.mlp, am + 3, st));
         {
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.fc2.bias);
             ep.scale = ly.ls2; ep.res1 = e->resid;
-            RC(gemm(e, plainA(e->mlp, d.mlp), ly.fc2, M, ep, st));
+            if (f8) { ep.deq = ly.deq[3]; RC(gemm8(e, plainA(e->mlp, d.mlp), ly.w8[3], M, ep, st)); }
+            else RC(gemm(e, plainA(e->mlp, d.mlp), ly.fc2, M, ep, st));
         }
         if (e->taps) D2S_HIP(hipMemcpyAsync(e->tap_hidden + (size_t)(l + 1) * N * D, e->resid, (size_t)N * D * 4, hipMemcpyDeviceToDevice, st));
         if (tap_i < 4 && l + 1 == d.out_indices[tap_i]) {     // HF Dinov2Backbone: shared final LN, drop cls
@@ -440,14 +493,16 @@ extern "C" int d2s_engine_create(const d2s_model_desc* desc, int device_id, d2s_
     D2S_REQUIRE(desc && out, "null pointer");
     D2S_REQUIRE(desc->hidden > 0 && desc->heads > 0 && desc->hidden == desc->heads * 64, "head_dim must be 64");
     D2S_REQUIRE(desc->layers > 0 && desc->patch > 0 && desc->pos_grid > 0 && desc->fusion % 8 == 0, "bad model desc");
-    D2S_REQUIRE(desc->precision == D2S_PREC_FP32 || desc->precision == D2S_PREC_BF16, "bad precision");
+    D2S_REQUIRE(desc->precision == D2S_PREC_FP32 || desc->precision == D2S_PREC_BF16 || desc->precision == D2S_PREC_FP8, "bad precision");
     for (int i = 0; i < 4; ++i) D2S_REQUIRE(desc->neck[i] % 8 == 0 && desc->out_indices[i] >= 1 && desc->out_indices[i] <= desc->layers, "bad neck / out_indices");
     D2S_REQUIRE(desc->head_hidden % 4 == 0 && desc->mlp % 8 == 0, "bad head_hidden / mlp");
     D2S_REQUIRE(desc->max_depth >= 0.f && !(desc->temporal && desc->max_depth > 0.f),
                 "max_depth must be >= 0, and 0 for a Video-Depth-Anything engine (its head ends in ReLU, dpt_temporal.py:136)");
     D2S_HIP(hipSetDevice(device_id));
     d2s_engine* e = new d2s_engine();
-    e->d = *desc; e->device = device_id; e->prec = desc->precision;
+    e->d = *desc; e->device = device_id;
+    e->fp8 = desc->precision == D2S_PREC_FP8;                  // bf16 engine whose encoder linears switch to e4m3 operands
+    e->prec = e->fp8 ? D2S_PREC_BF16 : desc->precision;
     const char* t = getenv("D2S_TAPS");
     e->taps = t && atoi(t) != 0;
     *out = e;
@@ -509,6 +564,20 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
         RC(pack_linear(e, p + "attention.output.dense.weight", p + "attention.output.dense.bias", D, D, ly.proj));
         RC(pack_linear(e, p + "mlp.fc1.weight", p + "mlp.fc1.bias", d.mlp, D, ly.fc1));
         RC(pack_linear(e, p + "mlp.fc2.weight", p + "mlp.fc2.bias", D, d.mlp, ly.fc2));
+        if (e->fp8) {
+            const float* wo = find(e, p + "attention.output.dense.weight")->data.data();
+            const float* w1 = find(e, p + "mlp.fc1.weight")->data.data();
+            const float* w2 = find(e, p + "mlp.fc2.weight")->data.data();
+            RC(pack_matrix_fp8(e, 3 * D, D, [&](int n, int k) { return ws[n / D][(size_t)(n % D) * D + k]; }, ly.qkv.bias, ly.w8[0], ly.sw[0]));
+            RC(pack_matrix_fp8(e, D, D, [&](int n, int k) { return wo[(size_t)n * D + k]; }, ly.proj.bias, ly.w8[1], ly.sw[1]));
+            RC(pack_matrix_fp8(e, d.mlp, D, [&](int n, int k) { return w1[(size_t)n * D + k]; }, ly.fc1.bias, ly.w8[2], ly.sw[2]));
+            RC(pack_matrix_fp8(e, D, d.mlp, [&](int n, int k) { return w2[(size_t)n * d.mlp + k]; }, ly.fc2.bias, ly.w8[3], ly.sw[3]));
+            for (int i = 0; i < 4; ++i) RC(dev_alloc(e, (void**)&ly.deq[i], (size_t)ly.w8[i].N * sizeof(float), true));
+        }
+    }
+    if (e->fp8) {
+        RC(dev_alloc(e, (void**)&e->amax, (size_t)d.layers * 4 * sizeof(float), true));
+        e->act_scale.assign((size_t)d.layers * 4, 0.f);
     }
     RC(upload_f32(e, "backbone.layernorm.weight", D, &e->lnfg));
     RC(upload_f32(e, "backbone.layernorm.bias", D, &e->lnfb));
@@ -632,6 +701,42 @@ extern "C" int d2s_model_forward(d2s_engine* e, const float* x, float* depth, in
     D2S_REQUIRE(batch >= 1 && batch <= e->maxB, "batch exceeds max_batch");
     D2S_REQUIRE(!e->d.temporal || batch == 1, "a Video-Depth-Anything engine is one stream: batch must be 1");
     return forward(e, x, depth, batch, (hipStream_t)stream);
+}
+
+extern "C" int d2s_engine_calibrate(d2s_engine* e, const float* x, int batch, void* stream) {
+    D2S_REQUIRE(e && x, "null pointer");
+    if (!e->finalized) { set_error("d2s_engine_calibrate before d2s_engine_finalize"); return D2S_E_STATE; }
+    D2S_REQUIRE(e->fp8, "d2s_engine_calibrate: not a D2S_PREC_FP8 engine");
+    D2S_REQUIRE(batch >= 1 && batch <= e->maxB && !e->d.temporal, "bad batch (or a Video-Depth-Anything engine)");
+    hipStream_t st = (hipStream_t)stream;
+    const int L = e->d.layers;
+    // one bf16 forward over the calibration frames, recording max |activation| at the four quantisation sites per layer
+    D2S_HIP(hipMemsetAsync(e->amax, 0, (size_t)L * 4 * sizeof(float), st));
+    const bool prof = e->prof_on;
+    e->prof_on = false;
+    e->calib = true;
+    int rc = forward(e, x, e->depth_small, batch, st);
+    e->calib = false;
+    e->prof_on = prof;
+    if (rc != D2S_OK) return rc;
+    std::vector<float> am((size_t)L * 4);
+    D2S_HIP(hipMemcpyAsync(am.data(), e->amax, am.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    D2S_HIP(hipStreamSynchronize(st));
+    for (int l = 0; l < L; ++l) {
+        Layer& ly = e->L[l];
+        for (int s = 0; s < 4; ++s) {
+            float a = am[(size_t)l * 4 + s];
+            if (!(a > 0.f) || !std::isfinite(a)) { set_error("d2s_engine_calibrate: degenerate activation range"); return D2S_E_INVALID; }
+            e->act_scale[(size_t)l * 4 + s] = a / FP8_MAX;
+        }
+        for (int i = 0; i < 4; ++i) {                         // linear i reads site i (qkv <- LN1, proj <- attention, fc1 <- LN2, fc2 <- GELU)
+            std::vector<float> dq(ly.sw[i].size());
+            for (size_t n = 0; n < dq.size(); ++n) dq[n] = e->act_scale[(size_t)l * 4 + i] * ly.sw[i][n];
+            D2S_HIP(hipMemcpy(ly.deq[i], dq.data(), dq.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
+    e->fp8_ready = true;
+    return D2S_OK;
 }
 
 extern "C" int d2s_engine_reset_stream(d2s_engine* e) {

@@ -8,7 +8,9 @@ namespace d2s {
 enum { A_PLAIN = 0, A_CONV3 = 1 };
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
 enum { MAP_ROWS = 0, MAP_SHUFFLE = 1, MAP_QKV = 2, MAP_HEAD = 3 };
-enum { OUT_T = 0, OUT_F32 = 1 };
+enum { OUT_T = 0, OUT_F32 = 1, OUT_BF16 = 2 };   // OUT_T: operand type (fp8 operands: e4m3 of v * out_qscale)
+
+constexpr int D2S_PREC_FP8_OPERANDS = D2S_PREC_FP8;   // as a GEMM precision: e4m3 operands (A and W), fp32 accumulate
 
 struct GemmA {
     const void* ptr;      // T*
@@ -41,16 +43,20 @@ struct GemmEpi {
     // MAP_HEAD: out = float depth[M]; bias = conv2 bias, scale = conv3 weights [N], head_b3 = conv3 bias
     float head_b3;
     float head_max_depth;                  // 0: ReLU; > 0: sigmoid * max_depth (metric head)
+    // fp8 operands: acc is in units of (activation scale * weight scale[n]); deq[n] = s_act * s_w[n] turns it back
+    // into real values before bias.  out_qscale = 1 / s_out for an e4m3 output (OUT_T with fp8 operands).
+    const float* deq;
+    float out_qscale;
 };
 
-// precision: D2S_PREC_FP32 (T = float) / D2S_PREC_BF16 (T = bf16).  tile: 0 = auto, 64, 128, 256128, 256256.
+// precision: D2S_PREC_FP32 (T = float) / D2S_PREC_BF16 (T = bf16) / D2S_PREC_FP8_OPERANDS (T = e4m3).  tile: 0 = auto.
 int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad,
                 const GemmEpi& e, hipStream_t st);
 
 // packed-weight geometry
-static inline int gemm_bk(int precision) { return precision == D2S_PREC_BF16 ? 64 : 32; }   // 128-byte K tile
+static inline size_t elem_size(int precision) { return precision == D2S_PREC_BF16 ? 2 : (precision == D2S_PREC_FP8_OPERANDS ? 1 : 4); }
+static inline int gemm_bk(int precision) { return 128 / (int)elem_size(precision); }   // 128-byte K tile
 static inline int gemm_kpad(int K, int precision) { int bk = 2 * gemm_bk(precision); return (K + bk - 1) / bk * bk; }   // 256-byte multiple
 static inline int gemm_npad(int N) { return (N + 255) / 256 * 256; }
-static inline size_t elem_size(int precision) { return precision == D2S_PREC_BF16 ? 2 : 4; }
 
 }  // namespace d2s

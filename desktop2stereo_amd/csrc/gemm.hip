@@ -25,6 +25,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vect
 template <typename T> struct Prec;
 template <> struct Prec<bf16_t> { static constexpr int CE = 8; };   // elements per 16-byte chunk
 template <> struct Prec<float>  { static constexpr int CE = 4; };
+template <> struct Prec<fp8_t>  { static constexpr int CE = 16; };  // e4m3: a 128-byte K tile holds 128 elements
 
 __device__ __forceinline__ u32x4 relu_chunk(u32x4 v, bf16_t) {
     uint32_t* p = (uint32_t*)&v;
@@ -47,6 +48,15 @@ __device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& w, const u32x
     const float* af = (const float*)&a;
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], af[t], acc, 0, 0, 0);
+}
+
+// e4m3 operands: a 16-byte chunk is 16 K elements = two v_mfma_f32_16x16x32_fp8_fp8 (8 bytes per lane each; the k
+// permutation is again the same for both operands).  Same MFMA count per byte as bf16, twice the K per byte moved.
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& w, const u32x4& a, fp8_t) {
+    const long* wl = (const long*)&w;
+    const long* al = (const long*)&a;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[0], al[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[1], al[1], acc, 0, 0, 0);
 }
 
 // exact-erf GELU (HF Dinov2MLP: nn.GELU()).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e. at
@@ -82,12 +92,28 @@ __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
     *(uint2*)p = t;
 }
 
+// four floats -> four e4m3 bytes (v_cvt_pk_fp8_f32, round-to-nearest-even), saturating at +-448
+__device__ __forceinline__ uint32_t pk_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -FP8_MAX), FP8_MAX); b = fminf(fmaxf(b, -FP8_MAX), FP8_MAX);
+    c = fminf(fmaxf(c, -FP8_MAX), FP8_MAX); d = fminf(fmaxf(d, -FP8_MAX), FP8_MAX);
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+}
+__device__ __forceinline__ void load4(const fp8_t* p, float v[4]) {
+    uint32_t t = *(const uint32_t*)p;
+    v[0] = e4m32f((fp8_t)(t & 255u)); v[1] = e4m32f((fp8_t)((t >> 8) & 255u));
+    v[2] = e4m32f((fp8_t)((t >> 16) & 255u)); v[3] = e4m32f((fp8_t)(t >> 24));
+}
+__device__ __forceinline__ void store4(fp8_t* p, const float v[4]) { *(uint32_t*)p = pk_fp8x4(v[0], v[1], v[2], v[3]); }
+
 template <typename OT> __device__ __forceinline__ OT cvt_out(float v);
 template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float v) { return f2bf(v); }
+template <> __device__ __forceinline__ fp8_t cvt_out<fp8_t>(float v) { return (fp8_t)(pk_fp8x4(v, 0.f, 0.f, 0.f) & 255u); }
 
 template <typename OT>
 __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float v[4]) {
+    if (e.deq) { float q[4]; load4(e.deq + n0, q); v[0] *= q[0]; v[1] *= q[1]; v[2] *= q[2]; v[3] *= q[3]; }   // fp8 operands -> real units
     if (e.bias) { float b[4]; load4(e.bias + n0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
     if (e.act == ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
     else if (e.act == ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -115,7 +141,16 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float
         float r[4]; load4((const OT*)e.res1 + roff, r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
     }
     if (e.res2) { float r[4]; load4((const OT*)e.res2 + off, r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+    if constexpr (std::is_same<OT, fp8_t>::value) { v[0] *= e.out_qscale; v[1] *= e.out_qscale; v[2] *= e.out_qscale; v[3] *= e.out_qscale; }
     store4((OT*)e.out + off, v);
+}
+
+// out_type -> element type of the output / residuals
+template <typename T>
+__device__ __forceinline__ void epilogue_dispatch(const GemmEpi& e, int m, int n0, float v[4]) {
+    if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v);
+    else if (e.out_type == OUT_BF16) epilogue4<bf16_t>(e, m, n0, v);
+    else epilogue4<T>(e, m, n0, v);
 }
 
 // XCD-aware block -> tile map.  Workgroup b is dispatched to XCD b % 8 (observed, used for speed
@@ -278,6 +313,7 @@ __device__ __forceinline__ u32x4 relu_frag(u32x4 v, int floor_bits, bf16_t) {
     x = __builtin_elementwise_max(x, (s16x8){f, f, f, f, f, f, f, f});
     return __builtin_bit_cast(u32x4, x);
 }
+__device__ __forceinline__ u32x4 relu_frag(u32x4 v, int, fp8_t) { return v; }   // e4m3 operands: encoder linears only, no ReLU-on-load
 __device__ __forceinline__ u32x4 relu_frag(u32x4 v, int floor_bits, float) {
     f32x4 x = __builtin_bit_cast(f32x4, v);
     float f = floor_bits == 0 ? 0.f : -3.0e38f;
@@ -517,8 +553,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
                 if (n0 < N) {
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     if (ksplit > 1) store4(e.part + ((long)blockIdx.y * M + m) * N + n0, v);     // reduced by splitk_reduce_kernel
-                    else if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v);
-                    else epilogue4<T>(e, m, n0, v);
+                    else epilogue_dispatch<T>(e, m, n0, v);
                 }
             });
         }
@@ -539,8 +574,7 @@ splitk_reduce_kernel(GemmEpi e, int M, int N) {
         load4(e.part + ((long)s * M + m) * N + n0, p);
         v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
     }
-    if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v);
-    else epilogue4<T>(e, m, n0, v);
+    epilogue_dispatch<T>(e, m, n0, v);
 }
 
 // pick the XCD grid (xn x 8/xn) for a tiles_m x tiles_n tile space: least padding, W chunk within L2
@@ -607,12 +641,14 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
         else if (b64 <= 160 && b64 >= 128 && K >= 2048 && a.mode == A_PLAIN) tile = 74964;   // batch-1 FC2: few tiles, 48 K tiles -> 4 K groups per block
         else tile = 3264;                           // skinny launches (batch 1, N = 768): more, smaller blocks
     }
-    if (v1 && (tile == 128 || tile == 64)) {
-        unsigned grid = 0;
-        if (tile == 128) { int xn = pick_xn(cdiv(M, 128), cdiv(N, 128), 128, Kpad, sizeof(T), grid);
-            hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), dim3(grid), dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn); }
-        else { int xn = pick_xn(cdiv(M, 64), cdiv(N, 64), 64, Kpad, sizeof(T), grid);
-            hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), dim3(grid), dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn); }
+    if (v1 && (tile == 128 || tile == 64) && !std::is_same<T, fp8_t>::value) {
+        if constexpr (!std::is_same<T, fp8_t>::value) {
+            unsigned grid = 0;
+            if (tile == 128) { int xn = pick_xn(cdiv(M, 128), cdiv(N, 128), 128, Kpad, sizeof(T), grid);
+                hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), dim3(grid), dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn); }
+            else { int xn = pick_xn(cdiv(M, 64), cdiv(N, 64), 64, Kpad, sizeof(T), grid);
+                hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), dim3(grid), dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn); }
+        }
     }
     // LDS-DMA ring (NS stages)
     else if (tile == 256128) launch_glds<T, 256, 128, 4, 2, 3>(a, W, M, N, K, Kpad, e, st);
@@ -641,24 +677,30 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
 
 int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad,
                 const GemmEpi& e, hipStream_t st) {
-    const int ce = precision == D2S_PREC_BF16 ? 8 : 4;
+    const int ce = 16 / (int)elem_size(precision);
     if (M <= 0 || N <= 0 || K <= 0 || (N & 3) || (K % ce) || Kpad % (2 * gemm_bk(precision))) {
         set_error("launch_gemm: bad dims (N % 4, K % chunk, Kpad % BK)"); return D2S_E_INVALID;
     }
     if (a.mode == A_PLAIN && (a.lda % ce)) { set_error("launch_gemm: lda not chunk aligned"); return D2S_E_INVALID; }
     if (a.mode == A_CONV3 && (a.C % ce)) { set_error("launch_gemm: conv channels not chunk aligned"); return D2S_E_INVALID; }
     if (precision == D2S_PREC_BF16) return launch_t<bf16_t>(tile, a, W, M, N, K, Kpad, e, st);
+    if (precision == D2S_PREC_FP8_OPERANDS) {
+        if (a.mode != A_PLAIN || a.relu) { set_error("launch_gemm: e4m3 operands are for plain linears"); return D2S_E_UNSUPPORTED; }
+        return launch_t<fp8_t>(tile, a, W, M, N, K, Kpad, e, st);
+    }
     return launch_t<float>(tile, a, W, M, N, K, Kpad, e, st);
 }
 
 // ---- test / micro-benchmark probe -----------------------------------------------------------------
 __global__ void cast_pad_kernel(const float* __restrict__ src, void* __restrict__ dst, int rows, int cols,
-                                int rows_pad, int cols_pad, int bf16) {
+                                int rows_pad, int cols_pad, int prec) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)rows_pad * cols_pad) return;
     int c = (int)(idx % cols_pad), r = (int)(idx / cols_pad);
     float v = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
-    if (bf16) ((bf16_t*)dst)[idx] = f2bf(v); else ((float*)dst)[idx] = v;
+    if (prec == D2S_PREC_BF16) ((bf16_t*)dst)[idx] = f2bf(v);
+    else if (prec == D2S_PREC_FP8_OPERANDS) ((fp8_t*)dst)[idx] = f2e4m3(v);      // unit scales: the caller keeps |v| <= 448
+    else ((float*)dst)[idx] = v;
 }
 
 }  // namespace d2s
@@ -668,9 +710,9 @@ using namespace d2s;
 extern "C" int d2s_gemm_probe(const float* A, const float* Wt, const float* bias, float* Cout, int M, int N, int K,
                               int precision, int tile, int iters, void* stream) {
     D2S_REQUIRE(A && Wt && Cout && M > 0 && N > 0 && K > 0 && (N % 4 == 0) && iters >= 1, "bad argument");
-    D2S_REQUIRE(precision == D2S_PREC_BF16 || precision == D2S_PREC_FP32, "bad precision");
+    D2S_REQUIRE(precision == D2S_PREC_BF16 || precision == D2S_PREC_FP32 || precision == D2S_PREC_FP8_OPERANDS, "bad precision");
     hipStream_t st = (hipStream_t)stream;
-    int bf = precision == D2S_PREC_BF16;
+    int bf = precision;
     int Kp = gemm_kpad(K, precision), Np = gemm_npad(N);
     size_t es = elem_size(precision);
     void *dA = nullptr, *dW = nullptr;

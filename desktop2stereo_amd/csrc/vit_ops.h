@@ -8,7 +8,8 @@ int launch_patchify(int prec, const float* x, void* A, int B, int h, int w, int 
                     const float* cls, const float* pos, float* resid, int N, int D, hipStream_t st);   // also writes the cls rows
 int launch_cls_rows(const float* cls, const float* pos, float* resid, int B, int N, int D, hipStream_t st);
 int launch_layernorm(int prec, const float* x, const float* g, const float* b, void* out, int rows_out, int D, float eps,
-                     int rows_per_img, int img_rows, int row_off, hipStream_t st);
+                     int rows_per_img, int img_rows, int row_off, hipStream_t st, float fp8_qscale = 0.f);   // > 0: e4m3 output
+int launch_amax(int prec, const void* x, long n, float* slot, hipStream_t st);       // *slot = max(*slot, max |x|); fp8 calibration
 int launch_bilinear_nhwc(int prec, const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t st);
 int launch_head_final(int prec, const void* x, const float* w3, float b3, float max_depth, float* depth, long npix, int C, hipStream_t st);
 int launch_to_f32(int prec, const void* in, float* out, long n, hipStream_t st);
@@ -16,7 +17,9 @@ int launch_to_f32(int prec, const void* in, float* out, long n, hipStream_t st);
 // Multi-head self-attention over the fused QKV activation [B*N, 3*D] (q | k | v, head-major inside
 // each), head_dim 64: out[B*N, D] = softmax(q k^T / 8) v.  (HF Dinov2SelfAttention.forward)
 // vt: V transposed [B, heads, 64, Npad] (Npad = N rounded up to 64, zero beyond N), see MAP_QKV in gemm.h.
-int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B, int N, int Npad, int heads, hipStream_t st);
+// fp8_qscale > 0 (bf16 inputs only): out is e4m3 = sat(result * fp8_qscale), the A operand of an fp8 output projection.
+int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B, int N, int Npad, int heads, hipStream_t st,
+                     float fp8_qscale = 0.f);
 
 // Video-Depth-Anything temporal-module kernels (temporal.hip)
 int launch_groupnorm(int prec, const void* x, const float* g, const float* b, void* out, int sites, int C, int groups, float eps, hipStream_t st);

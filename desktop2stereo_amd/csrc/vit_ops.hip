@@ -14,6 +14,21 @@ template <> __device__ __forceinline__ bf16_t cvt<bf16_t>(float v) { return f2bf
 __device__ __forceinline__ float tof(float v) { return v; }
 __device__ __forceinline__ float tof(bf16_t v) { return bf2f(v); }
 
+// 4 consecutive outputs of one row; e4m3 rows are scaled by qscale = 1 / (activation scale) and saturate at +-448
+__device__ __forceinline__ void store_row4(float* o, const float r[4], float) { *(float4*)o = make_float4(r[0], r[1], r[2], r[3]); }
+__device__ __forceinline__ void store_row4(bf16_t* o, const float r[4], float) {
+    uint2 t;
+    t.x = (uint32_t)f2bf(r[0]) | ((uint32_t)f2bf(r[1]) << 16);
+    t.y = (uint32_t)f2bf(r[2]) | ((uint32_t)f2bf(r[3]) << 16);
+    *(uint2*)o = t;
+}
+__device__ __forceinline__ void store_row4(fp8_t* o, const float r[4], float qscale) {
+    float a = fminf(fmaxf(r[0] * qscale, -FP8_MAX), FP8_MAX), b = fminf(fmaxf(r[1] * qscale, -FP8_MAX), FP8_MAX);
+    float c = fminf(fmaxf(r[2] * qscale, -FP8_MAX), FP8_MAX), d = fminf(fmaxf(r[3] * qscale, -FP8_MAX), FP8_MAX);
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    *(uint32_t*)o = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 patchify_kernel(const float* __restrict__ x, T* __restrict__ A, int B, int h, int w, int p, int Kp,
@@ -50,7 +65,7 @@ cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, fl
 template <typename T>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta,
-                 T* __restrict__ out, int rows_out, int D, float eps, int rows_per_img, int img_rows, int row_off) {
+                 T* __restrict__ out, int rows_out, int D, float eps, int rows_per_img, int img_rows, int row_off, float qscale) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (row >= rows_out) return;
@@ -85,8 +100,7 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const
             float4 gg = ((const float4*)g)[c], bb = ((const float4*)bta)[c];
             float r[4] = {(v[i].x - mu) * rstd * gg.x + bb.x, (v[i].y - mu) * rstd * gg.y + bb.y,
                           (v[i].z - mu) * rstd * gg.z + bb.z, (v[i].w - mu) * rstd * gg.w + bb.w};
-            T* o = orow + 4 * c;
-            o[0] = cvt<T>(r[0]); o[1] = cvt<T>(r[1]); o[2] = cvt<T>(r[2]); o[3] = cvt<T>(r[3]);
+            store_row4(orow + 4 * c, r, qscale);
         }
     }
 }
@@ -163,11 +177,32 @@ int launch_cls_rows(const float* cls, const float* pos, float* resid, int B, int
 }
 
 int launch_layernorm(int prec, const float* x, const float* g, const float* b, void* out, int rows_out, int D, float eps,
-                     int rows_per_img, int img_rows, int row_off, hipStream_t st) {
+                     int rows_per_img, int img_rows, int row_off, hipStream_t st, float fp8_qscale) {
     if (D > 1024 || (D & 3)) { set_error("layernorm: D must be a multiple of 4 and <= 1024"); return D2S_E_UNSUPPORTED; }
     dim3 grid(cdiv(rows_out, 4)), block(256);
-    DISPATCH_T(prec, hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, st, x, g, b, (bf16_t*)out, rows_out, D, eps, rows_per_img, img_rows, row_off),
-                     hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, st, x, g, b, (float*)out, rows_out, D, eps, rows_per_img, img_rows, row_off));
+    if (fp8_qscale > 0.f)       // e4m3 output for an fp8 linear: out = sat(LN(x) * qscale)
+        hipLaunchKernelGGL(layernorm_kernel<fp8_t>, grid, block, 0, st, x, g, b, (fp8_t*)out, rows_out, D, eps, rows_per_img, img_rows, row_off, fp8_qscale);
+    else
+        DISPATCH_T(prec, hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, st, x, g, b, (bf16_t*)out, rows_out, D, eps, rows_per_img, img_rows, row_off, 0.f),
+                         hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, st, x, g, b, (float*)out, rows_out, D, eps, rows_per_img, img_rows, row_off, 0.f));
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+// max |x| over a tensor into *slot (float bits as uint: non-negative floats order like uints); calibration only
+template <typename T>
+__global__ void __launch_bounds__(256)
+amax_kernel(const T* __restrict__ x, long n, unsigned* __restrict__ slot) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(tof(x[i])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+}
+int launch_amax(int prec, const void* x, long n, float* slot, hipStream_t st) {
+    dim3 grid((unsigned)(n / 2048 > 1024 ? 1024 : (n / 2048 < 1 ? 1 : n / 2048))), block(256);
+    DISPATCH_T(prec, hipLaunchKernelGGL(amax_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, n, (unsigned*)slot),
+                     hipLaunchKernelGGL(amax_kernel<float>, grid, block, 0, st, (const float*)x, n, (unsigned*)slot));
     D2S_CHECK_LAUNCH();
     return D2S_OK;
 }

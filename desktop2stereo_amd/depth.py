@@ -87,8 +87,10 @@ def _device() -> torch.device:
     return torch.device("cuda", _state["device"])
 
 
-def _ensure_engine_built(engine_h: int, engine_w: int) -> ops.Engine:
-    """Build the native engine on the first frame, once its shape is known (reference depth.py:1842-1862)."""
+def _ensure_engine_built(engine_h: int, engine_w: int, first_x: Optional[torch.Tensor] = None) -> ops.Engine:
+    """Build the native engine on the first frame, once its shape is known (reference depth.py:1842-1862).
+    precision "fp8": the static activation scales are calibrated on that first batch of model inputs (the reference
+    warms its engines up on the first frame the same way, depth.py:1861)."""
     if _state["cfg"] is None:
         raise _lib.D2SError("desktop2stereo_amd.depth.configure(...) has not been called")
     key = (engine_h, engine_w)
@@ -102,8 +104,20 @@ def _ensure_engine_built(engine_h: int, engine_w: int) -> ops.Engine:
         _state["engine"] = ops.Engine(_state["cfg"], _state["weights"], engine_h, engine_w, _state["max_batch"],
                                       _state["precision"], _state["device"], temporal=_state.get("temporal", False),
                                       max_depth=_state.get("max_depth", 0.0))
+        if _state["precision"] == "fp8":
+            if first_x is None:
+                raise _lib.D2SError("fp8 engine: no model inputs to calibrate on")
+            _state["engine"].calibrate(first_x[: _state["max_batch"]])
         _state["engine_key"] = key
     return _state["engine"]
+
+
+def _fp8_first_inputs(frames_u8: torch.Tensor, key) -> Optional[torch.Tensor]:
+    """Model inputs of the first batch, only when an fp8 engine is about to be built (calibration data)."""
+    if _state["precision"] != "fp8" or (_state["engine"] is not None and _state["engine_key"] == key):
+        return None
+    p = _state["params"]
+    return ops.preprocess(frames_u8, p.depth_resolution, _state["cfg"].patch, p.mean, p.std)
 
 
 def process(img_uint8, target_height: int) -> torch.Tensor:
@@ -169,7 +183,7 @@ def predict_depth(image_rgb, return_tuple=False, use_temporal_smooth: bool = Tru
         rgb_tensor = hwc.permute(2, 0, 1)
         src = hwc
     x = ops.preprocess(src, p.depth_resolution, _state["cfg"].patch if _state["cfg"] else 14, p.mean, p.std)
-    eng = _ensure_engine_built(x.shape[2], x.shape[3])
+    eng = _ensure_engine_built(x.shape[2], x.shape[3], x)
     depth = eng(x)
     depth = ops.post_process_depth(depth, p)[0]
     if use_temporal_smooth:
@@ -238,7 +252,7 @@ def pipeline(frames, display_mode=None, use_temporal_smooth=False, out_u8=True, 
     h, w, _s = engine_shape(H, W, p.depth_resolution, _state["cfg"].patch)
     if B > _state["max_batch"]:
         raise _lib.D2SError(f"batch {B} > configured max_batch {_state['max_batch']}")
-    eng = _ensure_engine_built(h, w)
+    eng = _ensure_engine_built(h, w, _fp8_first_inputs(t, (h, w)))
     sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, display_mode or p.display_mode, p.fill_16_9)
     return eng.pipeline(t, p, sp, use_ema=use_temporal_smooth, out_fmt=_lib.FMT_U8_HWC if out_u8 else _lib.FMT_F32_HWC,
                         want_depth=want_depth)
@@ -259,7 +273,7 @@ def pipeline_mixed(frames_list, display_mode=None, out_u8=True):
     h, w = shapes.pop()
     if len(ts) > _state["max_batch"]:
         raise _lib.D2SError(f"batch {len(ts)} > configured max_batch {_state['max_batch']}")
-    eng = _ensure_engine_built(h, w)
+    eng = _ensure_engine_built(h, w, _fp8_first_inputs(ts[0].unsqueeze(0), (h, w)))
     groups = {}
     for i, t in enumerate(ts):
         groups.setdefault(tuple(t.shape[:2]), []).append(i)

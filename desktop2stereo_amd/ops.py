@@ -215,9 +215,10 @@ class Engine:
         self.device = torch.device("cuda", device)
         desc = ModelDesc(cfg.hidden, cfg.heads, cfg.layers, (C.c_int32 * 4)(*cfg.out_indices), (C.c_int32 * 4)(*cfg.neck),
                          cfg.fusion, cfg.head_hidden, cfg.mlp, cfg.patch, cfg.pos_grid, cfg.ln_eps,
-                         PREC_BF16 if precision == "bf16" else PREC_FP32, int(bool(temporal)), float(max_depth))
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+                         {"bf16": PREC_BF16, "fp32": PREC_FP32, "fp8": _lib.PREC_FP8}.get(precision, -1), int(bool(temporal)),
+                         float(max_depth))
+        if precision not in ("bf16", "fp32", "fp8"):
+            raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
         self._h = C.c_void_p()
         check(self.lib.d2s_engine_create(C.byref(desc), device, C.byref(self._h)), "d2s_engine_create")
         for name, arr in weights.items():
@@ -243,6 +244,17 @@ class Engine:
         out = torch.empty((B, self.h, self.w), dtype=torch.float32, device=x.device)
         check(self.lib.d2s_model_forward(self._h, _ptr(x), _ptr(out), B, _stream()), "d2s_model_forward")
         return out
+
+    def calibrate(self, x: torch.Tensor):
+        """fp8 engines: set the static activation scales from one bf16 pass over calibration inputs x [B,3,h,w]
+        (normalised model inputs, e.g. ops.preprocess of representative frames).  Required before the first forward."""
+        _need_cuda(x, "calibration inputs")
+        x = x.to(torch.float32).contiguous()
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        if tuple(x.shape[1:]) != (3, self.h, self.w):
+            raise ValueError(f"engine was built for [B,3,{self.h},{self.w}], got {tuple(x.shape)}")
+        check(self.lib.d2s_engine_calibrate(self._h, _ptr(x), x.shape[0], _stream()), "d2s_engine_calibrate")
 
     def tap(self, name: str) -> torch.Tensor:
         rows, cols = C.c_int(), C.c_int()
@@ -307,6 +319,7 @@ def gemm_probe(A: torch.Tensor, Wt: torch.Tensor, bias: Optional[torch.Tensor], 
     N = Wt.shape[0]
     out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     check(_lib.load().d2s_gemm_probe(_ptr(A.contiguous()), _ptr(Wt.contiguous()), _ptr(bias) if bias is not None else None,
-                                     _ptr(out), M, N, K, PREC_BF16 if precision == "bf16" else PREC_FP32, tile, iters, _stream()),
+                                     _ptr(out), M, N, K, {"bf16": PREC_BF16, "fp32": PREC_FP32, "fp8": _lib.PREC_FP8}[precision], tile, iters,
+                                     _stream()),
           "d2s_gemm_probe")
     return out

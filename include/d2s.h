@@ -49,6 +49,9 @@ extern "C" {
 /* arithmetic of the model stage */
 #define D2S_PREC_FP32       0   /* f32 MFMA (v_mfma_f32_16x16x4_f32), fp32 activations: parity class */
 #define D2S_PREC_BF16       1   /* bf16 MFMA, fp32 accumulate / residual / softmax / LayerNorm */
+#define D2S_PREC_FP8        2   /* BASELINE config 3: the encoder's four linears per layer (75 % of the FLOPs) run on e4m3
+                                   operands (OCP e4m3fn; weights per-output-channel scales, activations static per-tensor
+                                   scales set by d2s_engine_calibrate), fp32 accumulate; everything else as D2S_PREC_BF16 */
 
 typedef struct d2s_engine d2s_engine;     /* opaque: weights + workspaces + per-stream state */
 
@@ -158,6 +161,13 @@ int d2s_preprocess(const void* frames, int fmt, int batch, int H, int W,
 /* A5-A9: model(pixel_values=x).predicted_depth  (reference depth.py:1763-1781 -> HF
  * DepthAnythingForDepthEstimation).  x: float [batch,3,h,w]; depth: float [batch,h,w]. */
 int d2s_model_forward(d2s_engine* e, const float* x, float* depth, int batch, void* stream);
+
+/* D2S_PREC_FP8 engines only: post-training calibration of the static per-tensor activation scales.  Runs one bf16
+ * forward over x (float [batch,3,h,w], the engine's input layout) recording max |activation| at the four e4m3
+ * quantisation sites of every encoder layer (LayerNorm-1 output, attention output, LayerNorm-2 output, GELU output),
+ * sets scale = amax / 448 and switches the engine's encoder linears to e4m3 operands.  Synchronous.  Forward calls
+ * before a successful calibration fail with D2S_E_STATE.  (No reference counterpart: the reference has FP16 only.) */
+int d2s_engine_calibrate(d2s_engine* e, const float* x, int batch, void* stream);
 
 /* A10-A11: post_process_depth = normalize -> gamma -> foreground_scale -> anti_alias
  * (reference depth.py:806-814), in place on float [batch,h,w].  Stateless. */
