@@ -619,6 +619,10 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
     hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG, KG>), dim3(grid), dim3(64 * WM * WN * KG), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn);
 }
 
+// when the 64 x 64 tile with 4 intra-block K groups replaces the 32 x 64 ring: batch-1 FC2 (156 tiles, 48 K tiles).
+// (Tried on the DPT 3x3 convs of the small maps, <= 160 tiles x 18 K tiles: 0.36 -> 0.41 ms per frame, not used.)
+static bool kg_rule(long b64, int K, int mode) { return mode == A_PLAIN && b64 <= 160 && b64 >= 128 && K >= 2048; }
+
 template <typename T>
 static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
     static const bool v1 = getenv("D2S_GEMM_V1") && atoi(getenv("D2S_GEMM_V1")) != 0;
@@ -638,7 +642,7 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
         else if (b64 >= 800) tile = 964128;
         else if (b64 >= 560) tile = 964;
         else if (b64 >= 384) tile = 64;
-        else if (b64 <= 160 && b64 >= 128 && K >= 2048 && a.mode == A_PLAIN) tile = 74964;   // batch-1 FC2: few tiles, 48 K tiles -> 4 K groups per block
+        else if (kg_rule(b64, K, a.mode)) tile = 74964;   // few tiles, long K loop -> 4 K groups per block
         else tile = 3264;                           // skinny launches (batch 1, N = 768): more, smaller blocks
     }
     if (v1 && (tile == 128 || tile == 64) && !std::is_same<T, fp8_t>::value) {
