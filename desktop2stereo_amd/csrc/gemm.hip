@@ -1,13 +1,16 @@
 // MFMA GEMM for gfx950: C[m,n] = epi(sum_k A[m,k] W[n,k]).
 //
-//  * operands bf16 (v_mfma_f32_16x16x32_bf16) or f32 (v_mfma_f32_16x16x4_f32, exact fp32), fp32 accumulate;
-//  * tile BM x BN x 128 bytes of K, 256 threads = 4 waves (2 x 2), wave tile (BM/2) x (BN/2);
+//  * operands bf16 (v_mfma_f32_16x16x32_bf16), e4m3 (v_mfma_f32_16x16x32_fp8_fp8) or f32 (v_mfma_f32_16x16x4_f32,
+//    exact fp32), fp32 accumulate;
+//  * tile BM x BN x 128 bytes of K, WM x WN waves; two data paths for the K tiles (gemm_glds_kernel): LDS-DMA into an
+//    NS-stage ring, or register staging into two LDS stages (STG) -- the tile rule in launch_t picks per launch;
+//    gemm_kernel below is the round-0 baseline kept behind D2S_GEMM_V1;
 //  * both operands are K-contiguous; a 16-byte chunk per lane is the unit everywhere:
-//      global -> registers (16 B/lane, 8 lanes cover one 128-B row = full cache lines)
-//      registers -> LDS with the chunk XOR-swizzle  phys = chunk ^ ((row >> 1) & 7)
+//      global -> LDS (16 B/lane, 8 lanes cover one 128-B row = full cache lines), chunk XOR-swizzle
+//      phys = chunk ^ ((row >> 1) & 7), applied on the source address for LDS-DMA
 //      LDS -> fragments with ds_read_b128 at (row = lane & 15, chunk = kstep*4 + (lane >> 4)),
-//    conflict-free for 128-byte rows.  One chunk feeds one bf16 MFMA (K=32 across the 4 lane groups)
-//    or four f32 MFMAs (the k permutation is the same for both operands, so the sum is unchanged);
+//    conflict-free for 128-byte rows.  One chunk feeds one bf16 MFMA (K=32 across the 4 lane groups), two e4m3
+//    MFMAs or four f32 MFMAs (the k permutation is the same for both operands, so the sum is unchanged);
 //  * operands are swapped (first = W rows, second = A rows) so each lane ends up with 4 consecutive
 //    n for one m: bias / LayerScale / residual / output move as 8- or 16-byte vectors;
 //  * the A loader is either a plain row-major matrix or an implicit 3x3 (pad 1, stride 1|2)
@@ -337,33 +340,26 @@ template <int CPR> __device__ __forceinline__ int swz_row(int r) { return CPR ==
 // -- are written to the stage compute(t-1) just released, the loads of tile t+2 are issued, then tile t is computed.
 // Measured on this chip (tools/ubench/l2_to_lds): L2-resident data reaches LDS at ~27 TB/s through VGPRs vs
 // ~13-16 TB/s by LDS-DMA, and the freed LDS (2 stages instead of 3) admits the 256 x 256 tile.
-//
-// KG > 1: intra-block split-K for the launches with too few tiles to fill the chip (batch 1: 300-470 blocks of 4
-// waves on 256 CUs).  The block holds KG independent wave groups of WM x WN waves; group g runs the whole pipeline
-// (its own LDS ring, its own loads) over K tiles g, g+KG, ... of the SAME output tile, all groups meet at the same
-// barriers, and the groups' accumulators are summed through LDS before the (single) epilogue.  KG x the waves and
-// loads in flight per CU without more blocks, no partials in HBM, no second launch.
-template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, int STG = 0, int KG = 1>
-__global__ void __launch_bounds__(64 * WM * WN * KG)
+// (An intra-block split-K variant -- several wave groups per block, each running the pipeline over every KG-th K tile,
+// accumulators summed through LDS -- was built and swept at batch 1: the batch-1 launches are L2->LDS-bandwidth-bound
+// (~10 TB/s aggregate), not latency-bound; it won 9 % on FC2 in isolation and lost 2 % in the pipeline.  Removed.)
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, int STG = 0>
+__global__ void __launch_bounds__(64 * WM * WN)
 gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
     static_assert(STG == 0 || (STG == 1 && NS == 2), "the register-staged variant uses two LDS stages");
     constexpr int CE = Prec<T>::CE;
     constexpr int BK = CPR * CE;                    // K tile: CPR 16-byte chunks per row (8 -> 128 B, 16 -> 256 B)
     constexpr int RPI = 64 / CPR;                   // rows covered by one 1-KiB LDS-DMA wave-instruction
-    constexpr int NW = WM * WN;                     // waves per group
+    constexpr int NW = WM * WN;                     // waves per block
     constexpr int AI = BM / (RPI * NW), BI = BN / (RPI * NW);   // LDS-DMA instructions per thread per tile (A / W)
     constexpr int LPT = AI + BI;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;   // 16x16 fragments per wave
     constexpr int PD = NS - 1;
     constexpr int STAGE = (BM + BN) * CPR;          // chunks per stage
-    static_assert(KG == 1 || (KG - 1) * NW * FM * FN * 64 <= KG * NS * STAGE, "reduction scratch must fit in the rings");
-    __shared__ __attribute__((aligned(16))) u32x4 lds_all[KG * NS * STAGE];
+    __shared__ __attribute__((aligned(16))) u32x4 lds[NS * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = KG == 1 ? 0 : wid_all / NW;     // K group of this wave
-    const int wid = KG == 1 ? wid_all : wid_all % NW;
-    u32x4* const lds = lds_all + grp * (NS * STAGE);
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wid / WN, wave_n = wid % WN;
     int tm_, tn_;
     if (!tile_of_block(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, xn, tm_, tn_)) return;
@@ -405,7 +401,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
 #define D2S_ISSUE_TILE(KT, S)                                                                                    \
     {                                                                                                            \
         u32x4* st_ = lds + ((KT) % NS) * STAGE;                                                                  \
-        const int k_ = ((KT) * KG + grp + kt0) * BK + src_chunk * CE;                                            \
+        const int k_ = ((KT) + kt0) * BK + src_chunk * CE;                                                       \
         if (a.mode == A_PLAIN) {                                                                                 \
             _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                     \
                 const T* s_ = (aok[i] && k_ < K) ? arow[i] + k_ : zero;                                          \
@@ -423,7 +419,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
             }                                                                                                    \
         }                                                                                                        \
         _Pragma("unroll") for (int i = 0; i < BI; ++i)                                                           \
-            D2S_MOVE(S, AI + i, wrow + (long)(RPI * NW * i) * Kpad + ((KT) * KG + grp + kt0) * BK, st_ + BM * CPR + (i * NW + wid) * 64); \
+            D2S_MOVE(S, AI + i, wrow + (long)(RPI * NW * i) * Kpad + ((KT) + kt0) * BK, st_ + BM * CPR + (i * NW + wid) * 64); \
     }
     // staging registers -> LDS, the same lane-linear slots the LDS-DMA path fills
 #define D2S_STORE_STG(KT, S)                                                                                     \
@@ -443,9 +439,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     const int nkt_all = (K + BK - 1) / BK;
     const int ksplit = e.ksplit > 1 ? e.ksplit : 1;
     const int kt0 = (int)(((long)nkt_all * blockIdx.y) / ksplit);
-    const int nkt_blk = (int)(((long)nkt_all * (blockIdx.y + 1)) / ksplit) - kt0;
-    const int nkt = KG == 1 ? nkt_blk : (nkt_blk > grp ? (nkt_blk - grp + KG - 1) / KG : 0);   // K tiles of this group
-    const int nit = KG == 1 ? nkt_blk : (nkt_blk + KG - 1) / KG;                               // barrier count, same for all groups
+    const int nkt = (int)(((long)nkt_all * (blockIdx.y + 1)) / ksplit) - kt0;
     const int fr = lane & 15, fg = lane >> 4;
     const int relu_floor = a.relu ? 0 : -32768;
 #define D2S_COMPUTE(KT)                                                                                          \
@@ -470,49 +464,29 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     if constexpr (STG == 1) {
         if (nkt > 0) { D2S_ISSUE_TILE(0, 0) D2S_STORE_STG(0, 0) }
         if (nkt > 1) D2S_ISSUE_TILE(1, 0)
-        for (int kt = 0; kt < nit; ++kt) {
+        for (int kt = 0; kt < nkt; ++kt) {
             __syncthreads();                                   // tile kt visible, stage (kt+1)&1 released, my loads of kt+1 landed
             if (kt + 1 < nkt) D2S_STORE_STG(kt + 1, 0)
             if (kt + 2 < nkt) D2S_ISSUE_TILE(kt + 2, 0)
-            if (KG == 1 || kt < nkt) D2S_COMPUTE(kt)
+            D2S_COMPUTE(kt)
         }
     } else {
 #pragma unroll
         for (int t = 0; t < PD; ++t)
             if (t < nkt) D2S_ISSUE_TILE(t, 0)
-        for (int kt = 0; kt < nit; ++kt) {
+        for (int kt = 0; kt < nkt; ++kt) {
             // tiles kt .. min(kt+PD-1, nkt-1) are in flight; let all but tile kt stay in flight
             if (kt + PD - 1 < nkt) wait_vmcnt<(PD - 1) * LPT>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (kt + PD < nkt) D2S_ISSUE_TILE(kt + PD, 0)
-            if (KG == 1 || kt < nkt) D2S_COMPUTE(kt)
+            D2S_COMPUTE(kt)
         }
     }
 #undef D2S_COMPUTE
 #undef D2S_ISSUE_TILE
 #undef D2S_STORE_STG
 #undef D2S_MOVE
-
-    if constexpr (KG > 1) {
-        // sum the groups' accumulators through LDS (the rings are free after the barrier); group 0 runs the epilogue
-        f32x4* red = (f32x4*)lds_all;
-        __syncthreads();
-        if (grp > 0) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) red[(((grp - 1) * NW + wid) * (FM * FN) + i * FN + j) * 64 + lane] = acc[i][j];
-        }
-        __syncthreads();
-        if (grp > 0) return;
-#pragma unroll
-        for (int g = 0; g < KG - 1; ++g)
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] += red[((g * NW + wid) * (FM * FN) + i * FN + j) * 64 + lane];
-    }
 
     // MAP_HEAD: the DPT head's tail fused into conv2 -- depth[m] = relu(b3 + sum_n w3[n] * relu(acc[m][n] + bias[n]))
     // (HF DepthAnythingDepthEstimationHead: conv2 -> ReLU -> conv3 (1x1, C->1) -> ReLU).  One wave owns all N
@@ -597,7 +571,7 @@ static int pick_xn(int tiles_m, int tiles_n, int BN, int Kpad, size_t es, unsign
 }
 
 // tile codes: 64 (64x64), 128 (128x128), 256128 / 256256 (8 waves), 25664 / 25632 (256 x 64|32, 4 waves); 0 = auto
-template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR = 8, int STG = 0, int KG = 1>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR = 8, int STG = 0>
 static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
     unsigned grid = 0;
     int xn = pick_xn(cdiv(M, BM), cdiv(N, BN), BN, Kpad, sizeof(T), grid);
@@ -611,17 +585,13 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
     }
     if (ks > 1) {
         GemmEpi e2 = e; e2.ksplit = ks;
-        hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG, KG>), dim3(grid, ks), dim3(64 * WM * WN * KG), 0, st, a, (const T*)W, M, N, K, Kpad, e2, xn);
+        hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid, ks), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e2, xn);
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(cdiv((long)M * (N / 4), 256)), dim3(256), 0, st, e2, M, N);
         return;
     }
     GemmEpi e1 = e; e1.ksplit = 1;
-    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG, KG>), dim3(grid), dim3(64 * WM * WN * KG), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn);
 }
-
-// when the 64 x 64 tile with 4 intra-block K groups replaces the 32 x 64 ring: batch-1 FC2 (156 tiles, 48 K tiles).
-// (Tried on the DPT 3x3 convs of the small maps, <= 160 tiles x 18 K tiles: 0.36 -> 0.41 ms per frame, not used.)
-static bool kg_rule(long b64, int K, int mode) { return mode == A_PLAIN && b64 <= 160 && b64 >= 128 && K >= 2048; }
 
 template <typename T>
 static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
@@ -642,7 +612,6 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
         else if (b64 >= 800) tile = 964128;
         else if (b64 >= 560) tile = 964;
         else if (b64 >= 384) tile = 64;
-        else if (kg_rule(b64, K, a.mode)) tile = 74964;   // few tiles, long K loop -> 4 K groups per block
         else tile = 3264;                           // skinny launches (batch 1, N = 768): more, smaller blocks
     }
     if (v1 && (tile == 128 || tile == 64) && !std::is_same<T, fp8_t>::value) {
@@ -670,10 +639,6 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     else if (tile == 912832) launch_glds<T, 128, 32, 4, 1, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);       // WN == 1: MAP_HEAD capable
     else if (tile == 9256648) launch_glds<T, 256, 64, 8, 1, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);      // WN == 1, 8 waves
     else if (tile == 925625616) launch_glds<T, 256, 256, 4, 4, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);   // 16 waves (batch >= 32 shapes)
-    // intra-block split-K (KG wave groups per block), code = 7 <KG> <tile>.  Swept at batch 1-2 over 32 x 64 / 64 x 64,
-    // LDS-DMA / staged, KG 2 / 4: the batch-1 launches turned out L2->LDS-bandwidth-bound (~10 TB/s aggregate), not
-    // latency-bound, so only the longest K loop gains (FC2 at batch 1: 18.4 -> 16.8 us)
-    else if (tile == 74964) launch_glds<T, 64, 64, 2, 2, 2, 8, 1, 4>(a, W, M, N, K, Kpad, e, st);
     else { set_error("launch_gemm: bad tile code"); return D2S_E_INVALID; }
     D2S_CHECK_LAUNCH();
     return D2S_OK;
