@@ -59,7 +59,20 @@ def cpu_baseline(cfg, weights, p, H, W, mode, budget_s=15.0, max_frames=3):
             "host_cpus": os.cpu_count()}
 
 
-def profile_pass(eng, step, steps, B, precision):
+def pmc_traffic(kernel_class, B, default_workload):
+    """HBM-side bytes per launch from the committed PMC profile (FETCH_SIZE / WRITE_SIZE are collected in separate
+    rocprofv3 --pmc passes, profiles/r1_07_gemm_pmc.md -- they cannot be read inside this process); only for the
+    workload the profile was taken on (ViT-B bf16, Depth Resolution 518, batch 1 / 16), else None."""
+    if not default_workload or kernel_class != "gemm_linear":
+        return None
+    try:
+        with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["gemm_linear_traffic_bytes_per_launch"].get(str(B))
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def profile_pass(eng, step, steps, B, precision, default_workload=False):
     """Second pass with HIP events around every kernel launch -> per-class table + roofline objects."""
     import torch
     eng.profile(True)
@@ -88,7 +101,7 @@ def profile_pass(eng, step, steps, B, precision):
     kd = kernels[dom]
     if "tflops" in kd:
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kd["tflops"], "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
-                           "frac": kd["frac_of_mfma_peak"], "traffic": None,
+                           "frac": kd["frac_of_mfma_peak"], "traffic": pmc_traffic(dom, B, default_workload),
                            "flop_per_launch": 1e9 * kd["gflop_per_frame"] * B / kd["launches_per_step"], "avg_launch_us": kd["avg_launch_us"]}
     else:
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kd.get("gbs"), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -158,6 +171,7 @@ def main():
     else:
         weights = make_weights(cfg, 0)
     eng = ops.Engine(cfg, weights, h, w, max_batch=max(B, B2), precision=args.precision, device=local_rank, temporal=args.vda)
+    default_wl = (args.model, args.precision, args.res, H, W, args.vda) == ("vitb", "bf16", 518, 1080, 1920, False)
     if args.precision == "fp8":     # static activation scales from two structured frames (outside the timed region)
         eng.calibrate(torch.cat([ops.preprocess(torch.from_numpy(synth.structured_frame(H, W, s)).to(dev), args.res) for s in (0, 1)][:max(B, B2)]))
     sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, args.mode, p.fill_16_9)
@@ -215,7 +229,7 @@ def main():
         args.no_cpu_baseline = True                      # the CPU leg times the DA-v2 oracle only
 
     if rank == 0 and not args.no_profile:
-        result.update(profile_pass(eng, step, args.profile_steps, B, args.precision))
+        result.update(profile_pass(eng, step, args.profile_steps, B, args.precision, default_wl))
         result["model_gflop_per_frame"] = {"counted": result.pop("model_gflop_per_frame_counted"),
                                            "survey": SURVEY_GF_PER_FRAME.get((args.model, args.res))}
         result["model_stage_tflops_at_measured_fps"] = value / world * result["model_gflop_per_frame"]["counted"] / 1e3
@@ -227,7 +241,7 @@ def main():
         batched = {"value": steps2 * B2 / dt2, "unit": "stereo frames/s", "frames_per_step": B2, "steps": steps2,
                    "ms_per_step": 1e3 * dt2 / steps2, "workload": workload(B2)}
         if not args.no_profile:
-            pr = profile_pass(eng, step2, 3, B2, args.precision)
+            pr = profile_pass(eng, step2, 3, B2, args.precision, default_wl)
             pr.pop("model_gflop_per_frame_counted", None)
             batched.update(pr)
         result["batched"] = batched
