@@ -274,7 +274,11 @@ GemmA convA(const void* p, int Hi, int Wi, int C, int Ho, int Wo, int stride, in
     GemmA a = {}; a.ptr = p; a.mode = A_CONV3; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.relu = relu; return a;
 }
 // tile of the fused head launch: MAP_HEAD needs a tile whose waves own all N columns of their rows (WN == 1)
-int head_tile(int bn) { return bn == 32 ? 912832 : 9256648; }
+int head_tile(int bn) {
+    static const int t32 = getenv("D2S_HEAD_T32") ? atoi(getenv("D2S_HEAD_T32")) : 0;      // tuning aid
+    static const int t64 = getenv("D2S_HEAD_T64") ? atoi(getenv("D2S_HEAD_T64")) : 0;
+    return bn == 32 ? (t32 ? t32 : 912832) : (t64 ? t64 : 9256648);
+}
 
 GemmEpi rowsE(void* out, int out_type, long ldc, const float* bias) {
     GemmEpi e = {}; e.out = out; e.out_type = out_type; e.ldc = ldc; e.bias = bias; return e;

@@ -332,7 +332,8 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // chunk XOR for a row of CPR chunks: conflict-free ds_read_b128 for 128-byte (CPR 8) and 256-byte (CPR 16) rows
-template <int CPR> __device__ __forceinline__ int swz_row(int r) { return CPR == 8 ? ((r >> 1) & 7) : (r & 15); }
+// (64-byte rows, CPR 4: rows r and r+2 share banks -> XOR by (r >> 1) & 3)
+template <int CPR> __device__ __forceinline__ int swz_row(int r) { return CPR == 8 ? ((r >> 1) & 7) : (CPR == 4 ? ((r >> 1) & 3) : (r & 15)); }
 
 // STG = true: register-staged variant of the same tile.  The K tile travels global -> VGPRs (global_load_dwordx4)
 // -> LDS (ds_write_b128, same lane-linear slots as the LDS-DMA path, so fragment reads are unchanged) with TWO LDS
@@ -441,8 +442,9 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     const int kt0 = (int)(((long)nkt_all * blockIdx.y) / ksplit);
     const int nkt = (int)(((long)nkt_all * (blockIdx.y + 1)) / ksplit) - kt0;
     const int fr = lane & 15, fg = lane >> 4;
-    const int relu_floor = a.relu ? 0 : -32768;
-#define D2S_COMPUTE(KT)                                                                                          \
+    // RELU is a literal: the K loop exists twice (with / without ReLU-on-load) so that plain linears do not pay
+    // 4 v_pk_max per A fragment (a third of the loop's VALU work) for an identity
+#define D2S_COMPUTE(KT, RELU)                                                                                    \
     {                                                                                                            \
         const u32x4* A_l = lds + ((KT) % NS) * STAGE + (wave_m * (BM / WM)) * CPR;                               \
         const u32x4* B_l = lds + ((KT) % NS) * STAGE + BM * CPR + (wave_n * (BN / WN)) * CPR;                    \
@@ -456,33 +458,39 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
             _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                                     \
                 int r = i * 16 + fr;                                                                             \
                 u32x4 fa = A_l[r * CPR + ((ks * 4 + fg) ^ swz_row<CPR>(r))];                                     \
-                fa = relu_frag(fa, relu_floor, T());     /* branch-free: floor = 0 (ReLU) or lowest (identity) */ \
+                if (RELU) fa = relu_frag(fa, 0, T());                                                            \
                 _Pragma("unroll") for (int j = 0; j < FN; ++j) mma_chunk(acc[i][j], fb[j], fa, T());             \
             }                                                                                                    \
+        }                                                                                                        \
+    }
+#define D2S_K_LOOP(RELU)                                                                                         \
+    if constexpr (STG == 1) {                                                                                    \
+        for (int kt = 0; kt < nkt; ++kt) {                                                                       \
+            __syncthreads();       /* tile kt visible, stage (kt+1)&1 released, my loads of kt+1 landed */        \
+            if (kt + 1 < nkt) D2S_STORE_STG(kt + 1, 0)                                                           \
+            if (kt + 2 < nkt) D2S_ISSUE_TILE(kt + 2, 0)                                                          \
+            D2S_COMPUTE(kt, RELU)                                                                                \
+        }                                                                                                        \
+    } else {                                                                                                     \
+        for (int kt = 0; kt < nkt; ++kt) {                                                                       \
+            /* tiles kt .. min(kt+PD-1, nkt-1) are in flight; let all but tile kt stay in flight */              \
+            if (kt + PD - 1 < nkt) wait_vmcnt<(PD - 1) * LPT>();                                                 \
+            else wait_vmcnt<0>();                                                                                \
+            __builtin_amdgcn_s_barrier();                                                                        \
+            if (kt + PD < nkt) D2S_ISSUE_TILE(kt + PD, 0)                                                        \
+            D2S_COMPUTE(kt, RELU)                                                                                \
         }                                                                                                        \
     }
     if constexpr (STG == 1) {
         if (nkt > 0) { D2S_ISSUE_TILE(0, 0) D2S_STORE_STG(0, 0) }
         if (nkt > 1) D2S_ISSUE_TILE(1, 0)
-        for (int kt = 0; kt < nkt; ++kt) {
-            __syncthreads();                                   // tile kt visible, stage (kt+1)&1 released, my loads of kt+1 landed
-            if (kt + 1 < nkt) D2S_STORE_STG(kt + 1, 0)
-            if (kt + 2 < nkt) D2S_ISSUE_TILE(kt + 2, 0)
-            D2S_COMPUTE(kt)
-        }
     } else {
 #pragma unroll
         for (int t = 0; t < PD; ++t)
             if (t < nkt) D2S_ISSUE_TILE(t, 0)
-        for (int kt = 0; kt < nkt; ++kt) {
-            // tiles kt .. min(kt+PD-1, nkt-1) are in flight; let all but tile kt stay in flight
-            if (kt + PD - 1 < nkt) wait_vmcnt<(PD - 1) * LPT>();
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (kt + PD < nkt) D2S_ISSUE_TILE(kt + PD, 0)
-            D2S_COMPUTE(kt)
-        }
     }
+    if (a.relu) { D2S_K_LOOP(1) } else { D2S_K_LOOP(0) }
+#undef D2S_K_LOOP
 #undef D2S_COMPUTE
 #undef D2S_ISSUE_TILE
 #undef D2S_STORE_STG
@@ -599,19 +607,20 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     static const int force_tile = getenv("D2S_GEMM_TILE") ? atoi(getenv("D2S_GEMM_TILE")) : 0;
     if (tile == 0) tile = force_tile;
     if (tile == 0) {
-        // Measured on the ViT-B shapes at batch 1..32 (tools/gemm_bench.py, profiles/r1_05): what matters most is ~16
-        // resident waves per CU in DIFFERENT phases of the K loop, then tile intensity.  128 x 128 with 8 waves
-        // (2 blocks / CU, register-staged) wins once it fills the chip; below that, smaller staged tiles, and the
-        // LDS-DMA ring (deeper prefetch, shorter prologue) for the launches with the fewest blocks.
-        const long b128 = (long)cdiv(M, 128) * cdiv(N, 128), b64 = (long)cdiv(M, 64) * cdiv(N, 64);
+        // Measured on the ViT-B shapes at batch 1..32 (tools/gemm_bench.py, profiles/r1_05): what matters most is 16-24
+        // resident waves per CU in DIFFERENT phases of the K loop (8-wave blocks, 2-5 blocks per CU), then tile intensity;
+        // with that in place the LDS-DMA path beats register staging (no VGPR / ds_write pass).  The 4-wave 32 x 64 ring
+        // (NS = 4: deepest prefetch, shortest prologue) keeps the launches with the fewest tiles (batch 1: proj, FC2).
+        static const int t64 = getenv("D2S_GEMM_T64") ? atoi(getenv("D2S_GEMM_T64")) : 0;    // tuning: N <= 64 tiles
+        static const int t32 = getenv("D2S_GEMM_T32") ? atoi(getenv("D2S_GEMM_T32")) : 0;
+        const long b128 = (long)cdiv(M, 128) * cdiv(N, 128), b64128 = (long)cdiv(M, 64) * cdiv(N, 128), b64 = (long)cdiv(M, 64) * cdiv(N, 64);
         if (N <= 64) {                              // DPT head: 64 / 32 output channels, M = pixels
-            if ((long)cdiv(M, 256) >= 224) tile = N <= 32 ? 912832 : 9256648;
+            if ((long)cdiv(M, 256) >= 224) tile = N <= 32 ? (t32 ? t32 : 912832) : (t64 ? t64 : 9256648);
             else tile = 3264;
         }
-        else if (b128 >= 280) tile = 91288;
-        else if (b64 >= 800) tile = 964128;
-        else if (b64 >= 560) tile = 964;
-        else if (b64 >= 384) tile = 64;
+        else if (b128 >= 400 && (N >= 1536 || b128 >= 900)) tile = 1281288;
+        else if (b64128 >= 280) tile = 641288;
+        else if (b64 >= 384) tile = 64648;
         else tile = 3264;                           // skinny launches (batch 1, N = 768): more, smaller blocks
     }
     if (v1 && (tile == 128 || tile == 64) && !std::is_same<T, fp8_t>::value) {
@@ -625,20 +634,22 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     }
     // LDS-DMA ring (NS stages)
     else if (tile == 256128) launch_glds<T, 256, 128, 4, 2, 3>(a, W, M, N, K, Kpad, e, st);
-    else if (tile == 25664) launch_glds<T, 256, 64, 4, 1, 3>(a, W, M, N, K, Kpad, e, st);
-    else if (tile == 25632) launch_glds<T, 256, 32, 4, 1, 3>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 128) launch_glds<T, 128, 128, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 64) launch_glds<T, 64, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 3264) launch_glds<T, 32, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
-    // register-staged variants (STG), code = 9 <BM> <BN> [waves]; the losers of the round-1 sweep (256 x 128 / 256 x 256
-    // with 8 waves, 128 x 128 with 4 or 16 waves, deeper rings, 256-byte K tiles, two register sets) were removed
+    // LDS-DMA, 8 waves, two stages: the winners of the second sweep (profiles/r1_05), code <BM><BN>8
+    else if (tile == 1281288) launch_glds<T, 128, 128, 2, 4, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);    // wave tile 64 x 32, 2 blocks / CU
+    else if (tile == 641288) launch_glds<T, 64, 128, 2, 4, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);      // 3 blocks / CU
+    else if (tile == 64648) launch_glds<T, 64, 64, 4, 2, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);        // 5 blocks / CU
+    else if (tile == 256648) launch_glds<T, 256, 64, 8, 1, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);      // WN == 1: MAP_HEAD capable
+    else if (tile == 128324) launch_glds<T, 128, 32, 4, 1, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);      // WN == 1, 4 waves
+    // register-staged variants (STG), code = 9 <BM> <BN> [waves].  Removed after losing the sweeps: 256 x 128 / 256 x 256
+    // with 8 waves (1 block / CU, lock-step), 128 x 128 with 4 or 16 waves, deeper rings, 64- and 256-byte K tiles, two
+    // register sets, intra-block split-K
     else if (tile == 964) launch_glds<T, 64, 64, 2, 2, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);
-    else if (tile == 93264) launch_glds<T, 32, 64, 2, 2, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);
-    else if (tile == 964128) launch_glds<T, 64, 128, 2, 2, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 91288) launch_glds<T, 128, 128, 4, 2, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);       // 8 waves, 2 blocks / CU
     else if (tile == 912832) launch_glds<T, 128, 32, 4, 1, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);       // WN == 1: MAP_HEAD capable
     else if (tile == 9256648) launch_glds<T, 256, 64, 8, 1, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);      // WN == 1, 8 waves
-    else if (tile == 925625616) launch_glds<T, 256, 256, 4, 4, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);   // 16 waves (batch >= 32 shapes)
     else { set_error("launch_gemm: bad tile code"); return D2S_E_INVALID; }
     D2S_CHECK_LAUNCH();
     return D2S_OK;

@@ -12,7 +12,7 @@ def t_probe(A, W, prec, tile, iters):
     torch.cuda.synchronize(); return time.perf_counter() - t0
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, nargs="+", default=[1, 16]); ap.add_argument("--prec", default="bf16")
-ap.add_argument("--tiles", type=int, nargs="+", default=[3264, 64, 256128, 964, 93264, 964128, 91288, 925625616])
+ap.add_argument("--tiles", type=int, nargs="+", default=[0, 3264, 64, 64648, 641288, 1281288, 91288, 256128])
 a = ap.parse_args()
 dev = torch.device("cuda")
 shapes = [("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]
