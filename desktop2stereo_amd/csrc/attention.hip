@@ -88,19 +88,23 @@ __device__ __forceinline__ void store_o4(fp8_t* p, const float v[4]) {     // va
 __device__ u32x4 d2s_attn_zero_page[4];
 
 // OT: output element type (T, or e4m3 when the output projection runs on fp8 operands: out = sat(result * oscale))
-template <typename T, int QF, int NW, int NS = 3, typename OT = T>
-__global__ void __launch_bounds__(64 * NW)
+// KS > 1 (batch 1: 156 blocks of 4 waves leave the chip empty and each walks 13 key tiles in sequence): KS wave groups
+// per block share the q tile and split the KEY range; each group runs the whole pipeline over its keys with its own LDS
+// ring, and the groups' (max, sum, O) are merged through LDS at the end (flash-decoding style).
+template <typename T, int QF, int NW, int NS = 3, typename OT = T, int KS = 1>
+__global__ void __launch_bounds__(64 * NW * KS)
 attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, OT* __restrict__ out,
                  int N, int Npad, int heads, float scale_log2e, float oscale) {
     using A = AT<T>;
     constexpr int CE = A::CE, CPR = A::CPR, NKS = A::NKS;
     constexpr int TILE_CHUNKS = 64 * CPR;              // chunks in one 64-row tile
-    constexpr int NT = 64 * NW;                        // threads per block
     constexpr int BQ = NW * QF * 16;
     constexpr int PD = NS - 1;                         // NS LDS ring stages, prefetch distance PD
-    __shared__ __attribute__((aligned(16))) u32x4 lds[NS * 2 * TILE_CHUNKS];   // [stage][K | V^T]
+    __shared__ __attribute__((aligned(16))) u32x4 lds_all[KS * NS * 2 * TILE_CHUNKS];   // [group][stage][K | V^T]
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid_all = tid >> 6, grp = KS == 1 ? 0 : wid_all / NW, wid = KS == 1 ? wid_all : wid_all % NW;
+    u32x4* const lds = lds_all + grp * (NS * 2 * TILE_CHUNKS);
     const int fr = lane & 15, fg = lane >> 4;
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int D = heads * 64;
@@ -144,23 +148,27 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, OT* __rest
         u32x4* st_ = lds + ((TT) % NS) * 2 * TILE_CHUNKS;                                              \
         _Pragma("unroll") for (int i = 0; i < IPW; ++i) {                                              \
             const int r_ = (i * NW + wu) * RPI + lane / CPR, p_ = lane % CPR;                          \
-            const int key_ = (TT) * 64 + r_;                                                           \
+            const int key_ = ((TT) + t0) * 64 + r_;                                                    \
             const T* ks_ = key_ < N ? kbase + (long)key_ * row3 + (p_ ^ A::swzK(r_)) * CE : zero;      \
             ATT_GLDS(ks_, st_ + (i * NW + wu) * 64);                                                   \
-            ATT_GLDS(vbase + (long)r_ * Npad + (TT) * 64 + (p_ ^ A::swzV(r_)) * CE, st_ + TILE_CHUNKS + (i * NW + wu) * 64); \
+            ATT_GLDS(vbase + (long)r_ * Npad + ((TT) + t0) * 64 + (p_ ^ A::swzV(r_)) * CE, st_ + TILE_CHUNKS + (i * NW + wu) * 64); \
         }                                                                                              \
     }
     constexpr int LPTA = 2 * IPW;                       // LDS-DMA instructions per thread per tile
 
-    const int ntiles = (N + 63) / 64;
+    const int ntiles_all = (N + 63) / 64;
+    const int t0 = KS == 1 ? 0 : (ntiles_all * grp) / KS;                      // this group's key tiles [t0, t0 + ntiles)
+    const int ntiles = KS == 1 ? ntiles_all : (ntiles_all * (grp + 1)) / KS - t0;
+    const int nit = KS == 1 ? ntiles_all : (ntiles_all + KS - 1) / KS;          // barrier count, the same for every group
 #pragma unroll
     for (int t = 0; t < PD; ++t)
         if (t < ntiles) ATT_ISSUE(t)
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = 0; t < nit; ++t) {
         if (t + PD - 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPTA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (t + PD < ntiles) ATT_ISSUE(t + PD)
+        if (KS > 1 && t >= ntiles) continue;
         const u32x4* Kl = lds + (t % NS) * 2 * TILE_CHUNKS;
         const u32x4* Vl = Kl + TILE_CHUNKS;
         // ---- S^T = K Q^T
@@ -180,12 +188,12 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, OT* __rest
             }
         }
         // ---- mask the ragged last tile: key of register r in fragment j = key_of(j, fg*4 + r)
-        if (t == ntiles - 1 && (N & 63)) {
+        if (t + t0 == ntiles_all - 1 && (N & 63)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (t * 64 + A::key_of(j, fg * 4 + r) >= N) {
+                    if ((t + t0) * 64 + A::key_of(j, fg * 4 + r) >= N) {
 #pragma unroll
                         for (int f = 0; f < QF; ++f) s[f][j][r] = -1e30f;
                     }
@@ -243,6 +251,45 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, OT* __rest
     }
 #undef ATT_ISSUE
 #undef ATT_GLDS
+    if constexpr (KS > 1) {
+        // merge the key groups: (m, l, O) of groups 1.. go through LDS (the rings are free after the barrier); group 0
+        // rescales to the common maximum and finishes.  m is uniform per query column, l is a per-lane partial, both
+        // combine linearly after the exp2 rescale.
+        constexpr int PER = QF * 18;                            // floats per lane: QF x (16 O + m + l)
+        static_assert((KS - 1) * NW * 64 * PER * 4 <= KS * NS * 2 * TILE_CHUNKS * 16, "merge scratch must fit in the rings");
+        float* red = (float*)lds_all;
+        __syncthreads();
+        if (grp > 0) {
+            float* p = red + ((long)((grp - 1) * NW + wid) * PER) * 64 + lane;
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[((f * 18) + d * 4 + r) * 64] = o[f][d][r];
+                p[(f * 18 + 16) * 64] = m_run[f];
+                p[(f * 18 + 17) * 64] = l_run[f];
+            }
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 0; g < KS - 1; ++g) {
+            const float* p = red + ((long)(g * NW + wid) * PER) * 64 + lane;
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                const float m1 = p[(f * 18 + 16) * 64], l1 = p[(f * 18 + 17) * 64];
+                const float m = fmaxf(m_run[f], m1);
+                const float a0 = __builtin_amdgcn_exp2f((m_run[f] - m) * scale_log2e), a1 = __builtin_amdgcn_exp2f((m1 - m) * scale_log2e);
+                m_run[f] = m;
+                l_run[f] = l_run[f] * a0 + l1 * a1;
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[f][d][r] = o[f][d][r] * a0 + p[((f * 18) + d * 4 + r) * 64] * a1;
+            }
+        }
+    }
     // ---- normalise and store: lane holds d = dfrag*16 + fg*4 + r for query fr
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
@@ -275,11 +322,24 @@ int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B
         (const TT*)qkv, (const TT*)vt, (TT*)out, N, Npad, heads, scale_log2e, 1.0f)
 #define D2S_ATT8(QF_, NW_) hipLaunchKernelGGL((attention_kernel<bf16_t, QF_, NW_, 3, fp8_t>), dim3(cdiv(N, NW_ * QF_ * 16), heads, B), dim3(64 * NW_), 0, st, \
         (const bf16_t*)qkv, (const bf16_t*)vt, (fp8_t*)out, N, Npad, heads, scale_log2e, fp8_qscale)
+    // too few (q-tile, head) blocks to fill 256 CUs (batch 1: 156): split the keys over 2 / 4 wave groups per block
+    // (batch 1, N = 778: 18.9 us -> 13.8 us with 2 groups, 13.2 us with 4)
+    static const int force_ks = getenv("D2S_ATTN_KS") ? atoi(getenv("D2S_ATTN_KS")) : 0;
+    const int ks = force_ks ? force_ks : (bq == 64 && (long)cdiv(N, 64) * hb < 256 ? (N >= 512 ? 4 : (N >= 256 ? 2 : 1)) : 1);
     if (fp8_qscale > 0.f) {
         if (bq == 128) D2S_ATT8(1, 8);
+        else if (ks >= 2)
+            hipLaunchKernelGGL((attention_kernel<bf16_t, 1, 4, 2, fp8_t, 4>), dim3(cdiv(N, 64), heads, B), dim3(1024), 0, st,
+                               (const bf16_t*)qkv, (const bf16_t*)vt, (fp8_t*)out, N, Npad, heads, scale_log2e, fp8_qscale);
         else D2S_ATT8(1, 4);
     } else if (prec == D2S_PREC_BF16) {
-        if (bq == 128) D2S_ATT(bf16_t, 1, 8);
+        if (bq == 64 && ks == 2)
+            hipLaunchKernelGGL((attention_kernel<bf16_t, 1, 4, 3, bf16_t, 2>), dim3(cdiv(N, 64), heads, B), dim3(512), 0, st,
+                               (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, N, Npad, heads, scale_log2e, 1.0f);
+        else if (bq == 64 && ks == 4)
+            hipLaunchKernelGGL((attention_kernel<bf16_t, 1, 4, 2, bf16_t, 4>), dim3(cdiv(N, 64), heads, B), dim3(1024), 0, st,
+                               (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, N, Npad, heads, scale_log2e, 1.0f);
+        else if (bq == 128) D2S_ATT(bf16_t, 1, 8);
         else if (bq == 64) D2S_ATT(bf16_t, 1, 4);
         else D2S_ATT(bf16_t, 1, 2);
     } else {
