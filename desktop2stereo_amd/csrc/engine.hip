@@ -69,14 +69,15 @@ struct d2s_engine {
     // Video-Depth-Anything temporal modules (desc.temporal): layer_3, layer_4, path_4, path_3
     struct TMod {
         int C = 0, sites = 0;
-        float *gn_g = nullptr, *gn_b = nullptr, *pe = nullptr;
+        float *gn_g = nullptr, *gn_b = nullptr;
         float *ln_g[2] = {nullptr, nullptr}, *ln_b[2] = {nullptr, nullptr}, *ffn_g = nullptr, *ffn_b = nullptr;
-        PackedW proj_in, proj_out, to_q[2], to_kv[2], to_out[2], ff1, ff2;
-        void* cache[2] = {nullptr, nullptr};       // ring [31][sites][C] T per attention block
+        PackedW proj_in, proj_out, kvq[2], to_out[2], ff1, ff2;     // kvq: fused to_k | to_v | to_q, [3C][C]
+        float* ptab[2] = {nullptr, nullptr};       // [32][3C] = pe @ kvq^T: the positional encoding's share of k | v | q
+        void* cache[2] = {nullptr, nullptr};       // ring [31][sites][2C] T per attention block: projected k' | v' rows
     } tm[4];
     int tm_head = 0, tm_init = 0;                  // oldest ring slot; 0 until the first frame has filled the rings
     float* tm_hs = nullptr;                        // [sites_max, C_max] fp32 residual of the temporal transformer
-    void *tm_a = nullptr, *tm_b = nullptr, *tm_kvin = nullptr, *tm_kv = nullptr, *tm_u = nullptr, *tm_g = nullptr, *tm_out = nullptr;
+    void *tm_a = nullptr, *tm_kv = nullptr, *tm_u = nullptr, *tm_g = nullptr, *tm_out = nullptr;
     // pipeline buffers
     float *pre_x = nullptr, *depth_small = nullptr;
     void* post_ws = nullptr;
@@ -321,17 +322,16 @@ int run_temporal(d2s_engine* e, int m, const void* x, void* out, hipStream_t st)
     RC(gemm(e, plainA(e->tm_a, C), t.proj_in, S, rowsE(e->tm_hs, OUT_F32, C, t.proj_in.bias), st));
     for (int a = 0; a < 2; ++a) {
         PROF(PC_LN, 0, 0, launch_layernorm(prec, e->tm_hs, t.ln_g[a], t.ln_b[a], e->tm_a, S, C, 1e-5f, 0, 0, 0, st));
-        PROF(PC_ELT, 0, 0, launch_gather_pe(prec, t.cache[a], e->tm_a, t.pe, e->tm_kvin, S, C, Tw, 31, e->tm_head, st));
-        RC(gemm(e, plainA(e->tm_kvin, C), t.to_kv[a], S * Tw, rowsE(e->tm_kv, OUT_T, 2 * C, nullptr), st));
-        RC(gemm(e, plainA((const char*)e->tm_kvin + (size_t)(Tw - 1) * C * es, (long)Tw * C), t.to_q[a], S, rowsE(e->tm_b, OUT_T, C, nullptr), st));
-        PROF(PC_ATTN, 4.0 * S * Tw * C, 0, launch_temporal_attn(prec, e->tm_b, e->tm_kv, e->tm_out, S, C, Tw, st));
+        // project THIS frame only (k' | v' | q'); the window's other 31 positions are already projected in the ring
+        RC(gemm(e, plainA(e->tm_a, C), t.kvq[a], S, rowsE(e->tm_kv, OUT_T, 3 * C, nullptr), st));
+        PROF(PC_ATTN, 4.0 * S * Tw * C, 0, launch_temporal_attn(prec, e->tm_kv, t.cache[a], t.ptab[a], e->tm_out, S, C, Tw, 31, e->tm_head, st));
         {
             GemmEpi ep = rowsE(e->tm_hs, OUT_F32, C, t.to_out[a].bias);
             ep.res1 = e->tm_hs;
             RC(gemm(e, plainA(e->tm_out, C), t.to_out[a], S, ep, st));
         }
-        // the normed hidden state joins the window: first frame fills all 31 slots, later frames replace the oldest
-        PROF(PC_ELT, 0, 0, launch_cache_store(prec, t.cache[a], e->tm_a, S, C, e->tm_init ? e->tm_head : 0, e->tm_init ? 1 : 31, st));
+        // the frame's projected rows join the window: first frame fills all 31 slots, later frames replace the oldest
+        PROF(PC_ELT, 0, 0, launch_cache_store(prec, t.cache[a], e->tm_kv, S, C, e->tm_init ? e->tm_head : 0, e->tm_init ? 1 : 31, st));
     }
     PROF(PC_LN, 0, 0, launch_layernorm(prec, e->tm_hs, t.ffn_g, t.ffn_b, e->tm_a, S, C, 1e-5f, 0, 0, 0, st));
     RC(gemm(e, plainA(e->tm_a, C), t.ff1, S, rowsE(e->tm_u, OUT_T, 8 * C, t.ff1.bias), st));
@@ -644,34 +644,42 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
             RC(upload_f32(e, p + "norm.weight", C, &t.gn_g)); RC(upload_f32(e, p + "norm.bias", C, &t.gn_b));
             RC(pack_linear(e, p + "proj_in.weight", p + "proj_in.bias", C, C, t.proj_in));
             RC(pack_linear(e, p + "proj_out.weight", p + "proj_out.bias", C, C, t.proj_out));
-            for (int a = 0; a < 2; ++a) {
-                std::string q = b + "attention_blocks." + std::to_string(a) + ".";
-                RC(upload_f32(e, b + "norms." + std::to_string(a) + ".weight", C, &t.ln_g[a]));
-                RC(upload_f32(e, b + "norms." + std::to_string(a) + ".bias", C, &t.ln_b[a]));
-                RC(pack_linear(e, q + "to_q.weight", "", C, C, t.to_q[a]));
-                const HostT *wk = find(e, q + "to_k.weight"), *wv = find(e, q + "to_v.weight");
-                if (!wk || !wv) return D2S_E_MISSING;
-                if (wk->data.size() != (size_t)C * C || wv->data.size() != (size_t)C * C) { set_error("to_k/to_v: wrong shape"); return D2S_E_MISSING; }
-                const float* kv[2] = {wk->data.data(), wv->data.data()};
-                RC(pack_matrix(e, 2 * C, C, [&](int n, int k) { return kv[n / C][(size_t)(n % C) * C + k]; }, nullptr, t.to_kv[a]));
-                RC(pack_linear(e, q + "to_out.0.weight", q + "to_out.0.bias", C, C, t.to_out[a]));
-                RC(dev_alloc(e, &t.cache[a], (size_t)31 * t.sites * C * es, true));
-            }
-            RC(upload_f32(e, b + "ff_norm.weight", C, &t.ffn_g)); RC(upload_f32(e, b + "ff_norm.bias", C, &t.ffn_b));
-            RC(pack_linear(e, b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", 8 * C, C, t.ff1));
-            RC(pack_linear(e, b + "ff.net.2.weight", b + "ff.net.2.bias", C, 4 * C, t.ff2));
             // sinusoidal APE over the 32-frame window (motion_module.py:214-222), float32 like torch
             std::vector<float> pe((size_t)32 * C);
             for (int i = 0; i < C / 2; ++i) {
                 float div = expf((float)(2 * i) * (float)(-std::log(10000.0) / C));
                 for (int pos = 0; pos < 32; ++pos) { pe[(size_t)pos * C + 2 * i] = sinf((float)pos * div); pe[(size_t)pos * C + 2 * i + 1] = cosf((float)pos * div); }
             }
-            RC(dev_alloc(e, (void**)&t.pe, pe.size() * 4));
-            D2S_HIP(hipMemcpy(t.pe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
+            for (int a = 0; a < 2; ++a) {
+                std::string q = b + "attention_blocks." + std::to_string(a) + ".";
+                RC(upload_f32(e, b + "norms." + std::to_string(a) + ".weight", C, &t.ln_g[a]));
+                RC(upload_f32(e, b + "norms." + std::to_string(a) + ".bias", C, &t.ln_b[a]));
+                const HostT *wq = find(e, q + "to_q.weight"), *wk = find(e, q + "to_k.weight"), *wv = find(e, q + "to_v.weight");
+                if (!wq || !wk || !wv) return D2S_E_MISSING;
+                for (const HostT* w3 : {wq, wk, wv}) if (w3->data.size() != (size_t)C * C) { set_error("to_q/to_k/to_v: wrong shape"); return D2S_E_MISSING; }
+                const float* kvq[3] = {wk->data.data(), wv->data.data(), wq->data.data()};      // fused rows: k | v | q (no biases)
+                RC(pack_matrix(e, 3 * C, C, [&](int n, int k) { return kvq[n / C][(size_t)(n % C) * C + k]; }, nullptr, t.kvq[a]));
+                // W (x + pe_j) = W x + W pe_j: the positional share of every window position, float32
+                std::vector<float> pt((size_t)32 * 3 * C);
+                for (int j = 0; j < 32; ++j)
+                    for (int n = 0; n < 3 * C; ++n) {
+                        const float* wr = kvq[n / C] + (size_t)(n % C) * C;
+                        double acc = 0.0;
+                        for (int k = 0; k < C; ++k) acc += (double)pe[(size_t)j * C + k] * (double)wr[k];
+                        pt[(size_t)j * 3 * C + n] = (float)acc;
+                    }
+                RC(dev_alloc(e, (void**)&t.ptab[a], pt.size() * 4));
+                D2S_HIP(hipMemcpy(t.ptab[a], pt.data(), pt.size() * 4, hipMemcpyHostToDevice));
+                RC(pack_linear(e, q + "to_out.0.weight", q + "to_out.0.bias", C, C, t.to_out[a]));
+                RC(dev_alloc(e, &t.cache[a], (size_t)31 * t.sites * 2 * C * es, true));
+            }
+            RC(upload_f32(e, b + "ff_norm.weight", C, &t.ffn_g)); RC(upload_f32(e, b + "ff_norm.bias", C, &t.ffn_b));
+            RC(pack_linear(e, b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", 8 * C, C, t.ff1));
+            RC(pack_linear(e, b + "ff.net.2.weight", b + "ff.net.2.bias", C, 4 * C, t.ff2));
         }
         RC(dev_alloc(e, (void**)&e->tm_hs, sc_max * 4));
-        RC(dev_alloc(e, &e->tm_a, sc_max * es)); RC(dev_alloc(e, &e->tm_b, sc_max * es)); RC(dev_alloc(e, &e->tm_out, sc_max * es));
-        RC(dev_alloc(e, &e->tm_kvin, sc_max * 32 * es)); RC(dev_alloc(e, &e->tm_kv, sc_max * 64 * es));
+        RC(dev_alloc(e, &e->tm_a, sc_max * es)); RC(dev_alloc(e, &e->tm_out, sc_max * es));
+        RC(dev_alloc(e, &e->tm_kv, sc_max * 3 * es));                  // k' | v' | q' of the current frame
         RC(dev_alloc(e, &e->tm_u, sc_max * 8 * es)); RC(dev_alloc(e, &e->tm_g, sc_max * 4 * es));
     }
     e->host.clear();

@@ -5,9 +5,10 @@
 //   FeedForward / GEGLU                  motion_module/attention.py:296-384
 //   cache update                         vda2_s.py:177-187, 203-218
 // Activations are NHWC = [sites, C] token matrices, so every Linear is the engine's MFMA GEMM; this file
-// holds the small kernels around them: GroupNorm, the window gather (+positional encoding), the
-// 32-key attention per spatial site, GEGLU, and the ring-buffer cache (the reference shift-copies the
-// whole cache every frame; here the oldest slot is overwritten in place).
+// holds the small kernels around them: GroupNorm, the 32-key attention per (spatial site, head) reading the
+// ring-buffer window of projected K'/V' rows, GEGLU, and the ring store (the reference shift-copies the whole
+// cache of hidden states every frame and re-projects all 32 window positions; here the oldest slot of projected
+// rows is overwritten in place and only the new frame is projected).
 #include "vit_ops.h"
 
 namespace d2s {
@@ -50,79 +51,115 @@ groupnorm_kernel(const T* __restrict__ x, const float* __restrict__ g, const flo
     }
 }
 
-// window rows: kvin[(s*Tw + j), :] = (j < Tw-1 ? cache[(head + j) % slots][s] : cur[s]) + pe[j]
-template <typename T>
-__global__ void __launch_bounds__(256)
-gather_pe_kernel(const T* __restrict__ cache, const T* __restrict__ cur, const float* __restrict__ pe, T* __restrict__ kvin,
-                 int sites, int C, int Tw, int slots, int head) {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (long)sites * Tw * C;
-    if (idx >= total) return;
-    int c = (int)(idx % C);
-    long r = idx / C;
-    int j = (int)(r % Tw), s = (int)(r / Tw);
-    float v = (j < Tw - 1) ? tf(cache[((long)((head + j) % slots) * sites + s) * C + c]) : tf(cur[(long)s * C + c]);
-    kvin[idx] = tcvt<T>(v + pe[(long)j * C + c]);
-}
+// The window caches hold the PROJECTED rows K' = W_k x, V' = W_v x of the past 31 frames (x = the normed hidden state,
+// without the positional encoding): the reference projects (x_j + pe_j) for all 32 window positions every frame
+// (motion_module.py:288-300), but the projection is linear, W (x + pe_j) = W x + W pe_j, and W pe_j is a constant
+// 32 x 3C table per attention block.  So a frame projects only its own rows (one [S, C] x [C, 3C] GEMM instead of
+// [32 S, C] x [C, 2C]), and the attention adds the table rows on the fly.
 
-// cache[slot][s][c] = cur[s][c] for slot in [slot0, slot0 + nslots)
+// ring[slot][s][0:2C] = cur[s][0:2C] for slot in [slot0, slot0 + nslots); cur rows are 3C wide (k | v | q)
 template <typename T>
 __global__ void __launch_bounds__(256)
 cache_store_kernel(T* __restrict__ cache, const T* __restrict__ cur, int sites, int C, int slot0, int nslots) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long per = (long)sites * C;
+    const int C2 = 2 * C;
+    long per = (long)sites * C2;
     if (idx >= per * nslots) return;
-    cache[(long)slot0 * per + idx] = cur[idx % per];
+    long r = idx % per;
+    cache[(long)slot0 * per + idx] = cur[(r / C2) * 3 * C + r % C2];
 }
 
-// One wave per spatial site: 8 heads x Tw (<= 32) keys.  q [sites, C]; kv [sites*Tw, 2C] (k | v); out [sites, C].
-template <typename T>
-__global__ void __launch_bounds__(256)
-temporal_attn_kernel(const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ out, int sites, int C, int Tw, float scale) {
-    __shared__ float prob[4][8 * 32];
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s0 = blockIdx.x * 4 + wid;
-    const bool live = s0 < sites;                       // (no early return: block-level barriers below)
-    const int s = live ? s0 : sites - 1;
-    const int dh = C >> 3;
-    const T* qs = q + (long)s * C;
-    const T* kvs = kv + (long)s * Tw * 2 * C;
-    float* p = prob[wid];
-    // scores: pair id -> (head, key)
-    const int npair = 8 * Tw;
-    float sc[4];
+template <int CH> __device__ __forceinline__ void load_ch(const float* p, float v[CH]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int pid = lane + 64 * i;
-        sc[i] = -1e30f;
-        if (pid < npair) {
-            int h = pid / Tw, j = pid - h * Tw;
-            const T* kr = kvs + (long)j * 2 * C + h * dh;
-            const T* qr = qs + h * dh;
-            float acc = 0.f;
-            for (int d = 0; d < dh; ++d) acc += tf(qr[d]) * tf(kr[d]);
-            sc[i] = acc * scale;
-            p[pid] = sc[i];
+    for (int i = 0; i < CH; i += 4) { float4 t = *(const float4*)(p + i); v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w; }
+}
+template <int CH> __device__ __forceinline__ void load_ch(const bf16_t* p, float v[CH]) {
+#pragma unroll
+    for (int i = 0; i < CH; i += 4) {
+        uint2 t = *(const uint2*)(p + i);
+        v[i] = __uint_as_float(t.x << 16); v[i + 1] = __uint_as_float(t.x & 0xffff0000u);
+        v[i + 2] = __uint_as_float(t.y << 16); v[i + 3] = __uint_as_float(t.y & 0xffff0000u);
+    }
+}
+
+// LPU (2..16, power of two >= head_dim / CH) lanes per (site, head) unit, lane <-> one CH-channel chunk of the head:
+// every K' / V' row segment of a head is read once, coalesced (head_dim * sizeof(T) contiguous bytes per key), the
+// score partials are xor-reduced over the unit's lanes, the 32 scores / probabilities live in registers.
+// cur [S, 3C] (k' | v' | q' of this frame), ring [slots][S][2C] (k' | v' of the past frames, oldest at `head`),
+// ptab [32][3C] float = pe @ [W_k | W_v | W_q]^T.  Window position j < Tw-1 is ring slot (head + j) % slots, j = Tw-1 the
+// current frame (reference motion_module.py:259-300: q from the last position, k / v from all).  out [S, C].
+template <typename T, int CH>
+__global__ void __launch_bounds__(256)
+temporal_attn_ring_kernel(const T* __restrict__ cur, const T* __restrict__ ring, const float* __restrict__ ptab, T* __restrict__ out,
+                          int sites, int C, int Tw, int slots, int head, float scale, int lpu) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int unit = gid / lpu, li = gid % lpu;
+    const bool live = unit < sites * 8;                            // (no early return: the shuffles below need every lane)
+    const int s = live ? unit >> 3 : 0, h = unit & 7, dh = C >> 3, C2 = 2 * C, C3 = 3 * C;
+    const bool act = live && li * CH < dh;                         // lanes beyond the head's channels only take part in shuffles
+    const int c = h * dh + (act ? li * CH : 0);                    // this lane's first channel
+    const T* cur_row = cur + (long)s * C3;
+    float q[CH];
+    {
+        float pq[CH];
+        load_ch<CH>(cur_row + C2 + c, q);
+        load_ch<CH>(ptab + (long)(Tw - 1) * C3 + C2 + c, pq);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) q[i] = act ? q[i] + pq[i] : 0.f;
+    }
+    // keys in groups of 8: all loads of a group are issued before its arithmetic (the kernel is latency-bound: a unit
+    // touches 32 x 2 short row segments).  Positions >= Tw (first frame only: Tw = 1) re-read the last valid row and are
+    // masked out of the softmax.
+    float sc[32];
+#pragma unroll
+    for (int jb = 0; jb < 32; jb += 8) {
+        float k[8][CH], pk[8][CH];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int j = min(jb + t, Tw - 1);
+            const T* krow = j < Tw - 1 ? ring + ((long)((head + j) % slots) * sites + s) * C2 : cur_row;
+            load_ch<CH>(krow + c, k[t]);
+            load_ch<CH>(ptab + (long)j * C3 + c, pk[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) a += q[i] * (k[t][i] + pk[t][i]);
+            for (int o = lpu >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            sc[jb + t] = jb + t < Tw ? a * scale : -1e30f;
         }
     }
-    __syncthreads();
-    // softmax per head over Tw keys: lanes 0..7 each own one head's row in LDS
-    if (lane < 8) {
-        float* row = p + lane * Tw;
-        float mx = -1e30f;
-        for (int j = 0; j < Tw; ++j) mx = fmaxf(mx, row[j]);
-        float sum = 0.f;
-        for (int j = 0; j < Tw; ++j) { float e = __expf(row[j] - mx); row[j] = e; sum += e; }
-        float inv = 1.0f / sum;
-        for (int j = 0; j < Tw; ++j) row[j] *= inv;
+    float mx = -1e30f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) mx = fmaxf(mx, sc[j]);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { sc[j] = j < Tw ? __expf(sc[j] - mx) : 0.f; sum += sc[j]; }
+    const float inv = 1.0f / sum;
+    float acc[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 32; jb += 8) {
+        float v[8][CH], pv[8][CH];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int j = min(jb + t, Tw - 1);
+            const T* vrow = (j < Tw - 1 ? ring + ((long)((head + j) % slots) * sites + s) * C2 : cur_row) + C;
+            load_ch<CH>(vrow + c, v[t]);
+            load_ch<CH>(ptab + (long)j * C3 + C + c, pv[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float p = sc[jb + t] * inv;                      // 0 for masked positions
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc[i] += p * (v[t][i] + pv[t][i]);
+        }
     }
-    __syncthreads();
-    // out[c] = sum_j prob[h(c)][j] * v[j][c]; lanes stride over channels (coalesced V reads)
-    for (int c = lane; c < C; c += 64) {
-        const float* row = p + (c / dh) * Tw;
-        float acc = 0.f;
-        for (int j = 0; j < Tw; ++j) acc += row[j] * tf(kvs[(long)j * 2 * C + C + c]);
-        if (live) out[(long)s * C + c] = tcvt<T>(acc);
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) out[(long)s * C + c + i] = tcvt<T>(acc[i]);
     }
 }
 
@@ -159,27 +196,28 @@ int launch_groupnorm(int prec, const void* x, const float* g, const float* b, vo
     return D2S_OK;
 }
 
-int launch_gather_pe(int prec, const void* cache, const void* cur, const float* pe, void* kvin, int sites, int C, int Tw, int slots, int head, hipStream_t st) {
-    long total = (long)sites * Tw * C;
-    if (prec == D2S_PREC_BF16) hipLaunchKernelGGL(gather_pe_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16_t*)cache, (const bf16_t*)cur, pe, (bf16_t*)kvin, sites, C, Tw, slots, head);
-    else hipLaunchKernelGGL(gather_pe_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)cache, (const float*)cur, pe, (float*)kvin, sites, C, Tw, slots, head);
-    D2S_CHECK_LAUNCH();
-    return D2S_OK;
-}
-
 int launch_cache_store(int prec, void* cache, const void* cur, int sites, int C, int slot0, int nslots, hipStream_t st) {
-    long total = (long)sites * C * nslots;
+    long total = (long)sites * 2 * C * nslots;
     if (prec == D2S_PREC_BF16) hipLaunchKernelGGL(cache_store_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, st, (bf16_t*)cache, (const bf16_t*)cur, sites, C, slot0, nslots);
     else hipLaunchKernelGGL(cache_store_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, st, (float*)cache, (const float*)cur, sites, C, slot0, nslots);
     D2S_CHECK_LAUNCH();
     return D2S_OK;
 }
 
-int launch_temporal_attn(int prec, const void* q, const void* kv, void* out, int sites, int C, int Tw, hipStream_t st) {
-    if (C % 8 || Tw < 1 || Tw > 32) { set_error("temporal_attn: C % 8 == 0 and 1 <= window <= 32 required"); return D2S_E_INVALID; }
-    float scale = 1.0f / sqrtf((float)(C / 8));
-    if (prec == D2S_PREC_BF16) hipLaunchKernelGGL(temporal_attn_kernel<bf16_t>, dim3(cdiv(sites, 4)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, sites, C, Tw, scale);
-    else hipLaunchKernelGGL(temporal_attn_kernel<float>, dim3(cdiv(sites, 4)), dim3(256), 0, st, (const float*)q, (const float*)kv, (float*)out, sites, C, Tw, scale);
+int launch_temporal_attn(int prec, const void* cur, const void* ring, const float* ptab, void* out, int sites, int C, int Tw, int slots,
+                         int head, hipStream_t st) {
+    if (C % 32 || Tw < 1 || Tw > 32) { set_error("temporal_attn: C % 32 == 0 and 1 <= window <= 32 required"); return D2S_E_INVALID; }
+    const float scale = 1.0f / sqrtf((float)(C / 8));
+    const bool ch8 = (C / 8) % 8 == 0;                 // head dim multiple of 8: 16-byte bf16 chunks
+    int lpu = 1;                                       // lanes per (site, head) unit: power of two >= head_dim / chunk
+    while (lpu * (ch8 ? 8 : 4) < C / 8) lpu <<= 1;
+    if (lpu > 64) { set_error("temporal_attn: head dim too large"); return D2S_E_UNSUPPORTED; }
+    const dim3 grid(cdiv((long)sites * 8 * lpu, 256)), block(256);
+#define D2S_TATT(TT, CH) hipLaunchKernelGGL((temporal_attn_ring_kernel<TT, CH>), grid, block, 0, st, (const TT*)cur, (const TT*)ring, ptab, (TT*)out, \
+                                            sites, C, Tw, slots, head, scale, lpu)
+    if (prec == D2S_PREC_BF16) { if (ch8) D2S_TATT(bf16_t, 8); else D2S_TATT(bf16_t, 4); }
+    else { if (ch8) D2S_TATT(float, 8); else D2S_TATT(float, 4); }
+#undef D2S_TATT
     D2S_CHECK_LAUNCH();
     return D2S_OK;
 }

@@ -21,15 +21,20 @@ ap.add_argument("--res", type=int, default=518)
 ap.add_argument("--prec", default="bf16")
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--vda", action="store_true")
 a = ap.parse_args()
 os.environ["D2S_PROF_DUMP"] = "1"
 cfg = MODELS[a.model]
 h, w, _ = engine_shape(a.height, a.width, a.res)
-eng = ops.Engine(cfg, make_weights(cfg, 0), h, w, a.batch, a.prec)
+if a.vda:
+    from desktop2stereo_amd.vda_weights import make_vda_weights
+    eng = ops.Engine(cfg, make_vda_weights(cfg, 0), h, w, 1, a.prec, temporal=True)
+else:
+    eng = ops.Engine(cfg, make_weights(cfg, 0), h, w, a.batch, a.prec)
 p = PipelineParams(depth_resolution=a.res)
 sp = ops.sbs_params(0.064, 4.0, 0.0, "Full-SBS", False)
 frames = torch.from_numpy(np.stack([synth.noise_frame(a.height, a.width, i) for i in range(a.batch)])).cuda()
-for _ in range(5):
+for _ in range(40 if a.vda else 5):
     eng.pipeline(frames, p, sp)
 torch.cuda.synchronize()
 eng.profile(True)
