@@ -66,6 +66,14 @@ struct d2s_engine {
     void* scr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float* splitk_ws = nullptr;                    // fp32 partials for split-K launches (tiny-M, long-K DPT convs)
     size_t splitk_elems = 0;
+    // Neck branches of taps 0..2 (+ the RCU1 of their fusion layer) only depend on their tap, not on later encoder
+    // layers: they run on a second stream under the remaining layers (batch 1 leaves most CUs idle per launch).
+    hipStream_t side = nullptr;
+    hipEvent_t ev_tap[4] = {nullptr, nullptr, nullptr, nullptr}, ev_side = nullptr;
+    bool overlap = true;
+    float* splitk_ws_side = nullptr;               // the side stream's own split-K partials
+    void* r1[3] = {nullptr, nullptr, nullptr};     // RCU1(feat[i]) = feat[i] + conv2(relu(conv1(relu(feat[i])))), i = 0..2
+    void* r1tmp = nullptr;
     // Video-Depth-Anything temporal modules (desc.temporal): layer_3, layer_4, path_4, path_3
     struct TMod {
         int C = 0, sites = 0;
@@ -288,7 +296,10 @@ GemmEpi rowsE(void* out, int out_type, long ldc, const float* bias) {
 int gemm(d2s_engine* e, const GemmA& a, const PackedW& w, int M, const GemmEpi& ep, hipStream_t st) {
     int Kl = w.K % (e->prec == D2S_PREC_BF16 ? 8 : 4) ? w.Kpad : w.K;   // ragged K (patch embed): A is zero padded to Kpad
     GemmEpi ep2 = ep;
-    if (ep.map == MAP_ROWS) { ep2.part = e->splitk_ws; ep2.part_elems = e->splitk_elems; }   // launcher decides whether to split K
+    if (ep.map == MAP_ROWS) {                      // launcher decides whether to split K; each stream has its own partials
+        ep2.part = (e->side && st == e->side) ? e->splitk_ws_side : e->splitk_ws;
+        ep2.part_elems = e->splitk_elems;
+    }
     PROF(a.mode == A_CONV3 ? PC_CONV : PC_GEMM, 2.0 * M * w.N * w.K, 0, launch_gemm(e->prec, 0, a, w.w, M, w.N, Kl, w.Kpad, ep2, st));
     return D2S_OK;
 }
@@ -313,7 +324,7 @@ int conv3(d2s_engine* e, const void* in, int B, int Hi, int Wi, int C, int strid
 
 // One streaming TemporalModule on an NHWC map x [sites, C] -> out; reads then updates its ring caches.
 // (reference motion_module.py:102-134, 164-196, 242-321; cache semantics vda2_s.py:177-218)
-int run_temporal(d2s_engine* e, int m, const void* x, void* out, hipStream_t st) {
+int run_temporal(d2s_engine* e, int m, const void* x, void* out, hipStream_t st, const void* add = nullptr) {   // out = module(x) [+ add]
     d2s_engine::TMod& t = e->tm[m];
     const int C = t.C, S = t.sites, prec = e->prec;
     const int Tw = e->tm_init ? 32 : 1;                 // first frame: a window of one (the frame itself at position 0)
@@ -344,8 +355,38 @@ int run_temporal(d2s_engine* e, int m, const void* x, void* out, hipStream_t st)
     PROF(PC_ELT, 0, 0, launch_cast_f32(prec, e->tm_hs, e->tm_a, (long)S * C, st));
     {
         GemmEpi ep = rowsE(out, OUT_T, C, t.proj_out.bias);
-        ep.res1 = x;
+        ep.res1 = x; ep.res2 = add;
         RC(gemm(e, plainA(e->tm_a, C), t.proj_out, S, ep, st));
+    }
+    return D2S_OK;
+}
+
+// Tap i of the neck: reassemble (HF DepthAnythingReassembleStage) + 3x3 to fusion width (neck.convs), then -- for the
+// three shallower taps -- the first residual unit of their fusion layer, RCU1(m) = m + conv2(relu(conv1(relu(m)))),
+// which depends on this map only (HF DepthAnythingFeatureFusionLayer adds it to the deeper stage's output later).
+int neck_branch(d2s_engine* e, int i, int B, hipStream_t st) {
+    const d2s_model_desc& d = e->d;
+    const int D = d.hidden, F = d.fusion, gh = e->gh, gw = e->gw, Mp = B * e->P, c = d.neck[i];
+    RC(gemm(e, plainA(e->tapbuf[i], D), e->re[i].proj, Mp, rowsE(e->rproj[i], OUT_T, c, e->re[i].proj.bias), st));
+    const void* src = e->rproj[i];
+    int Hs = gh, Ws = gw;
+    if (i < 2) {
+        int ks = i == 0 ? 4 : 2;
+        GemmEpi ep = rowsE(e->rres[i], OUT_T, c, e->re[i].resize.bias);
+        ep.map = MAP_SHUFFLE; ep.gh = gh; ep.gw = gw; ep.ks = ks; ep.cout = c;
+        RC(gemm(e, plainA(e->rproj[i], c), e->re[i].resize, Mp, ep, st));
+        src = e->rres[i]; Hs = gh * ks; Ws = gw * ks;
+    } else if (i == 3) {
+        RC(conv3(e, e->rproj[i], B, gh, gw, c, 2, 0, e->re[i].resize, e->rres[i], ACT_NONE, nullptr, nullptr, st));
+        src = e->rres[i]; Hs = (gh - 1) / 2 + 1; Ws = (gw - 1) / 2 + 1;
+    }
+    if (d.temporal && i == 2) { RC(run_temporal(e, 0, src, e->rres[2], st)); src = e->rres[2]; }     // layer_3
+    if (d.temporal && i == 3) { RC(run_temporal(e, 1, src, e->scr[0], st)); src = e->scr[0]; }       // layer_4
+    RC(conv3(e, src, B, Hs, Ws, c, 1, 0, e->re[i].conv, e->feat[i], ACT_NONE, nullptr, nullptr, st));
+    if (i < 3) {
+        const int idx = 3 - i;                          // the fusion layer that consumes this map
+        RC(conv3(e, e->feat[i], B, Hs, Ws, F, 1, 1, e->fu[idx].r1c1, e->r1tmp, ACT_NONE, nullptr, nullptr, st));
+        RC(conv3(e, e->r1tmp, B, Hs, Ws, F, 1, 1, e->fu[idx].r1c2, e->r1[i], ACT_NONE, e->feat[i], nullptr, st));
     }
     return D2S_OK;
 }
@@ -354,6 +395,7 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     const d2s_model_desc& d = e->d;
     const int D = d.hidden, N = e->N, P = e->P, M = B * N, Mp = B * P, prec = e->prec;
     const int F = d.fusion;
+    const bool use_side = e->overlap && e->side != nullptr;
     if (e->fp8 && !e->fp8_ready && !e->calib) {
         set_error("D2S_PREC_FP8 engine: activation scales are not set, call d2s_engine_calibrate first");
         return D2S_E_STATE;
@@ -411,31 +453,25 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         if (e->taps) D2S_HIP(hipMemcpyAsync(e->tap_hidden + (size_t)(l + 1) * N * D, e->resid, (size_t)N * D * 4, hipMemcpyDeviceToDevice, st));
         if (tap_i < 4 && l + 1 == d.out_indices[tap_i]) {     // HF Dinov2Backbone: shared final LN, drop cls
             PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, e->lnfg, e->lnfb, e->tapbuf[tap_i], Mp, D, d.ln_eps, P, N, 1, st));
+            // this tap's neck branch runs under the remaining encoder layers.  VDA: the temporal modules of branches 2 and 3
+            // share the tm_* workspaces, so branch 3 queues behind branch 2 on the side stream instead of racing it.
+            if (use_side && (tap_i < 3 || d.temporal)) {
+                D2S_HIP(hipEventRecord(e->ev_tap[tap_i], st));
+                D2S_HIP(hipStreamWaitEvent(e->side, e->ev_tap[tap_i], 0));
+                RC(neck_branch(e, tap_i, B, e->side));
+            }
             ++tap_i;
         }
     }
-    // ---- neck: reassemble (HF DepthAnythingReassembleStage) + 3x3 to fusion width
-    const int gh = e->gh, gw = e->gw;
-    for (int i = 0; i < 4; ++i) {
-        int c = d.neck[i];
-        RC(gemm(e, plainA(e->tapbuf[i], D), e->re[i].proj, Mp, rowsE(e->rproj[i], OUT_T, c, e->re[i].proj.bias), st));
-        const void* src = e->rproj[i];
-        int Hs = gh, Ws = gw;
-        if (i < 2) {
-            int ks = i == 0 ? 4 : 2;
-            GemmEpi ep = rowsE(e->rres[i], OUT_T, c, e->re[i].resize.bias);
-            ep.map = MAP_SHUFFLE; ep.gh = gh; ep.gw = gw; ep.ks = ks; ep.cout = c;
-            RC(gemm(e, plainA(e->rproj[i], c), e->re[i].resize, Mp, ep, st));
-            src = e->rres[i]; Hs = gh * ks; Ws = gw * ks;
-        } else if (i == 3) {
-            RC(conv3(e, e->rproj[i], B, gh, gw, c, 2, 0, e->re[i].resize, e->rres[i], ACT_NONE, nullptr, nullptr, st));
-            src = e->rres[i]; Hs = (gh - 1) / 2 + 1; Ws = (gw - 1) / 2 + 1;
-        }
-        if (d.temporal && i == 2) { RC(run_temporal(e, 0, src, e->rres[2], st)); src = e->rres[2]; }     // layer_3
-        if (d.temporal && i == 3) { RC(run_temporal(e, 1, src, e->scr[0], st)); src = e->scr[0]; }       // layer_4
-        RC(conv3(e, src, B, Hs, Ws, c, 1, 0, e->re[i].conv, e->feat[i], ACT_NONE, nullptr, nullptr, st));
+    // ---- neck branches that did not run on the side stream, then join it
+    for (int i = 0; i < 4; ++i)
+        if (!(use_side && (i < 3 || d.temporal))) RC(neck_branch(e, i, B, st));
+    if (use_side) {
+        D2S_HIP(hipEventRecord(e->ev_side, e->side));
+        D2S_HIP(hipStreamWaitEvent(st, e->ev_side, 0));
     }
-    // ---- fusion, deep -> shallow (HF DepthAnythingFeatureFusionStage)
+    // ---- fusion, deep -> shallow (HF DepthAnythingFeatureFusionStage).  hidden(idx) = fused(idx-1) + RCU1(m): the sum is
+    // formed where fused(idx-1) is produced (up-sample / temporal-module epilogue), from the r1[] maps of the neck branches.
     void *X = e->scr[0], *Y = e->scr[1], *Z = e->scr[2];
     void* fused = nullptr;
     int Hc = 0, Wc = 0;
@@ -443,12 +479,7 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         int mi = 3 - idx;
         void* m = e->feat[mi];
         Hc = e->fH[mi]; Wc = e->fW[mi];
-        const void* hcur = m;
-        if (idx > 0) {       // hidden = fused + RCU1(m)
-            RC(conv3(e, m, B, Hc, Wc, F, 1, 1, e->fu[idx].r1c1, X, ACT_NONE, nullptr, nullptr, st));
-            RC(conv3(e, X, B, Hc, Wc, F, 1, 1, e->fu[idx].r1c2, Y, ACT_NONE, m, fused, st));
-            hcur = Y;
-        }
+        const void* hcur = idx == 0 ? m : fused;
         RC(conv3(e, hcur, B, Hc, Wc, F, 1, 1, e->fu[idx].r2c1, X, ACT_NONE, nullptr, nullptr, st));
         RC(conv3(e, X, B, Hc, Wc, F, 1, 1, e->fu[idx].r2c2, Z, ACT_NONE, hcur, nullptr, st));
         int Ho, Wo;
@@ -456,12 +487,15 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         // HF: projection(interpolate(h)).  The 1x1 projection (+bias) commutes with bilinear interpolation
         // (interpolation weights sum to 1), so it runs BEFORE the up-sample on 4x fewer pixels.
         void* pout = e->scr[3 + (idx & 1)];
+        const void* next_r1 = idx < 3 ? e->r1[2 - idx] : nullptr;      // RCU1 of the next (shallower) stage's map
         RC(gemm(e, plainA(Z, F), e->fu[idx].proj, B * Hc * Wc, rowsE(X, OUT_T, F, e->fu[idx].proj.bias), st));
-        PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, X, pout, B, Hc, Wc, Ho, Wo, F, st));
         if (d.temporal && idx < 2) {                     // path_4 / path_3 (dpt_temporal.py:98-103)
+            PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, X, pout, B, Hc, Wc, Ho, Wo, F, st));
             void* alt = e->scr[3 + ((idx + 1) & 1)];
-            RC(run_temporal(e, 2 + idx, pout, alt, st));
+            RC(run_temporal(e, 2 + idx, pout, alt, st, next_r1));
             pout = alt;
+        } else {
+            PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, X, pout, B, Hc, Wc, Ho, Wo, F, st, next_r1));
         }
         fused = pout; Hc = Ho; Wc = Wo;
     }
@@ -628,6 +662,19 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
     for (int i = 0; i < 5; ++i) RC(dev_alloc(e, &e->scr[i], scr_elems * es));
     e->splitk_elems = (size_t)B * 16 * e->fH[2] * e->fW[2] * std::max(F, d.neck[3]);
     RC(dev_alloc(e, (void**)&e->splitk_ws, e->splitk_elems * 4));
+    // side stream of the neck branches (D2S_NO_OVERLAP=1 keeps everything on the caller's stream)
+    for (int i = 0; i < 3; ++i) RC(dev_alloc(e, &e->r1[i], (size_t)B * e->fH[i] * e->fW[i] * F * es));
+    RC(dev_alloc(e, &e->r1tmp, (size_t)B * e->fH[0] * e->fW[0] * F * es));
+    RC(dev_alloc(e, (void**)&e->splitk_ws_side, e->splitk_elems * 4));
+    {
+        const char* no = getenv("D2S_NO_OVERLAP");
+        e->overlap = !(no && atoi(no) != 0);
+        if (e->overlap) {
+            D2S_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+            for (int i = 0; i < 4; ++i) D2S_HIP(hipEventCreateWithFlags(&e->ev_tap[i], hipEventDisableTiming));
+            D2S_HIP(hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
+        }
+    }
     if (d.temporal) {
         // ---- Video-Depth-Anything temporal modules (reference dpt_temporal.py:50-60): layer_3, layer_4, path_4, path_3
         const int tC[4] = {d.neck[2], d.neck[3], F, F};
@@ -696,6 +743,10 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
 
 extern "C" int d2s_engine_destroy(d2s_engine* e) {
     if (!e) return D2S_OK;
+    if (e->side) (void)hipStreamSynchronize(e->side);
+    for (int i = 0; i < 4; ++i) if (e->ev_tap[i]) (void)hipEventDestroy(e->ev_tap[i]);
+    if (e->ev_side) (void)hipEventDestroy(e->ev_side);
+    if (e->side) (void)hipStreamDestroy(e->side);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
     return D2S_OK;

@@ -10,7 +10,8 @@ int launch_cls_rows(const float* cls, const float* pos, float* resid, int B, int
 int launch_layernorm(int prec, const float* x, const float* g, const float* b, void* out, int rows_out, int D, float eps,
                      int rows_per_img, int img_rows, int row_off, hipStream_t st, float fp8_qscale = 0.f);   // > 0: e4m3 output
 int launch_amax(int prec, const void* x, long n, float* slot, hipStream_t st);       // *slot = max(*slot, max |x|); fp8 calibration
-int launch_bilinear_nhwc(int prec, const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t st);
+int launch_bilinear_nhwc(int prec, const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t st,
+                         const void* addend = nullptr);    // out = upsample(in) [+ addend]
 int launch_head_final(int prec, const void* x, const float* w3, float b3, float max_depth, float* depth, long npix, int C, hipStream_t st);
 int launch_to_f32(int prec, const void* in, float* out, long n, hipStream_t st);
 

@@ -109,8 +109,9 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const
 template <typename T>
 __global__ void __launch_bounds__(256)
 bilinear_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo, int C,
-                     float sy, float sx) {
-    // one thread = one output pixel x one 16-byte channel chunk (8 bf16 / 4 f32): 4 x 16-B tap loads, one 16-B store
+                     float sy, float sx, const T* __restrict__ addend) {
+    // one thread = one output pixel x one 16-byte channel chunk (8 bf16 / 4 f32): 4 x 16-B tap loads, one 16-B store.
+    // addend (optional, output-shaped): out = upsample(in) + addend -- the next fusion stage's "fused + RCU1(m)" sum
     constexpr int CE = 16 / sizeof(T);
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,13 +128,15 @@ bilinear_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H
     u32x4 v10 = *(const u32x4*)(base + ((long)ty.i1 * Wi + tx.i0) * C);
     u32x4 v11 = *(const u32x4*)(base + ((long)ty.i1 * Wi + tx.i1) * C);
     const T *p00 = (const T*)&v00, *p01 = (const T*)&v01, *p10 = (const T*)&v10, *p11 = (const T*)&v11;
-    u32x4 r;
+    u32x4 r, av = {0u, 0u, 0u, 0u};
+    if (addend) av = *(const u32x4*)(addend + pix * C + c);
+    const T* pa = (const T*)&av;
     T* o = (T*)&r;
 #pragma unroll
     for (int k = 0; k < CE; ++k) {
         float top = tx.w0 * tof(p00[k]) + tx.w1 * tof(p01[k]);
         float bot = tx.w0 * tof(p10[k]) + tx.w1 * tof(p11[k]);
-        o[k] = cvt<T>(ty.w0 * top + ty.w1 * bot);
+        o[k] = cvt<T>(ty.w0 * top + ty.w1 * bot + tof(pa[k]));
     }
     *(u32x4*)(out + pix * C + c) = r;
 }
@@ -207,14 +210,15 @@ int launch_amax(int prec, const void* x, long n, float* slot, hipStream_t st) {
     return D2S_OK;
 }
 
-int launch_bilinear_nhwc(int prec, const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t st) {
+int launch_bilinear_nhwc(int prec, const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t st,
+                         const void* addend) {
     float sy = linear_scale(Hi, Ho, true), sx = linear_scale(Wi, Wo, true);
     const int ce = prec == D2S_PREC_BF16 ? 8 : 4;
     if (C % ce) { set_error("bilinear_nhwc: channels must be a multiple of the 16-byte chunk"); return D2S_E_INVALID; }
     long total = (long)B * Ho * Wo * (C / ce);
     dim3 grid(cdiv(total, 256)), block(256);
-    DISPATCH_T(prec, hipLaunchKernelGGL(bilinear_nhwc_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)in, (bf16_t*)out, B, Hi, Wi, Ho, Wo, C, sy, sx),
-                     hipLaunchKernelGGL(bilinear_nhwc_kernel<float>, grid, block, 0, st, (const float*)in, (float*)out, B, Hi, Wi, Ho, Wo, C, sy, sx));
+    DISPATCH_T(prec, hipLaunchKernelGGL(bilinear_nhwc_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)in, (bf16_t*)out, B, Hi, Wi, Ho, Wo, C, sy, sx, (const bf16_t*)addend),
+                     hipLaunchKernelGGL(bilinear_nhwc_kernel<float>, grid, block, 0, st, (const float*)in, (float*)out, B, Hi, Wi, Ho, Wo, C, sy, sx, (const float*)addend));
     D2S_CHECK_LAUNCH();
     return D2S_OK;
 }
