@@ -395,7 +395,7 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     const d2s_model_desc& d = e->d;
     const int D = d.hidden, N = e->N, P = e->P, M = B * N, Mp = B * P, prec = e->prec;
     const int F = d.fusion;
-    const bool use_side = e->overlap && e->side != nullptr;
+    const bool use_side = e->overlap && e->side != nullptr && !e->prof_on;   // per-kernel timing passes run un-overlapped
     if (e->fp8 && !e->fp8_ready && !e->calib) {
         set_error("D2S_PREC_FP8 engine: activation scales are not set, call d2s_engine_calibrate first");
         return D2S_E_STATE;

@@ -229,7 +229,7 @@ int d2s_engine_profile_read(d2s_engine* e, int max_classes, double* ms, double* 
 const char* d2s_profile_class_name(int cls);
 
 /* Debug / parity taps: copy an internal activation (after the last d2s_model_forward) to a
- * caller device buffer as float32.  name: "embeddings", "layer<N>", "neck_feat<i>", "fused<i>".
+ * caller device buffer as float32.  name: "embeddings", "layer<N>" (engines created with D2S_TAPS=1), "neck_feat<i>".
  * rows/cols describe [rows, cols] of frame 0 (tokens x D, or pixels x C, NHWC). */
 int d2s_engine_tap(d2s_engine* e, const char* name, float* out, uint64_t out_elems,
                    int* rows, int* cols, void* stream);
