@@ -559,6 +559,116 @@ splitk_reduce_kernel(GemmEpi e, int M, int N) {
     epilogue_dispatch<T>(e, m, n0, v);
 }
 
+// ================================================================================================
+// 3x3 convolution (stride 1, pad 1, NHWC) with the INPUT resident in LDS.  The implicit-GEMM loader above fetches
+// every input pixel nine times from L2 (once per tap); here a block owns an 8 x 16 output tile, loads its 10 x 18 x C
+// input halo ONCE (zero outside the image, ReLU-on-load applied at that point), and the K loop (9 taps x C) only
+// streams the weights (LDS-DMA, two stages).  A fragment of tile row ty, tap (ky, kx) is halo pixel
+// (ty + ky, fr + kx): 16 consecutive pixels per fragment, chunk index XOR-ed with the pixel index so the 16 lanes hit
+// 16 different bank groups.  Same MFMA fragments, accumulators and epilogues as gemm_glds_kernel.
+// Requirements (checked by the launcher): C * sizeof(T) a multiple of 128 (a K tile lies inside one tap), at most
+// 16 chunks per pixel (C <= 128 bf16 / 64 f32), MAP_ROWS without row remapping, N >= 64.  Measured at batch 16:
+// 84x148 RCU convs 118 -> 100 us (606 TFLOP/s), 42x74 45 -> 33 us, head conv1 271 -> 241 us.
+// ================================================================================================
+template <typename T, int BN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN)
+conv3_halo_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
+    constexpr int CE = Prec<T>::CE, CPR = 8, BK = CPR * CE, NS = 2;
+    constexpr int TW = 16, TH = 8, BM = TH * TW, HWD = TW + 2, HPX = (TH + 2) * HWD;
+    constexpr int HCPP = 16;                            // capacity: 16-byte chunks per input pixel
+    constexpr int NW = WM * WN, RPI = 64 / CPR;
+    constexpr int BI = BN / (RPI * NW);
+    static_assert(BI >= 1 && BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "bad tile split");
+    constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+    constexpr int STAGE = BN * CPR;
+    __shared__ __attribute__((aligned(16))) u32x4 lds[NS * STAGE + HPX * HCPP];
+    u32x4* const halo = lds + NS * STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wid / WN, wave_n = wid % WN;
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    const int nimg = M / (a.Ho * a.Wo);
+    int tm_, tn_;
+    if (!tile_of_block(blockIdx.x, nimg * tiles_y * tiles_x, (N + BN - 1) / BN, xn, tm_, tn_)) return;
+    const int b = tm_ / (tiles_y * tiles_x), ty0 = ((tm_ / tiles_x) % tiles_y) * TH, tx0 = (tm_ % tiles_x) * TW;
+    const int bn0 = tn_ * BN;
+    const int cpp = a.C / CE, smask = cpp - 1;          // chunks per pixel: a power of two <= 16
+
+    // ---- the input halo, once
+    {
+        const T* img = (const T*)a.ptr + (long)b * a.Hi * a.Wi * a.C;
+        for (int idx = tid; idx < HPX * cpp; idx += 64 * NW) {
+            const int p = idx / cpp, c = idx - p * cpp;
+            const int hy = p / HWD, hx = p - hy * HWD;
+            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) v = *(const u32x4*)(img + ((long)iy * a.Wi + ix) * a.C + c * CE);
+            if (a.relu) v = relu_frag(v, 0, T());
+            halo[p * cpp + (c ^ (p & smask))] = v;
+        }
+    }
+    // ---- weights: LDS-DMA ring, as in gemm_glds_kernel
+    const int lrow = wid * RPI + lane / CPR;
+    const int src_chunk = (lane % CPR) ^ swz_row<CPR>(lrow);
+    const T* wrow = W + (long)(bn0 + lrow) * Kpad + src_chunk * CE;
+#define D2S_ISSUE_W(KT)                                                                                               \
+    {                                                                                                                 \
+        u32x4* st_ = lds + ((KT) % NS) * STAGE;                                                                       \
+        _Pragma("unroll") for (int i = 0; i < BI; ++i)                                                                \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow + (long)(RPI * NW * i) * Kpad + (KT) * BK), \
+                                             (__attribute__((address_space(3))) void*)(st_ + (i * NW + wid) * 64), 16, 0, 0);              \
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nkt = K / BK, kpt = cpp / CPR;             // K tiles in all, K tiles per tap
+    const int fr = lane & 15, fg = lane >> 4;
+    D2S_ISSUE_W(0)
+    int tap = 0, sub = 0;                                // kt = tap * kpt + sub
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // my W loads of tile kt (and, first time, my halo stores)
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nkt) D2S_ISSUE_W(kt + 1)
+        const int ky = tap / 3, kx = tap - ky * 3, cb = sub * CPR;
+        const u32x4* B_l = lds + (kt % NS) * STAGE + (wave_n * (BN / WN)) * CPR;
+#pragma unroll
+        for (int ks = 0; ks < CPR / 4; ++ks) {
+            u32x4 fb[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) { int r = j * 16 + fr; fb[j] = B_l[r * CPR + ((ks * 4 + fg) ^ swz_row<CPR>(r))]; }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int p = (wave_m * FM + i + ky) * HWD + fr + kx;
+                const u32x4 fa = halo[p * cpp + ((cb + ks * 4 + fg) ^ (p & smask))];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma_chunk(acc[i][j], fb[j], fa, T());
+            }
+        }
+        if (++sub == kpt) { sub = 0; ++tap; }
+    }
+#undef D2S_ISSUE_W
+    // ---- epilogue: tile row ty -> output pixel (ty0 + ty, tx0 + fr)
+    const int x = tx0 + fr;
+    static_for<FM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int y = ty0 + wave_m * FM + i;
+        if (y < a.Ho && x < a.Wo) {
+            const int m = (b * a.Ho + y) * a.Wo + x;
+            static_for<FN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int n0 = bn0 + wave_n * (BN / WN) + j * 16 + fg * 4;
+                if (n0 < N) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    epilogue_dispatch<T>(e, m, n0, v);
+                }
+            });
+        }
+    });
+}
+
 // pick the XCD grid (xn x 8/xn) for a tiles_m x tiles_n tile space: least padding, W chunk within L2
 static int pick_xn(int tiles_m, int tiles_n, int BN, int Kpad, size_t es, unsigned& grid) {
     static const int force = getenv("D2S_GEMM_XN") ? atoi(getenv("D2S_GEMM_XN")) : -1;
@@ -601,11 +711,38 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
     hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn);
 }
 
+// stride-1 3x3 convs on the large maps go to conv3_halo_kernel (input tile resident in LDS); D2S_NO_HALO=1 keeps the
+// implicit-GEMM loader (the parity tests run both)
+template <typename T>
+static bool launch_conv_halo(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
+    static const bool off = getenv("D2S_NO_HALO") && atoi(getenv("D2S_NO_HALO")) != 0;
+    if (off) return false;
+    if constexpr (std::is_same<T, fp8_t>::value) return false;
+    else {
+    const int cpp = a.C * (int)sizeof(T) / 16;
+    if (a.mode != A_CONV3 || a.stride != 1 || a.Hi != a.Ho || a.Wi != a.Wo || (a.C * (int)sizeof(T)) % 128 || cpp > 16 || (cpp & (cpp - 1))) return false;
+    if (e.map != MAP_ROWS || e.rows_per_img || K != 9 * a.C || N <= 32) return false;   // (the N = 32 head conv measured 20 % slower here)
+    const int nimg = M / (a.Ho * a.Wo);
+    const long tiles_m = (long)nimg * cdiv(a.Ho, 8) * cdiv(a.Wo, 16);
+    if (tiles_m * cdiv(N, 128) < 200 || (long)nimg * a.Ho * a.Wo != M) return false;      // small maps: too few tiles, latency-bound anyway
+    GemmEpi e1 = e; e1.ksplit = 1;
+    unsigned grid = 0;
+#define D2S_HALO(BN_, WM_, WN_)                                                                                       \
+    { int xn = pick_xn((int)tiles_m, cdiv(N, BN_), BN_, Kpad, sizeof(T), grid);                                       \
+      hipLaunchKernelGGL((conv3_halo_kernel<T, BN_, WM_, WN_>), dim3(grid), dim3(64 * WM_ * WN_), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn); }
+    if (N <= 64) D2S_HALO(64, 4, 2)
+    else D2S_HALO(128, 2, 4)
+#undef D2S_HALO
+    return true;
+    }
+}
+
 template <typename T>
 static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
     static const bool v1 = getenv("D2S_GEMM_V1") && atoi(getenv("D2S_GEMM_V1")) != 0;
     static const int force_tile = getenv("D2S_GEMM_TILE") ? atoi(getenv("D2S_GEMM_TILE")) : 0;
     if (tile == 0) tile = force_tile;
+    if (tile == 0 && launch_conv_halo<T>(a, W, M, N, K, Kpad, e, st)) { D2S_CHECK_LAUNCH(); return D2S_OK; }
     if (tile == 0) {
         // Measured on the ViT-B shapes at batch 1..32 (tools/gemm_bench.py, profiles/r1_05): what matters most is 16-24
         // resident waves per CU in DIFFERENT phases of the K loop (8-wave blocks, 2-5 blocks per CU), then tile intensity;
