@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--vda", action="store_true",
                     help="streaming Video-Depth-Anything (BASELINE config 4): one stream per GPU, batch 1, 32-frame window")
+    ap.add_argument("--mixed", type=int, default=0,
+                    help="extra measurement (N=1): BASELINE config 5, this many frames per step drawn with seed 0 from "
+                         "{1280x720, 1920x1080, 2560x1440} -- one batched model pass, per-size pre-process and warp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -170,7 +173,8 @@ def main():
         weights = make_vda_weights(cfg, 0)
     else:
         weights = make_weights(cfg, 0)
-    eng = ops.Engine(cfg, weights, h, w, max_batch=max(B, B2), precision=args.precision, device=local_rank, temporal=args.vda)
+    NM = args.mixed if (world == 1 and not args.vda) else 0
+    eng = ops.Engine(cfg, weights, h, w, max_batch=max(B, B2, NM), precision=args.precision, device=local_rank, temporal=args.vda)
     default_wl = (args.model, args.precision, args.res, H, W, args.vda) == ("vitb", "bf16", 518, 1080, 1920, False)
     if args.precision == "fp8":     # static activation scales from two structured frames (outside the timed region)
         eng.calibrate(torch.cat([ops.preprocess(torch.from_numpy(synth.structured_frame(H, W, s)).to(dev), args.res) for s in (0, 1)][:max(B, B2)]))
@@ -245,6 +249,30 @@ def main():
             pr.pop("model_gflop_per_frame_counted", None)
             batched.update(pr)
         result["batched"] = batched
+
+    if NM:
+        # config 5: every 16:9 size maps to the same model input (reference depth.py:676-706), so the model runs as ONE
+        # batch of NM frames; only pre-process (A2-A4) and the warp (A13+A14) are per frame size
+        sizes = [(720, 1280), (1080, 1920), (1440, 2560)]
+        pick = np.random.default_rng(0).integers(0, 3, NM)
+        groups = {s: [i for i in range(NM) if sizes[pick[i]] == s] for s in sizes}
+        assert len({engine_shape(hh, ww, args.res)[:2] for hh, ww in sizes}) == 1
+        frames = {s: torch.from_numpy(np.stack([synth.noise_frame(s[0], s[1], 7000 + i) for i in idx])).to(dev) for s, idx in groups.items() if idx}
+        outs = {s: torch.empty((len(groups[s]),) + ops.sbs_shape(s[0], s[1], sp) + (3,), dtype=torch.uint8, device=dev) for s in frames}
+        xm = torch.empty((NM, 3, h, w), dtype=torch.float32, device=dev)
+
+        def step_mixed(i):
+            for s, f in frames.items():
+                xm[groups[s]] = ops.preprocess(f, args.res)
+            depth = ops.post_process_depth(eng(xm), p)
+            for s, f in frames.items():
+                outs[s].copy_(ops.make_sbs(f, depth[groups[s]], sp))
+        stepsm = max(5, args.steps // NM)
+        dtm = timed(step_mixed, 2, stepsm)
+        result["mixed"] = {"value": stepsm * NM / dtm, "unit": "stereo frames/s", "frames_per_step": NM, "steps": stepsm,
+                           "ms_per_step": 1e3 * dtm / stepsm,
+                           "workload": f"{NM} frames/step, sizes seed 0: " + ", ".join(f"{len(groups[s])}x{s[1]}x{s[0]}" for s in sizes)
+                                       + f"; one {cfg.name} {args.precision} batch at {h}x{w}; {args.mode}"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, weights, p, H, W, args.mode)

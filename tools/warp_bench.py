@@ -21,3 +21,16 @@ for mode in ("Full-SBS", "Half-SBS", "Full-TAB", "Half-TAB"):
     us = e0.elapsed_time(e1) / n * 1e3
     byts = B * (H * W * 3 + 294 * 518 * 4 + oh * ow * 3)
     print(f"{mode:9s} B={B} {W}x{H}: {us:8.1f} us  {byts/us/1e6:7.3f} TB/s algorithmic ({byts/1e6:.2f} MB)  [incl. output alloc]", flush=True)
+# the viewer-shader warp with disocclusion in-painting (d2s_dibr_warp): full-resolution depth in, both eyes out
+depf = torch.from_numpy(np.stack([synth.smooth_depth(H, W, i) for i in range(B)])).to(dev)
+for mode in ("Full-SBS", "Half-SBS"):
+    dp = ops.dibr_params(0.064, 4.0, 0.0, mode)
+    for _ in range(5): ops.dibr_warp(img, depf, dp)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 50; e0.record()
+    for _ in range(n): out = ops.dibr_warp(img, depf, dp)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    byts = B * (H * W * 3 + H * W * 4) + out.numel()
+    print(f"DIBR {mode:9s} B={B} {W}x{H}: {us:8.1f} us  {byts/us/1e6:7.3f} TB/s algorithmic ({byts/1e6:.2f} MB)  [incl. output alloc]", flush=True)
