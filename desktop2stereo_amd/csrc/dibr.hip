@@ -26,7 +26,13 @@ struct DibrGeom {
     float w1[16], w2[16];  // exp(-i*0.15), exp(-i*0.2)
 };
 
-__device__ __forceinline__ int wrapi(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+// GL_REPEAT index: one conditional add / subtract covers every coordinate within one period of the texture (all but
+// absurd parallax settings); the integer modulo (~25 instructions on this ISA) is the fallback
+__device__ __forceinline__ int wrapi(int i, int n) {
+    if (i < 0) i += n; else if (i >= n) i -= n;
+    if ((unsigned)i >= (unsigned)n) { i %= n; if (i < 0) i += n; }
+    return i;
+}
 
 struct TexTap { int x0, x1, y0, y1; float fx, fy; };
 __device__ __forceinline__ TexTap tex_tap(float u, float v, int H, int W) {
@@ -114,14 +120,9 @@ __device__ void push_pull(const uint8_t* __restrict__ rgb, const float* __restri
     tex_color(rgb, g.H, g.W, u, v, out);                                              // :505
 }
 
-template <int OUT_FMT>
-__global__ void __launch_bounds__(256)
-dibr_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ dep_all, void* __restrict__ out_all, DibrGeom g) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y % g.oh, eye = blockIdx.y / g.oh, b = blockIdx.z;
-    if (x >= g.ow) return;
-    const uint8_t* rgb = rgb_all + (long)b * g.H * g.W * 3;
-    const float* dep = dep_all + (long)b * g.H * g.W;
+// one output pixel of one eye: FRAGMENT_SHADER.main (:533-631) -> colour * alpha
+__device__ __forceinline__ void dibr_pixel(const uint8_t* __restrict__ rgb, const float* __restrict__ dep, const DibrGeom& g,
+                                           int x, int y, int eye, float outc[3]) {
     const float eye_offset = eye ? g.half_ipd : -g.half_ipd;                          // :2701, 2714
     const float sg = eye_offset > 0.f ? 1.f : (eye_offset < 0.f ? -1.f : 0.f);
     const float parx = g.c * sg, pary = g.s * sg;                                     // :540
@@ -164,14 +165,30 @@ dibr_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ dep_a
 #pragma unroll
         for (int k = 0; k < 3; ++k) col[k] *= sh;
     }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) outc[k] = col[k] * alpha;
+}
+
+// one thread = one output pixel of one eye.  (4 pixels per thread with packed dword stores measured SLOWER -- 113 -> 120 us
+// Full-SBS, 38 -> 97 us Half-SBS at 1080p: the kernel lives on the locality of neighbouring threads' gathers, not on
+// its stores.)
+template <int OUT_FMT>
+__global__ void __launch_bounds__(256)
+dibr_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ dep_all, void* __restrict__ out_all, DibrGeom g) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y % g.oh, eye = blockIdx.y / g.oh, b = blockIdx.z;
+    if (x >= g.ow) return;
+    const uint8_t* rgb = rgb_all + (long)b * g.H * g.W * 3;
+    const float* dep = dep_all + (long)b * g.H * g.W;
     const bool sbs = g.mode == D2S_MODE_HALF_SBS || g.mode == D2S_MODE_FULL_SBS;
     const int ox = sbs ? eye * g.ow + x : x, oy = sbs ? y : eye * g.oh + y;
     const long o = (((long)b * g.out_h + oy) * g.out_w + ox) * 3;
+    float c[3];
+    dibr_pixel(rgb, dep, g, x, y, eye, c);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        float r = col[k] * alpha;
-        if (OUT_FMT == D2S_FMT_U8_HWC) ((uint8_t*)out_all)[o + k] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(r, 0, 0);
-        else ((float*)out_all)[o + k] = r;
+        if (OUT_FMT == D2S_FMT_U8_HWC) ((uint8_t*)out_all)[o + k] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(c[k], 0, 0);
+        else ((float*)out_all)[o + k] = c[k];
     }
 }
 
