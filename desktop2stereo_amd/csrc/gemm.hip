@@ -4,7 +4,6 @@
 //    exact fp32), fp32 accumulate;
 //  * tile BM x BN x 128 bytes of K, WM x WN waves; two data paths for the K tiles (gemm_glds_kernel): LDS-DMA into an
 //    NS-stage ring, or register staging into two LDS stages (STG) -- the tile rule in launch_t picks per launch;
-//    gemm_kernel below is the round-0 baseline kept behind D2S_GEMM_V1;
 //  * both operands are K-contiguous; a 16-byte chunk per lane is the unit everywhere:
 //      global -> LDS (16 B/lane, 8 lanes cover one 128-B row = full cache lines), chunk XOR-swizzle
 //      phys = chunk ^ ((row >> 1) & 7), applied on the source address for LDS-DMA
@@ -14,8 +13,8 @@
 //  * operands are swapped (first = W rows, second = A rows) so each lane ends up with 4 consecutive
 //    n for one m: bias / LayerScale / residual / output move as 8- or 16-byte vectors;
 //  * the A loader is either a plain row-major matrix or an implicit 3x3 (pad 1, stride 1|2)
-//    convolution over an NHWC activation, with optional ReLU-on-load (pre-activation units);
-//  * double-buffered LDS, register-staged prefetch of the next K tile, one barrier per tile.
+//    convolution over an NHWC activation, with optional ReLU-on-load (pre-activation units); stride-1 convs on
+//    the large maps use conv3_halo_kernel (input tile resident in LDS) instead.
 #include "gemm.h"
 #include <type_traits>
 
@@ -29,19 +28,6 @@ template <typename T> struct Prec;
 template <> struct Prec<bf16_t> { static constexpr int CE = 8; };   // elements per 16-byte chunk
 template <> struct Prec<float>  { static constexpr int CE = 4; };
 template <> struct Prec<fp8_t>  { static constexpr int CE = 16; };  // e4m3: a 128-byte K tile holds 128 elements
-
-__device__ __forceinline__ u32x4 relu_chunk(u32x4 v, bf16_t) {
-    uint32_t* p = (uint32_t*)&v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { uint32_t m = ((p[i] >> 15) & 0x00010001u) * 0xffffu; p[i] &= ~m; }
-    return v;
-}
-__device__ __forceinline__ u32x4 relu_chunk(u32x4 v, float) {
-    float* p = (float*)&v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = fmaxf(p[i], 0.f);
-    return v;
-}
 
 __device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& w, const u32x4& a, bf16_t) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w, *(const bf16x8*)&a, acc, 0, 0, 0);
@@ -175,123 +161,8 @@ __device__ __forceinline__ bool tile_of_block(int bid, int tiles_m, int tiles_n,
     return true;
 }
 
-template <typename T, int BM, int BN>
-__global__ void __launch_bounds__(256)
-gemm_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
-    constexpr int CE = Prec<T>::CE;
-    constexpr int BK = 8 * CE;                 // 128-byte K tile
-    constexpr int AI = BM / 32, BI = BN / 32;  // chunks per thread per tile
-    constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave
-    __shared__ __attribute__((aligned(16))) u32x4 lds[2][(BM + BN) * 8];
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wave_m = wid >> 1, wave_n = wid & 1;
-    int tm_, tn_;
-    if (!tile_of_block(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, xn, tm_, tn_)) return;
-    const int bm0 = tm_ * BM, bn0 = tn_ * BN;
-    const int lrow = tid >> 3, lchunk = tid & 7;
-
-    // ---- per-thread A row descriptors (fixed across K tiles)
-    const T* arow[AI];
-    int aiy[AI], aix[AI];
-    bool aok[AI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        int m = bm0 + lrow + 32 * i;
-        aok[i] = m < M;
-        int mm = aok[i] ? m : 0;
-        if (a.mode == A_PLAIN) { arow[i] = (const T*)a.ptr + (long)mm * a.lda; aiy[i] = aix[i] = 0; }
-        else {
-            int ox = mm % a.Wo, oy = (mm / a.Wo) % a.Ho, b = mm / (a.Wo * a.Ho);
-            aiy[i] = oy * a.stride - 1; aix[i] = ox * a.stride - 1;
-            arow[i] = (const T*)a.ptr + (long)b * a.Hi * a.Wi * a.C;
-        }
-    }
-    const T* wrow = W + (long)(bn0 + lrow) * Kpad + lchunk * CE;
-
-    u32x4 ra[AI], rb[BI];
-    // (macros, not lambdas: by-reference captures of the staging arrays end up in scratch)
-#define D2S_LOAD_TILE(KT)                                                                                        \
-    {                                                                                                            \
-        const int k_ = (KT) * BK + lchunk * CE;                                                                  \
-        if (a.mode == A_PLAIN) {                                                                                 \
-            _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                     \
-                u32x4 z_ = (u32x4){0u, 0u, 0u, 0u};                                                               \
-                if (aok[i] && k_ < K) z_ = *(const u32x4*)(arow[i] + k_);                                        \
-                ra[i] = z_;                                                                                      \
-            }                                                                                                    \
-        } else {                                                                                                 \
-            int tap_ = k_ / a.C, c0_ = k_ - tap_ * a.C;                                                          \
-            int ky_ = tap_ / 3, kx_ = tap_ - ky_ * 3;                                                            \
-            _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                     \
-                int iy_ = aiy[i] + ky_, ix_ = aix[i] + kx_;                                                      \
-                u32x4 z_ = (u32x4){0u, 0u, 0u, 0u};                                                               \
-                if (aok[i] && k_ < K && iy_ >= 0 && iy_ < a.Hi && ix_ >= 0 && ix_ < a.Wi)                        \
-                    z_ = *(const u32x4*)(arow[i] + ((long)iy_ * a.Wi + ix_) * a.C + c0_);                        \
-                ra[i] = z_;                                                                                      \
-            }                                                                                                    \
-        }                                                                                                        \
-        if (a.relu) { _Pragma("unroll") for (int i = 0; i < AI; ++i) ra[i] = relu_chunk(ra[i], T()); }           \
-        _Pragma("unroll") for (int i = 0; i < BI; ++i) rb[i] = *(const u32x4*)(wrow + (long)(32 * i) * Kpad + (KT) * BK); \
-    }
-#define D2S_STORE_TILE(BUF)                                                                                      \
-    {                                                                                                            \
-        u32x4* A_s = lds[BUF];                                                                                   \
-        u32x4* B_s = lds[BUF] + BM * 8;                                                                          \
-        _Pragma("unroll") for (int i = 0; i < AI; ++i) { int r = lrow + 32 * i; A_s[r * 8 + (lchunk ^ ((r >> 1) & 7))] = ra[i]; } \
-        _Pragma("unroll") for (int i = 0; i < BI; ++i) { int r = lrow + 32 * i; B_s[r * 8 + (lchunk ^ ((r >> 1) & 7))] = rb[i]; } \
-    }
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nkt = Kpad / BK;
-    D2S_LOAD_TILE(0)
-    D2S_STORE_TILE(0)
-    __syncthreads();
-    const int fr = lane & 15, fg = lane >> 4;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) D2S_LOAD_TILE(kt + 1)
-        const u32x4* A_l = lds[kt & 1] + (wave_m * (BM / 2)) * 8;
-        const u32x4* B_l = lds[kt & 1] + BM * 8 + (wave_n * (BN / 2)) * 8;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 fa[FM], fb[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) { int r = i * 16 + fr; fa[i] = A_l[r * 8 + ((ks * 4 + fg) ^ ((r >> 1) & 7))]; }
-#pragma unroll
-            for (int j = 0; j < FN; ++j) { int r = j * 16 + fr; fb[j] = B_l[r * 8 + ((ks * 4 + fg) ^ ((r >> 1) & 7))]; }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) mma_chunk(acc[i][j], fb[j], fa[i], T());
-        }
-        if (kt + 1 < nkt) D2S_STORE_TILE((kt + 1) & 1)
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane holds n = n0..n0+3 for m
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        int m = bm0 + wave_m * (BM / 2) + i * 16 + fr;
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            int n0 = bn0 + wave_n * (BN / 2) + j * 16 + fg * 4;
-            if (n0 >= N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v);
-            else epilogue4<T>(e, m, n0, v);
-        }
-    }
-}
-
-
 // ================================================================================================
-// v2: LDS-DMA ring.  Same tile / fragment / epilogue design as gemm_kernel, but the K tiles travel
+// LDS-DMA ring.  The K tiles travel
 // global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging VGPRs, no
 // ds_write pass) into a ring of NS stages, PD = NS-1 tiles ahead, with counted vmcnt and ONE raw
 // s_barrier per tile:
@@ -739,7 +610,6 @@ static bool launch_conv_halo(const GemmA& a, const void* W, int M, int N, int K,
 
 template <typename T>
 static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
-    static const bool v1 = getenv("D2S_GEMM_V1") && atoi(getenv("D2S_GEMM_V1")) != 0;
     static const int force_tile = getenv("D2S_GEMM_TILE") ? atoi(getenv("D2S_GEMM_TILE")) : 0;
     if (tile == 0) tile = force_tile;
     if (tile == 0 && launch_conv_halo<T>(a, W, M, N, K, Kpad, e, st)) { D2S_CHECK_LAUNCH(); return D2S_OK; }
@@ -760,17 +630,8 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
         else if (b64 >= 384) tile = 64648;
         else tile = 3264;                           // skinny launches (batch 1, N = 768): more, smaller blocks
     }
-    if (v1 && (tile == 128 || tile == 64) && !std::is_same<T, fp8_t>::value) {
-        if constexpr (!std::is_same<T, fp8_t>::value) {
-            unsigned grid = 0;
-            if (tile == 128) { int xn = pick_xn(cdiv(M, 128), cdiv(N, 128), 128, Kpad, sizeof(T), grid);
-                hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), dim3(grid), dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn); }
-            else { int xn = pick_xn(cdiv(M, 64), cdiv(N, 64), 64, Kpad, sizeof(T), grid);
-                hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), dim3(grid), dim3(256), 0, st, a, (const T*)W, M, N, K, Kpad, e, xn); }
-        }
-    }
     // LDS-DMA ring (NS stages)
-    else if (tile == 256128) launch_glds<T, 256, 128, 4, 2, 3>(a, W, M, N, K, Kpad, e, st);
+    if (tile == 256128) launch_glds<T, 256, 128, 4, 2, 3>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 128) launch_glds<T, 128, 128, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 64) launch_glds<T, 64, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 3264) launch_glds<T, 32, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
