@@ -206,7 +206,7 @@ stereo_warp_generic(const void* __restrict__ rgb, const float* __restrict__ dept
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fast path (the bench configuration): u8 HWC in, u8 HWC out, no padding, even W.
+// Fast path (the bench configuration): u8 HWC in, u8 HWC out, no padding, W % 4 == 0.
 // One thread per 4 consecutive SOURCE pixels of one row: the depth sample / shift is computed once
 // and shared by both eyes; the source row window is staged through LDS with coalesced dword reads;
 // each eye's 4 (Full) or 2 (Half-SBS) output pixels leave as one 12-/6-byte store.
@@ -217,123 +217,8 @@ constexpr int FP_TW = 256 * FP_PX;          // tile width in source pixels
 constexpr int FP_MARGIN = 64;               // staged halo each side (pixels); beyond it -> global fallback
 constexpr int FP_LDS_PX = FP_TW + 2 * FP_MARGIN;
 
-template <int MODE>
-__global__ void __launch_bounds__(256)
-stereo_warp_fast(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
-                 int B, WarpGeom g) {
-    __shared__ __attribute__((aligned(16))) uint8_t srow[FP_LDS_PX * 3 + 16];
-    __shared__ float drow[FP_TW + 8];       // vertically interpolated depth row segment (dw <= W: dispatcher)
-    const int tiles_x = (g.W + FP_TW - 1) / FP_TW;
-    int bid = blockIdx.x;
-    int tx = bid % tiles_x;
-    int y = (bid / tiles_x) % g.H;
-    int b = bid / (tiles_x * g.H);
-    const int xa = tx * FP_TW;
-    const uint8_t* src_row = rgb + ((long)b * g.H + y) * (long)g.W * 3;
-    // ---- stage source window [xa - M, xa + TW + M) clipped to [0, W) : coalesced 4-byte reads
-    int wx0 = xa - FP_MARGIN; if (wx0 < 0) wx0 = 0;
-    int wx1 = xa + FP_TW + FP_MARGIN; if (wx1 > g.W) wx1 = g.W;
-    {
-        long byte0 = (long)wx0 * 3;
-        long byte1 = (long)wx1 * 3;
-        long a0 = byte0 & ~3L;                                  // row base is 4-aligned when W*3 % 4 == 0 (dispatcher)
-        int nwords = (int)((byte1 - a0 + 3) >> 2);
-        const uint32_t* gp = (const uint32_t*)(src_row + a0);
-        uint32_t* lp = (uint32_t*)srow;
-        long row_bytes = (long)g.W * 3;
-        for (int i = threadIdx.x; i < nwords; i += 256) {
-            uint32_t v;
-            if (a0 + 4L * i + 4 <= row_bytes) v = gp[i];
-            else { v = 0; for (int k = 0; k < 4; ++k) if (a0 + 4L * i + k < row_bytes) v |= (uint32_t)src_row[a0 + 4L * i + k] << (8 * k); }
-            lp[i] = v;
-        }
-    }
-    const int lds_byte0 = (int)(((long)wx0 * 3) & 3L) - wx0 * 3;   // srow index of pixel x byte c = x*3 + c + lds_byte0
-    // ---- stage depth: vertical lerp of the two depth rows over the needed column span
-    const float* dep = depth + (long)b * g.dh * g.dw;
-    Tap ty = linear_tap(y, g.dsy, g.dh, false);
-    int xe = xa + FP_TW - 1; if (xe > g.W - 1) xe = g.W - 1;
-    int dxa = linear_tap(xa, g.dsx, g.dw, false).i0;
-    int dxb = linear_tap(xe, g.dsx, g.dw, false).i1;
-    int dn = dxb - dxa + 1;
-    for (int i = threadIdx.x; i < dn; i += 256)
-        drow[i] = ty.w0 * dep[ty.i0 * g.dw + dxa + i] + ty.w1 * dep[ty.i1 * g.dw + dxa + i];
-    __syncthreads();
-
-    const int x_base = xa + threadIdx.x * FP_PX;
-    if (x_base >= g.W) return;
-    float shift[FP_PX];
-#pragma unroll
-    for (int k = 0; k < FP_PX; ++k) {
-        int x = x_base + k; if (x > g.W - 1) x = g.W - 1;
-        Tap t = linear_tap(x, g.dsx, g.dw, false);
-        float d = t.w0 * drow[t.i0 - dxa] + t.w1 * drow[t.i1 - dxa] - g.conv;
-        shift[k] = ((-d * g.ratio) * g.max_px) * 0.05f;
-    }
-    const float span = (float)(g.W - 1);
-    const long per = (long)g.out_h * g.out_w;
-#pragma unroll
-    for (int eye = 0; eye < 2; ++eye) {
-        float px[FP_PX][3];
-#pragma unroll
-        for (int k = 0; k < FP_PX; ++k) {
-            int x = x_base + k;
-            float sx = reflect_clip((float)x + (eye ? -shift[k] : shift[k]), span);
-            int x0 = (int)sx;
-            float w1 = sx - (float)x0, w0 = 1.0f - w1;
-            int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
-            const uint8_t *p0, *p1;
-            if (x0 >= wx0 && x1 < wx1) { p0 = srow + x0 * 3 + lds_byte0; p1 = srow + x1 * 3 + lds_byte0; }
-            else { p0 = src_row + (long)x0 * 3; p1 = src_row + (long)x1 * 3; }      // rare: shift beyond halo
-#pragma unroll
-            for (int c = 0; c < 3; ++c) px[k][c] = w0 * (float)p0[c] + w1 * (float)p1[c];
-        }
-        if (x_base + FP_PX <= g.W) {
-            if (MODE == D2S_MODE_FULL_SBS || MODE == D2S_MODE_FULL_TAB) {
-                long row = (MODE == D2S_MODE_FULL_SBS) ? y : (long)eye * g.H + y;
-                long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + x_base : x_base;
-                uint32_t w[3];
-                uint8_t bytes[12];
-#pragma unroll
-                for (int k = 0; k < FP_PX; ++k)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) bytes[k * 3 + c] = to_u8(px[k][c]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    w[i] = bytes[4 * i] | (bytes[4 * i + 1] << 8) | (bytes[4 * i + 2] << 16) | ((uint32_t)bytes[4 * i + 3] << 24);
-                uint32_t* o = (uint32_t*)(out + (b * per + row * g.out_w + col) * 3);
-                o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
-            } else {  // HALF_SBS: cat columns (eye*W + x) pair up; W even and x_base % 4 == 0
-                long col = ((long)eye * g.W + x_base) >> 1;
-                uint8_t* o = out + (b * per + (long)y * g.out_w + col) * 3;
-                uint8_t bytes[6];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    bytes[c] = to_u8((px[0][c] + px[1][c]) * 0.5f);
-                    bytes[3 + c] = to_u8((px[2][c] + px[3][c]) * 0.5f);
-                }
-                uint16_t* o16 = (uint16_t*)o;                       // 6-byte aligned to 2
-                o16[0] = bytes[0] | (bytes[1] << 8); o16[1] = bytes[2] | (bytes[3] << 8); o16[2] = bytes[4] | (bytes[5] << 8);
-            }
-        } else {  // ragged tail of the row: per-pixel stores
-            for (int k = 0; k < FP_PX && x_base + k < g.W; ++k) {
-                if (MODE == D2S_MODE_FULL_SBS || MODE == D2S_MODE_FULL_TAB) {
-                    long row = (MODE == D2S_MODE_FULL_SBS) ? y : (long)eye * g.H + y;
-                    long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + x_base + k : x_base + k;
-                    uint8_t* o = out + (b * per + row * g.out_w + col) * 3;
-                    for (int c = 0; c < 3; ++c) o[c] = to_u8(px[k][c]);
-                } else if ((k & 1) == 0 && x_base + k + 1 < g.W) {
-                    long col = ((long)eye * g.W + x_base + k) >> 1;
-                    uint8_t* o = out + (b * per + (long)y * g.out_w + col) * 3;
-                    for (int c = 0; c < 3; ++c) o[c] = to_u8((px[k][c] + px[k + 1][c]) * 0.5f);
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Streaming version of the fast path (v2): persistent blocks walk (frame, row, tile) items with a
+// Streaming fast path (Full-SBS / Full-TAB / Half-SBS): persistent blocks walk (frame, row, tile) items with a
 // balanced grid; the NEXT item's source window and depth rows are prefetched into registers while
 // the current one is computed (global latency hidden, one barrier per item); the source window is
 // unpacked once into one RGBX dword per pixel in LDS, so a bilinear tap pair is two ds_read_b32
@@ -675,25 +560,15 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
             dim3 grid((unsigned)((long)tiles_x * (H / 2) * batch));
             hipLaunchKernelGGL(stereo_warp_fast_halftab, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
         } else {
-            dim3 grid((unsigned)((long)tiles_x * H * batch));
-            static const bool warp_v1 = getenv("D2S_WARP_V1") && atoi(getenv("D2S_WARP_V1")) != 0;
-            if (!warp_v1) {
-                long rows = (long)H * batch;
-                long rounds = (rows * tiles_x + 256 * 6 - 1) / (256 * 6);   // balanced persistent grid: every block walks `rounds` rows
-                dim3 pgrid((unsigned)((rows + rounds - 1) / rounds), tiles_x);
-                if (g.mode == D2S_MODE_FULL_SBS)
-                    hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
-                else if (g.mode == D2S_MODE_FULL_TAB)
-                    hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
-                else
-                    hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_HALF_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
-            } else
+            long rows = (long)H * batch;
+            long rounds = (rows * tiles_x + 256 * 6 - 1) / (256 * 6);   // balanced persistent grid: every block walks `rounds` rows
+            dim3 pgrid((unsigned)((rows + rounds - 1) / rounds), tiles_x);
             if (g.mode == D2S_MODE_FULL_SBS)
-                hipLaunchKernelGGL(stereo_warp_fast<D2S_MODE_FULL_SBS>, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+                hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
             else if (g.mode == D2S_MODE_FULL_TAB)
-                hipLaunchKernelGGL(stereo_warp_fast<D2S_MODE_FULL_TAB>, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+                hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
             else
-                hipLaunchKernelGGL(stereo_warp_fast<D2S_MODE_HALF_SBS>, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+                hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_HALF_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
         }
     } else {
         if (rgb_fmt == D2S_FMT_U8_HWC) launch_generic<D2S_FMT_U8_HWC>(rgb, depth, out, out_fmt, batch, g, st);
