@@ -69,6 +69,8 @@ SYMBOLS = {
     "d2s_sbs_shape": (C.c_int, [C.c_int, C.c_int, C.POINTER(SbsParams), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "d2s_dibr_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "d2s_dibr_warp": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(DibrParams), _P, C.c_int, _P]),
+    "d2s_jpeg_bound": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "d2s_jpeg_encode": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P, _P, C.c_int64, _P]),
     "d2s_pipeline": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(PostParams),
                                C.POINTER(SbsParams), C.c_int, _P, C.c_int, _P, _P]),
     "d2s_engine_reset_stream": (C.c_int, [_P]),

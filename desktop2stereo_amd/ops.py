@@ -199,6 +199,43 @@ def dibr_warp(frames: torch.Tensor, depth: torch.Tensor, dp: "_lib.DibrParams", 
     return out if batched else out[0]
 
 
+_JPEG_WS: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def jpeg_bound(H: int, W: int) -> Tuple[int, int]:
+    """(output bytes that can never overflow, workspace bytes per frame) for an H x W frame."""
+    ob, wb = C.c_int64(), C.c_int64()
+    check(_lib.load().d2s_jpeg_bound(H, W, C.byref(ob), C.byref(wb)), "d2s_jpeg_bound")
+    return ob.value, wb.value
+
+
+def jpeg_encode(frames: torch.Tensor, quality: int = 90, out_stride: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """f3, the MJPEG sink (reference streamer.py:249-256, 285-291 — cv2.imencode('.jpg', ...)): RGB frames
+    [B,H,W,3] or [H,W,3], uint8 or float32 0..255 (rounded half-even + saturated like cv2's convertTo), on the
+    device -> (bytes [B, out_stride] uint8, sizes [B] int32), both on the device, no host sync.  The first
+    sizes[b] bytes of row b are the JPEG libjpeg-turbo would write for that frame at that quality (4:2:0)."""
+    _need_cuda(frames, "frames")
+    if frames.shape[-1] != 3 or frames.dim() not in (3, 4) or frames.dtype not in (torch.uint8, torch.float32):
+        raise ValueError("jpeg_encode: frames must be uint8/float32 [B,H,W,3] or [H,W,3]")
+    f = (frames if frames.dim() == 4 else frames.unsqueeze(0)).contiguous()
+    B, H, W, _ = f.shape
+    safe, ws_frame = jpeg_bound(H, W)
+    # default stride: the unstuffed worst case + 1/16 for 0xFF stuffing; sizes[b] = -1 reports an overflow
+    stride = int(out_stride) if out_stride else (safe // 2 + safe // 32 + 1024)
+    key = (f.device.index or 0, ws_frame * B)
+    ws = _JPEG_WS.get(key)
+    if ws is None:
+        _JPEG_WS.clear()
+        ws = _JPEG_WS[key] = torch.empty(ws_frame * B + 256, dtype=torch.uint8, device=f.device)
+    pad = (-ws.data_ptr()) % 256
+    out = torch.empty((B, stride), dtype=torch.uint8, device=f.device)
+    sizes = torch.empty((B,), dtype=torch.int32, device=f.device)
+    check(_lib.load().d2s_jpeg_encode(_ptr(f), FMT_U8_HWC if f.dtype == torch.uint8 else FMT_F32_HWC, B, H, W, int(quality),
+                                      _ptr(out), stride, _ptr(sizes), C.c_void_p(ws.data_ptr() + pad), ws_frame * B, _stream()),
+          "d2s_jpeg_encode")
+    return out, sizes
+
+
 class Engine:
     """The native depth engine: what DepthModelWrapper holds in ``self.model`` for an accelerated
     backend (reference depth.py:1539-1781).  ``__call__(tensor[B,3,h,w]) -> tensor[B,h,w]``."""

@@ -1,0 +1,61 @@
+"""The MJPEG sink of the Streamer modes, on the device.
+
+Mirror of the two encode sites of the reference's ``MJPEGStreamer`` (reference streamer.py:249-256
+``_encoder_loop`` and 285-291 ``encode_jpeg``): there the float32 HWC frame ``make_sbs`` copied to the host is
+channel-flipped and handed to ``cv2.imencode('.jpg', bgr, [IMWRITE_JPEG_QUALITY, quality])``.  Here the frame
+stays on the GPU: ``encode_jpeg`` takes what ``make_sbs`` / ``pipeline`` produced (uint8 or float32 0..255, RGB,
+HWC) and returns the JPEG bytes; only those bytes (≈1-3 MB instead of a 25-50 MB float frame) cross PCIe.
+Same names, argument meaning and failure behaviour as the reference's method (``b""`` for ``None``).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+def _to_device(arr) -> torch.Tensor:
+    t = torch.from_numpy(np.ascontiguousarray(arr)) if isinstance(arr, np.ndarray) else arr
+    if t.dtype not in (torch.uint8, torch.float32):
+        t = t.float()
+    if not t.is_cuda:
+        if not torch.cuda.is_available():
+            raise _lib.D2SError("encode_jpeg needs a ROCm device (no CPU path in this package)")
+        t = t.cuda()
+    return t
+
+
+def encode_jpeg_batch(frames, quality: int = 90) -> List[bytes]:
+    """[B,H,W,3] RGB frames -> list of JPEG byte strings (one host copy of the packed bytes)."""
+    t = _to_device(frames)
+    out, sizes = ops.jpeg_encode(t, quality)
+    sz = sizes.cpu().tolist()
+    if any(s < 0 for s in sz):                                        # incompressible frame: retry with the hard bound
+        out, sizes = ops.jpeg_encode(t, quality, out_stride=ops.jpeg_bound(t.shape[-3], t.shape[-2])[0])
+        sz = sizes.cpu().tolist()
+    n = max(sz)
+    host = out[:, :n].cpu().numpy()
+    return [host[b, :s].tobytes() for b, s in enumerate(sz)]
+
+
+def encode_jpeg(arr, quality: int = 90) -> bytes:
+    """``MJPEGStreamer.encode_jpeg`` (reference streamer.py:285-291): one HWC RGB frame -> JPEG bytes."""
+    if arr is None:
+        return b""
+    return encode_jpeg_batch(_to_device(arr).unsqueeze(0), quality)[0]
+
+
+class MJPEGEncoder:
+    """The encode half of ``MJPEGStreamer`` (reference streamer.py:37-44, 230-257): fixed quality, latest-frame
+    semantics; the HTTP half is out of scope."""
+
+    def __init__(self, quality: int = 90):
+        self.quality = int(quality)
+        self.encoded_frame: Optional[bytes] = None
+
+    def set_frame(self, frame) -> bytes:
+        self.encoded_frame = encode_jpeg(frame, self.quality)
+        return self.encoded_frame

@@ -206,6 +206,19 @@ int d2s_dibr_shape(int H, int W, int display_mode, int* out_h, int* out_w);
 int d2s_dibr_warp(const uint8_t* rgb, const float* depth, int batch, int H, int W, const d2s_dibr_params* p,
                   void* out, int out_fmt, void* stream);
 
+/* f3: the MJPEG sink of the Streamer modes.  Replaces `cv2.imencode('.jpg', bgr, [IMWRITE_JPEG_QUALITY, q])` on the
+ * frame make_sbs returns (reference streamer.py:249-256, 285-291; quality = settings.yaml "Stream Quality",
+ * utils.py:821): convertTo(CV_8U) (round-half-even, saturate) + baseline JPEG as libjpeg(-turbo) writes it with
+ * jpeg_set_defaults + jpeg_set_quality(q, TRUE) -- YCbCr 4:2:0, slow-integer FDCT, Annex-K tables, no restart
+ * markers, JFIF 1.01 -- BYTE-IDENTICAL to libjpeg-turbo's output for the same RGB frame.
+ * frames: `batch` RGB frames, D2S_FMT_U8_HWC or D2S_FMT_F32_HWC (0..255), device.  out: device bytes, frame b at
+ * out + b*out_stride; sizes[b] (device int32) = JPEG length, or -1 if it would not fit out_stride (nothing usable
+ * is written then).  d2s_jpeg_bound gives a stride that can never overflow and the workspace bytes PER FRAME
+ * (workspace: device, 256-byte aligned, >= batch * that).  Stream-ordered, no host synchronisation. */
+int d2s_jpeg_bound(int H, int W, int64_t* out_bytes, int64_t* workspace_bytes);
+int d2s_jpeg_encode(const void* frames, int fmt, int batch, int H, int W, int quality, uint8_t* out,
+                    int64_t out_stride, int32_t* sizes, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused frame pipeline: predict_depth + make_sbs for a batch of frames
  * (capture -> depth -> warp of reference main.py:232-262, 1336-1341 in one stream-ordered
