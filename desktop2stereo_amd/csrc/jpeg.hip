@@ -118,7 +118,7 @@ struct JpegGeom {
     int ybw, ybh;                    // real luma blocks across / down
     int He;                          // H rounded up to even (the rows the chroma planes are derived from)
     long ws_frame;                   // workspace bytes per frame
-    long off_acbits, off_mcuoff, off_stream, off_ffcnt;
+    long off_acbits, off_dcs, off_mcuoff, off_stream, off_ffcnt;
     long cap_words;                  // words of the unstuffed stream buffer
     int n_chunks;                    // 64-byte chunks of it
 };
@@ -132,6 +132,7 @@ static JpegGeom make_geom(int H, int W) {
     auto al = [](long v) { return (v + 255) / 256 * 256; };
     long o = al((long)g.nmcu * 6 * 64 * 2);
     g.off_acbits = o; o = al(o + (long)g.nmcu * 4);
+    g.off_dcs = o; o = al(o + (long)g.nmcu * 8 * 2);                 // quantised DC of the 6 blocks of every MCU ([mcu][8] int16)
     g.off_mcuoff = o; o = al(o + (long)(g.nmcu + 1) * 4);
     g.cap_words = ((long)g.nmcu * 6 * BLK_WORDS + 16 + 15) / 16 * 16;
     g.n_chunks = (int)(g.cap_words / 16);
@@ -155,6 +156,21 @@ __device__ __forceinline__ void load_rgb(const void* frame, long idx, int& r, in
         r = (int)fminf(fmaxf(rintf(p[0]), 0.f), 255.f);
         g = (int)fminf(fmaxf(rintf(p[1]), 0.f), 255.f);
         b = (int)fminf(fmaxf(rintf(p[2]), 0.f), 255.f);
+    }
+}
+// 4 consecutive pixels of row y starting at column xs (columns clamped to W-1).  `wide`: uint8 frame with W % 4 == 0
+// and a 4-byte aligned base, so the 12 bytes are three aligned dwords.
+template <int FMT>
+__device__ __forceinline__ void load_row4(const void* frame, int W, int y, int xs, bool wide, int* R, int* G, int* B) {
+    if (FMT == D2S_FMT_U8_HWC && wide && xs + 3 < W) {
+        const uint32_t* p = (const uint32_t*)((const uint8_t*)frame + ((long)y * W + xs) * 3);
+        uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        R[0] = w0 & 255; G[0] = (w0 >> 8) & 255; B[0] = (w0 >> 16) & 255;
+        R[1] = w0 >> 24; G[1] = w1 & 255; B[1] = (w1 >> 8) & 255;
+        R[2] = (w1 >> 16) & 255; G[2] = w1 >> 24; B[2] = w2 & 255;
+        R[3] = (w2 >> 8) & 255; G[3] = (w2 >> 16) & 255; B[3] = w2 >> 24;
+    } else {
+        for (int i = 0; i < 4; ++i) load_rgb<FMT>(frame, (long)y * W + min(xs + i, W - 1), R[i], G[i], B[i]);
     }
 }
 // jccolor.c rgb_ycc_convert (SCALEBITS 16)
@@ -200,15 +216,14 @@ __device__ __forceinline__ int ac_symbol(int v, int lane, unsigned long long nzm
 template <int FMT>
 __global__ void __launch_bounds__(256)
 jpeg_dct_kernel(const void* __restrict__ frames, uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
-    __shared__ uint8_t sY[16][DCT_MCUS * 16];
-    __shared__ uint8_t sC[2][8][DCT_MCUS * 8];
-    __shared__ int sW[DCT_BLOCKS][64];
+    __shared__ __attribute__((aligned(16))) uint8_t sY[16][DCT_MCUS * 16];
+    __shared__ __attribute__((aligned(16))) uint8_t sC[2][8][DCT_MCUS * 8];
+    __shared__ short sW[DCT_BLOCKS][64];       // row-pass output: |x| <= 1024 << PASS1_BITS, fits int16
     __shared__ short sZ[DCT_BLOCKS][64];
     __shared__ uint16_t sQ8[2][64];
     __shared__ uint32_t sMagic[2][64];
     __shared__ uint8_t sN2Z[64];
     __shared__ uint32_t sAcLen[2][256];
-    __shared__ int sBits[DCT_MCUS];
 
     const int tid = threadIdx.x;
     const int mrow = blockIdx.y, mcol0 = blockIdx.x * DCT_MCUS, f = blockIdx.z;
@@ -218,39 +233,40 @@ jpeg_dct_kernel(const void* __restrict__ frames, uint8_t* __restrict__ ws, JpegG
 
     if (tid < 128) { sQ8[tid >> 6][tid & 63] = tb.q8[tid >> 6][tid & 63]; sMagic[tid >> 6][tid & 63] = tb.magic[tid >> 6][tid & 63]; }
     if (tid < 64) sN2Z[tid] = tb.nat2zig[tid];
-    if (tid < DCT_MCUS) sBits[tid] = 0;
     for (int i = tid; i < 512; i += 256) sAcLen[i >> 8][i & 255] = tb.ac[i >> 8][i & 255] >> 16;
 
-    // colour conversion + h2v2: one 2x2 quad per step.  Columns are edge-replicated on the INPUT (expand_right_edge);
-    // rows: luma replicates the last row, chroma replicates its last DOWNSAMPLED row (jcprepct.c), whose sources are
-    // rows He-2, min(He-1, H-1).
+    // colour conversion + h2v2: 4 pixels x 2 rows (two 2x2 quads) per step.  Columns are edge-replicated on the INPUT
+    // (expand_right_edge); rows: luma replicates the last row, chroma replicates its last DOWNSAMPLED row (jcprepct.c),
+    // whose sources are rows He-2, min(He-1, H-1).
     const int x0 = mcol0 * 16, y0 = mrow * 16;
-    for (int qd = tid; qd < 8 * nm * 8; qd += 256) {
-        int r = qd / (nm * 8), c = qd % (nm * 8);
-        int xa = min(x0 + 2 * c, g.W - 1), xb = min(x0 + 2 * c + 1, g.W - 1);
-        int ya = min(y0 + 2 * r, g.H - 1), yb = min(y0 + 2 * r + 1, g.H - 1);
-        int R[4], G[4], B[4];
-        load_rgb<FMT>(frame, (long)ya * g.W + xa, R[0], G[0], B[0]);
-        load_rgb<FMT>(frame, (long)ya * g.W + xb, R[1], G[1], B[1]);
-        load_rgb<FMT>(frame, (long)yb * g.W + xa, R[2], G[2], B[2]);
-        load_rgb<FMT>(frame, (long)yb * g.W + xb, R[3], G[3], B[3]);
-        sY[2 * r][2 * c] = (uint8_t)ycc_y(R[0], G[0], B[0]);
-        sY[2 * r][2 * c + 1] = (uint8_t)ycc_y(R[1], G[1], B[1]);
-        sY[2 * r + 1][2 * c] = (uint8_t)ycc_y(R[2], G[2], B[2]);
-        sY[2 * r + 1][2 * c + 1] = (uint8_t)ycc_y(R[3], G[3], B[3]);
-        int cy = min(mrow * 8 + r, g.He / 2 - 1);                     // chroma row this sample replicates
-        int ca = 2 * cy, cb2 = min(2 * cy + 1, g.H - 1);
-        if (ca != ya || cb2 != yb) {
-            load_rgb<FMT>(frame, (long)ca * g.W + xa, R[0], G[0], B[0]);
-            load_rgb<FMT>(frame, (long)ca * g.W + xb, R[1], G[1], B[1]);
-            load_rgb<FMT>(frame, (long)cb2 * g.W + xa, R[2], G[2], B[2]);
-            load_rgb<FMT>(frame, (long)cb2 * g.W + xb, R[3], G[3], B[3]);
+    const bool wide = FMT == D2S_FMT_U8_HWC && (g.W & 3) == 0 && (((uintptr_t)frames) & 3) == 0;
+    for (int it = tid; it < 8 * nm * 4; it += 256) {
+        const int r = it / (nm * 4), cg = it % (nm * 4), xs = x0 + 4 * cg;
+        const int ya = min(y0 + 2 * r, g.H - 1), yb = min(y0 + 2 * r + 1, g.H - 1);
+        int R[2][4], G[2][4], B[2][4];
+        load_row4<FMT>(frame, g.W, ya, xs, wide, R[0], G[0], B[0]);
+        load_row4<FMT>(frame, g.W, yb, xs, wide, R[1], G[1], B[1]);
+        for (int k = 0; k < 2; ++k) {
+            uint32_t y4 = 0;
+            for (int i = 0; i < 4; ++i) y4 |= (uint32_t)ycc_y(R[k][i], G[k][i], B[k][i]) << (8 * i);
+            *(uint32_t*)&sY[2 * r + k][4 * cg] = y4;
         }
-        int bias = 1 + (c & 1);                                       // jcsample.c h2v2_downsample: 1,2,1,2,... along the row
-        int sb = 0, sr = 0;
-        for (int i = 0; i < 4; ++i) { sb += ycc_cb(R[i], G[i], B[i]); sr += ycc_cr(R[i], G[i], B[i]); }
-        sC[0][r][c] = (uint8_t)((sb + bias) >> 2);
-        sC[1][r][c] = (uint8_t)((sr + bias) >> 2);
+        const int cy = min(mrow * 8 + r, g.He / 2 - 1);               // chroma row this sample replicates
+        const int ca = 2 * cy, cb2 = min(2 * cy + 1, g.H - 1);
+        if (ca != ya || cb2 != yb) {
+            load_row4<FMT>(frame, g.W, ca, xs, wide, R[0], G[0], B[0]);
+            load_row4<FMT>(frame, g.W, cb2, xs, wide, R[1], G[1], B[1]);
+        }
+        uint32_t cb16 = 0, cr16 = 0;
+        for (int h = 0; h < 2; ++h) {                                 // jcsample.c h2v2_downsample: bias 1,2,1,2,... along the row
+            int sb = 1 + h, sr = 1 + h;
+            for (int k = 0; k < 2; ++k)
+                for (int i = 2 * h; i < 2 * h + 2; ++i) { sb += ycc_cb(R[k][i], G[k][i], B[k][i]); sr += ycc_cr(R[k][i], G[k][i], B[k][i]); }
+            cb16 |= (uint32_t)(sb >> 2) << (8 * h);
+            cr16 |= (uint32_t)(sr >> 2) << (8 * h);
+        }
+        *(uint16_t*)&sC[0][r][2 * cg] = (uint16_t)cb16;
+        *(uint16_t*)&sC[1][r][2 * cg] = (uint16_t)cr16;
     }
     __syncthreads();
 
@@ -258,15 +274,10 @@ jpeg_dct_kernel(const void* __restrict__ frames, uint8_t* __restrict__ ws, JpegG
     for (int task = tid; task < nm * 6 * 8; task += 256) {
         int blk = task >> 3, r = task & 7, m = blk / 6, b = blk % 6;
         int d[8];
-        if (b < 4) {
-            const uint8_t* p = &sY[(b >> 1) * 8 + r][m * 16 + (b & 1) * 8];
-            for (int i = 0; i < 8; ++i) d[i] = (int)p[i] - 128;
-        } else {
-            const uint8_t* p = &sC[b - 4][r][m * 8];
-            for (int i = 0; i < 8; ++i) d[i] = (int)p[i] - 128;
-        }
+        const uint2 px = b < 4 ? *(const uint2*)&sY[(b >> 1) * 8 + r][m * 16 + (b & 1) * 8] : *(const uint2*)&sC[b - 4][r][m * 8];
+        for (int i = 0; i < 4; ++i) { d[i] = (int)((px.x >> (8 * i)) & 255) - 128; d[4 + i] = (int)((px.y >> (8 * i)) & 255) - 128; }
         fdct8<true>(d);
-        for (int i = 0; i < 8; ++i) sW[blk][r * 8 + i] = d[i];
+        for (int i = 0; i < 8; ++i) sW[blk][r * 8 + i] = (short)d[i];
     }
     __syncthreads();
     // pass 2 (columns) + quantise (jcdctmgr.c: sign * ((|x| + q8/2) / q8)) + zigzag
@@ -285,34 +296,33 @@ jpeg_dct_kernel(const void* __restrict__ frames, uint8_t* __restrict__ ws, JpegG
     }
     __syncthreads();
 
-    // dummy blocks (jccoefct.c compress_data), coefficient store, AC bit count: one wave per block, lane = zigzag k
+    // dummy blocks (jccoefct.c compress_data), coefficient store, AC bit count: one wave per MCU, lane = zigzag k
     const int lane = tid & 63, wv = tid >> 6;
     short* coefs = (short*)wsf;
-    for (int blk = wv; blk < nm * 6; blk += 4) {
-        int m = blk / 6, b = blk % 6, src = b;
-        if (b < 4) {
-            bool row1 = (2 * mrow + 1) < g.ybh, col1 = (2 * (mcol0 + m) + 1) < g.ybw;
-            int s1 = col1 ? 1 : 0;
-            if (b == 1) src = s1;
-            else if (b == 2) src = row1 ? 2 : s1;
-            else if (b == 3) src = row1 ? (col1 ? 3 : 2) : s1;
-        }
-        int v = (src == b) ? sZ[blk][lane] : (lane == 0 ? sZ[m * 6 + src][0] : 0);
-        long mcu = (long)mrow * g.mc + mcol0 + m;
-        coefs[(mcu * 6 + b) * 64 + lane] = (short)v;
-        unsigned long long nz = __ballot(v != 0 && lane > 0);
+    const bool row1 = (2 * mrow + 1) < g.ybh;
+    for (int m = wv; m < nm; m += 4) {
+        const bool col1 = (2 * (mcol0 + m) + 1) < g.ybw;
+        const int s1 = col1 ? 1 : 0;
+        const int srcs[6] = {0, s1, row1 ? 2 : s1, row1 ? (col1 ? 3 : 2) : s1, 4, 5};
+        const long mcu = (long)mrow * g.mc + mcol0 + m;
         int bits = 0;
-        if (v != 0 && lane > 0) {
-            int nb, run;
-            int sym = ac_symbol(v, lane, nz, nb, run);
-            bits = (run >> 4) * (int)sAcLen[b >= 4][0xF0] + (int)sAcLen[b >= 4][sym] + nb;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int src = srcs[b];
+            int v = (src == b) ? sZ[m * 6 + b][lane] : (lane == 0 ? sZ[m * 6 + src][0] : 0);
+            coefs[(mcu * 6 + b) * 64 + lane] = (short)v;
+            if (lane == 0) ((short*)(wsf + g.off_dcs))[mcu * 8 + b] = (short)v;
+            unsigned long long nz = __ballot(v != 0 && lane > 0);
+            if (v != 0 && lane > 0) {
+                int nb, run;
+                int sym = ac_symbol(v, lane, nz, nb, run);
+                bits += (run >> 4) * (int)sAcLen[b >= 4][0xF0] + (int)sAcLen[b >= 4][sym] + nb;
+            }
+            if (lane == 0 && (nz >> 63) == 0) bits += (int)sAcLen[b >= 4][0];          // EOB unless position 63 is non-zero
         }
-        if (lane == 0 && (nz >> 63) == 0) bits = (int)sAcLen[b >= 4][0];            // EOB unless position 63 is non-zero
         for (int o = 32; o > 0; o >>= 1) bits += __shfl_xor(bits, o);
-        if (lane == 0) atomicAdd(&sBits[m], bits);
+        if (lane == 0) ((uint32_t*)(wsf + g.off_acbits))[mcu] = (uint32_t)bits;
     }
-    __syncthreads();
-    if (tid < nm) ((uint32_t*)(wsf + g.off_acbits))[(long)mrow * g.mc + mcol0 + tid] = (uint32_t)sBits[tid];
 }
 
 // ---- stage 2: bit offsets ----------------------------------------------------------------------
@@ -347,35 +357,31 @@ jpeg_scan_kernel(uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
     __shared__ uint32_t s_wave[17];
     __shared__ uint32_t s_dc[2][12];
     uint8_t* wsf = ws + (long)blockIdx.x * g.ws_frame;
-    const short* coefs = (const short*)wsf;
-    const uint32_t* acbits = (const uint32_t*)(wsf + g.off_acbits);
+    const short* dcs = (const short*)(wsf + g.off_dcs);
+    uint32_t* acbits = (uint32_t*)(wsf + g.off_acbits);
     uint32_t* off = (uint32_t*)(wsf + g.off_mcuoff);
     if (threadIdx.x < 24) s_dc[threadIdx.x / 12][threadIdx.x % 12] = tb.dc[threadIdx.x / 12][threadIdx.x % 12];
     __syncthreads();
+    // walk 1 (coalesced): total bits of every MCU = AC bits + the six DC codes (DC prediction runs across MCUs)
+    for (int m = threadIdx.x; m < g.nmcu; m += 1024) {
+        const short* c = dcs + (long)m * 8;
+        int py = 0, pb = 0, pr = 0;
+        if (m > 0) { py = c[-8 + 3]; pb = c[-8 + 4]; pr = c[-8 + 5]; }
+        uint32_t bits = acbits[m];
+        for (int b = 0; b < 4; ++b) { int d = c[b]; bits += dc_bits(d - py, s_dc[0]); py = d; }
+        bits += dc_bits(c[4] - pb, s_dc[1]) + dc_bits(c[5] - pr, s_dc[1]);
+        acbits[m] = bits;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // walk 2: each thread owns a contiguous run of MCUs
     const int per = (g.nmcu + 1023) / 1024;
     const int m0 = threadIdx.x * per, m1 = min(m0 + per, g.nmcu);
     uint32_t sum = 0;
-    for (int m = m0; m < m1; ++m) {
-        const short* c = coefs + (long)m * 384;
-        int py = 0, pb = 0, pr = 0;
-        if (m > 0) { py = c[-384 + 3 * 64]; pb = c[-384 + 4 * 64]; pr = c[-384 + 5 * 64]; }
-        uint32_t bits = acbits[m];
-        for (int b = 0; b < 4; ++b) { int d = c[b * 64]; bits += dc_bits(d - py, s_dc[0]); py = d; }
-        bits += dc_bits(c[4 * 64] - pb, s_dc[1]) + dc_bits(c[5 * 64] - pr, s_dc[1]);
-        sum += bits;
-    }
+    for (int m = m0; m < m1; ++m) sum += acbits[m];
     uint32_t total;
     uint32_t base = block_exscan(sum, s_wave, &total);
-    for (int m = m0; m < m1; ++m) {                                   // second walk: same arithmetic, now with the base
-        const short* c = coefs + (long)m * 384;
-        int py = 0, pb = 0, pr = 0;
-        if (m > 0) { py = c[-384 + 3 * 64]; pb = c[-384 + 4 * 64]; pr = c[-384 + 5 * 64]; }
-        uint32_t bits = acbits[m];
-        for (int b = 0; b < 4; ++b) { int d = c[b * 64]; bits += dc_bits(d - py, s_dc[0]); py = d; }
-        bits += dc_bits(c[4 * 64] - pb, s_dc[1]) + dc_bits(c[5 * 64] - pr, s_dc[1]);
-        off[m] = base;
-        base += bits;
-    }
+    for (int m = m0; m < m1; ++m) { off[m] = base; base += acbits[m]; }
     if (threadIdx.x == 0) off[g.nmcu] = (total + 7u) & ~7u;           // flush_bits pads the last byte with 1-bits
 }
 
@@ -422,12 +428,14 @@ jpeg_huff_kernel(uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
     uint32_t* stream = (uint32_t*)(wsf + g.off_stream);
 
     int prev[3] = {0, 0, 0};
-    if (m > 0) { prev[0] = c[-384 + 3 * 64]; prev[1] = c[-384 + 4 * 64]; prev[2] = c[-384 + 5 * 64]; }
-    int pos = 0;
+    if (m > 0) { const short* d = (const short*)(wsf + g.off_dcs) + (long)(m - 1) * 8; prev[0] = d[3]; prev[1] = d[4]; prev[2] = d[5]; }
+    unsigned long long bitsv[6];
+    int lens[6], inc[6];
+#pragma unroll
     for (int b = 0; b < 6; ++b) {
         const int tbl = b >= 4, comp = b < 4 ? 0 : b - 3;
         int v = c[b * 64 + lane];
-        int dcv = __shfl(v, 0);
+        int dcv = __builtin_amdgcn_readfirstlane(v);
         unsigned long long nz = __ballot(v != 0 && lane > 0);
         unsigned long long bits = 0;
         int len = 0;
@@ -450,10 +458,20 @@ jpeg_huff_kernel(uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
         const int last = nz ? 63 - __builtin_clzll(nz) : 0;          // the lane that owns the end-of-block code
         if (lane == last && last != 63) { uint32_t e = sAc[tbl][0]; bits = (bits << (e >> 16)) | (e & 0xffff); len += (int)(e >> 16); }
         prev[comp] = dcv;
-        int inc = len;
-        for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-        lds_put(buf, pos + inc - len, bits, len);
-        pos += __shfl(inc, 63);
+        bitsv[b] = bits; lens[b] = len; inc[b] = len;
+    }
+    for (int o = 1; o < 64; o <<= 1) {                                // six inclusive scans in lockstep (independent shuffles in flight)
+        int u[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) u[b] = __shfl_up(inc[b], o);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) if (lane >= o) inc[b] += u[b];
+    }
+    int pos = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        lds_put(buf, pos + inc[b] - lens[b], bitsv[b], lens[b]);
+        pos += __builtin_amdgcn_readlane(inc[b], 63);
     }
     const uint32_t G = off[m];
     if (m == g.nmcu - 1) {                                            // jchuff.c flush_bits: fill the last byte with ones

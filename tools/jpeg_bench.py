@@ -1,6 +1,9 @@
 """Time the MJPEG sink (csrc/jpeg.hip) on the device and libjpeg-turbo (Pillow) on the host for the same frames.
     python tools/jpeg_bench.py [--h 1080 --w 3840 --batch 1 --quality 90 --kind scene|noise]"""
 import argparse
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import io
 import time
 
