@@ -7,16 +7,15 @@
 // arithmetic libjpeg publishes (jccolor.c, jcsample.c, jfdctint.c, jcdctmgr.c, jccoefct.c, jchuff.c,
 // jcmarker.c), so the stream is BYTE-IDENTICAL to libjpeg-turbo's (oracle/jpeg_oracle.py pins that).
 //
-// Stages (all HBM-/latency-bound byte work; grid.z = frame):
-//   1 jpeg_dct_kernel     16 MCUs (256x16 px) per block: RGB -> YCbCr (+h2v2), FDCT, quantise, zigzag;
-//                         writes int16 coefficients [mcu][6][64] and the AC bit count of every MCU
-//   2 jpeg_scan_kernel    one block per frame: adds the DC code lengths (needs the neighbour MCU's DC),
-//                         exclusive scan -> bit offset of every MCU, total bits
-//   3 jpeg_zero_kernel    zero the words of the (unstuffed) bit stream that will be used
-//   4 jpeg_huff_kernel    one wave per MCU, one lane per coefficient: codes assembled in LDS, shifted to the
-//                         MCU's bit offset and merged into the stream (atomic OR only on the two edge words)
-//   5 jpeg_ffcount_kernel 0xFF bytes per 64-byte chunk;  6 jpeg_ffscan_kernel: scan + header + EOI + size
-//   7 jpeg_stuff_kernel   byte-stuffed copy behind the header
+// Stages (all HBM-/latency-bound byte work; one grid dimension = frame; no single-block pass, no host sync):
+//   1 jpeg_dct_kernel            16 MCUs (256x16 px) per block: RGB -> YCbCr (+h2v2), FDCT, quantise, zigzag, dummy
+//                                blocks; writes int16 coefficients [mcu][6][64] and the DCs [mcu][8]
+//   2 jpeg_entropy_kernel<false> one LANE per 8x8 block: code lengths -> bits per block, bits per 256-block tile
+//   3 jpeg_zero_kernel           zero the words of the (unstuffed) bit stream that will be used; publish the total
+//   4 jpeg_entropy_kernel<true>  same walk, emitting: offset = tile prefix + in-block scan; whole words are plain
+//                                stores, the two edge words of a block are atomic ORs
+//   5 jpeg_ffcount_kernel        0xFF bytes per 64-byte chunk and per 256-chunk tile
+//   6 jpeg_stuff_kernel          byte-stuffed copy behind the header (+ header, EOI, size from block 0)
 #include "common.h"
 #include <string.h>
 #include <initializer_list>
@@ -51,7 +50,6 @@ static const uint8_t AC_VALS[2][162] = {
 
 constexpr int HDR_LEN = 623;            // SOI + APP0 + 2 DQT + SOF0 + 4 DHT + SOS
 constexpr int BLK_WORDS = 54;           // worst case of one 8x8 block: 22 + 63*26 = 1660 bits < 54 words
-constexpr int MCU_LDS_WORDS = 320;      // 6 * 1660 bits = 312 words, + slack read by the shifted flush
 
 // Everything the kernels need that depends on `quality` or is a table: passed BY VALUE (kernarg), staged to LDS.
 struct JpegTables {
@@ -113,12 +111,14 @@ static void make_tables(int H, int W, int quality, JpegTables& t) {
     put({0xff, 0xda, 0x00, 0x0c, 0x03, 0x01, 0x00, 0x02, 0x11, 0x03, 0x11, 0x00, 0x3f, 0x00});
 }
 
+__host__ __device__ static inline int cdiv_dev(long a, long b) { return (int)((a + b - 1) / b); }
+
 struct JpegGeom {
     int H, W, mr, mc, nmcu;          // MCU rows / cols (16x16 px)
     int ybw, ybh;                    // real luma blocks across / down
     int He;                          // H rounded up to even (the rows the chroma planes are derived from)
     long ws_frame;                   // workspace bytes per frame
-    long off_acbits, off_dcs, off_mcuoff, off_stream, off_ffcnt;
+    long off_blkbits, off_dcs, off_tiles, off_total, off_stream, off_ffcnt, off_fftiles;
     long cap_words;                  // words of the unstuffed stream buffer
     int n_chunks;                    // 64-byte chunks of it
 };
@@ -131,13 +131,15 @@ static JpegGeom make_geom(int H, int W) {
     g.He = H + (H & 1);
     auto al = [](long v) { return (v + 255) / 256 * 256; };
     long o = al((long)g.nmcu * 6 * 64 * 2);
-    g.off_acbits = o; o = al(o + (long)g.nmcu * 4);
+    g.off_blkbits = o; o = al(o + (long)g.nmcu * 6 * 2 + 16);        // bits of every block (uint16: <= 1660)
     g.off_dcs = o; o = al(o + (long)g.nmcu * 8 * 2);                 // quantised DC of the 6 blocks of every MCU ([mcu][8] int16)
-    g.off_mcuoff = o; o = al(o + (long)(g.nmcu + 1) * 4);
+    g.off_tiles = o; o = al(o + ((long)g.nmcu * 6 / 256 + 2) * 4);    // bits per 256-block tile
+    g.off_total = o; o = al(o + 16);                                  // byte-padded total bits of the frame
     g.cap_words = ((long)g.nmcu * 6 * BLK_WORDS + 16 + 15) / 16 * 16;
     g.n_chunks = (int)(g.cap_words / 16);
     g.off_stream = o; o = al(o + g.cap_words * 4);
     g.off_ffcnt = o; o = al(o + (long)(g.n_chunks + 1) * 4);
+    g.off_fftiles = o; o = al(o + ((long)g.n_chunks / 256 + 2) * 4);
     g.ws_frame = o;
     return g;
 }
@@ -202,28 +204,16 @@ __device__ __forceinline__ void fdct8(int* d) {
     d[1] = descale(t7 + z1 + z4, SH);
 }
 
-// Bits the AC coefficients of one block take (jchuff.c encode_one_block), one lane per zigzag position.
-// v: this lane's coefficient (lane 0 = DC, ignored).  Returns the wave-uniform total.
-__device__ __forceinline__ int ac_symbol(int v, int lane, unsigned long long nzmask, int& nb, int& run) {
-    unsigned long long below = nzmask & ((1ull << lane) - 1ull);
-    int prev = below ? 63 - __builtin_clzll(below) : 0;              // previous non-zero AC position (0 = the DC slot)
-    run = lane - prev - 1;
-    int a = v < 0 ? -v : v;
-    nb = a ? 32 - __builtin_clz(a) : 0;
-    return ((run & 15) << 4) | nb;
-}
-
 template <int FMT>
 __global__ void __launch_bounds__(256)
 jpeg_dct_kernel(const void* __restrict__ frames, uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
     __shared__ __attribute__((aligned(16))) uint8_t sY[16][DCT_MCUS * 16];
     __shared__ __attribute__((aligned(16))) uint8_t sC[2][8][DCT_MCUS * 8];
     __shared__ short sW[DCT_BLOCKS][64];       // row-pass output: |x| <= 1024 << PASS1_BITS, fits int16
-    __shared__ short sZ[DCT_BLOCKS][64];
+    __shared__ __attribute__((aligned(16))) short sZ[DCT_BLOCKS][64];
     __shared__ uint16_t sQ8[2][64];
     __shared__ uint32_t sMagic[2][64];
     __shared__ uint8_t sN2Z[64];
-    __shared__ uint32_t sAcLen[2][256];
 
     const int tid = threadIdx.x;
     const int mrow = blockIdx.y, mcol0 = blockIdx.x * DCT_MCUS, f = blockIdx.z;
@@ -233,7 +223,6 @@ jpeg_dct_kernel(const void* __restrict__ frames, uint8_t* __restrict__ ws, JpegG
 
     if (tid < 128) { sQ8[tid >> 6][tid & 63] = tb.q8[tid >> 6][tid & 63]; sMagic[tid >> 6][tid & 63] = tb.magic[tid >> 6][tid & 63]; }
     if (tid < 64) sN2Z[tid] = tb.nat2zig[tid];
-    for (int i = tid; i < 512; i += 256) sAcLen[i >> 8][i & 255] = tb.ac[i >> 8][i & 255] >> 16;
 
     // colour conversion + h2v2: 4 pixels x 2 rows (two 2x2 quads) per step.  Columns are edge-replicated on the INPUT
     // (expand_right_edge); rows: luma replicates the last row, chroma replicates its last DOWNSAMPLED row (jcprepct.c),
@@ -296,200 +285,186 @@ jpeg_dct_kernel(const void* __restrict__ frames, uint8_t* __restrict__ ws, JpegG
     }
     __syncthreads();
 
-    // dummy blocks (jccoefct.c compress_data), coefficient store, AC bit count: one wave per MCU, lane = zigzag k
-    const int lane = tid & 63, wv = tid >> 6;
-    short* coefs = (short*)wsf;
+    // dummy blocks (jccoefct.c compress_data) + coefficient store: 32 threads per block, two zigzag positions each
+    uint32_t* coefs = (uint32_t*)wsf;
     const bool row1 = (2 * mrow + 1) < g.ybh;
-    for (int m = wv; m < nm; m += 4) {
+    for (int task = tid; task < nm * 6 * 32; task += 256) {
+        const int blk = task >> 5, k2 = task & 31, m = blk / 6, b = blk % 6;
         const bool col1 = (2 * (mcol0 + m) + 1) < g.ybw;
         const int s1 = col1 ? 1 : 0;
-        const int srcs[6] = {0, s1, row1 ? 2 : s1, row1 ? (col1 ? 3 : 2) : s1, 4, 5};
+        int src = b;
+        if (b == 1) src = s1;
+        else if (b == 2) src = row1 ? 2 : s1;
+        else if (b == 3) src = row1 ? (col1 ? 3 : 2) : s1;
+        uint32_t v = (src == b) ? *(const uint32_t*)&sZ[blk][2 * k2] : (k2 == 0 ? (uint32_t)(uint16_t)sZ[m * 6 + src][0] : 0u);
         const long mcu = (long)mrow * g.mc + mcol0 + m;
-        int bits = 0;
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const int src = srcs[b];
-            int v = (src == b) ? sZ[m * 6 + b][lane] : (lane == 0 ? sZ[m * 6 + src][0] : 0);
-            coefs[(mcu * 6 + b) * 64 + lane] = (short)v;
-            if (lane == 0) ((short*)(wsf + g.off_dcs))[mcu * 8 + b] = (short)v;
-            unsigned long long nz = __ballot(v != 0 && lane > 0);
-            if (v != 0 && lane > 0) {
-                int nb, run;
-                int sym = ac_symbol(v, lane, nz, nb, run);
-                bits += (run >> 4) * (int)sAcLen[b >= 4][0xF0] + (int)sAcLen[b >= 4][sym] + nb;
-            }
-            if (lane == 0 && (nz >> 63) == 0) bits += (int)sAcLen[b >= 4][0];          // EOB unless position 63 is non-zero
-        }
-        for (int o = 32; o > 0; o >>= 1) bits += __shfl_xor(bits, o);
-        if (lane == 0) ((uint32_t*)(wsf + g.off_acbits))[mcu] = (uint32_t)bits;
+        coefs[(mcu * 6 + b) * 32 + k2] = v;
+        if (k2 == 0) ((short*)(wsf + g.off_dcs))[mcu * 8 + b] = (short)(v & 0xffffu);
     }
 }
 
-// ---- stage 2: bit offsets ----------------------------------------------------------------------
-__device__ __forceinline__ int dc_bits(int diff, const uint32_t* dctab) {
-    int a = diff < 0 ? -diff : diff;
-    int nb = a ? 32 - __builtin_clz(a) : 0;
-    return (int)(dctab[nb] >> 16) + nb;
+// ---- stages 2-5: entropy coding, one LANE per 8x8 block -------------------------------------------
+// Bit order everywhere: stream bit p lives in word p >> 5 at bit 31 - (p & 31) (MSB first).
+// A lane keeps its block's 64 coefficients in registers (8 x 16-byte loads) and walks them in zigzag order exactly
+// like jchuff.c encode_one_block; COUNT instantiation adds code lengths, EMIT instantiation streams the codes to the
+// block's bit offset.  Words a block covers completely are plain stores; its first and last (possibly shared with the
+// neighbouring blocks) are atomic ORs into the zeroed stream.
+struct BitSink {
+    uint32_t* stream;      // EMIT only
+    long w;                // current word
+    uint32_t acc;          // bits already placed in the current word (from the MSB)
+    int fill;              // how many
+    bool first;            // the current word is the block's first (shared) word
+    uint32_t count;        // COUNT only
+};
+
+template <bool EMIT>
+__device__ __forceinline__ void put(BitSink& s, uint32_t val, int len) {          // len <= 27
+    if (!EMIT) { s.count += (uint32_t)len; return; }
+    unsigned long long win = ((unsigned long long)s.acc << 32) | ((unsigned long long)val << (64 - s.fill - len));
+    s.fill += len;
+    if (s.fill >= 32) {
+        uint32_t word = (uint32_t)(win >> 32);
+        if (s.first) { if (word) atomicOr(&s.stream[s.w], word); s.first = false; }
+        else s.stream[s.w] = word;
+        ++s.w;
+        s.acc = (uint32_t)win;
+        s.fill -= 32;
+    } else {
+        s.acc = (uint32_t)(win >> 32);
+    }
 }
 
-// Block-wide exclusive scan of one value per thread (1024 threads); returns the exclusive prefix, *total = sum.
-__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+template <bool EMIT>
+__device__ __forceinline__ void coef_step(BitSink& s, int v, int& run, const uint32_t* ac) {
+    if (v == 0) { ++run; return; }
+    while (run > 15) { put<EMIT>(s, ac[0xF0] & 0xffffu, (int)(ac[0xF0] >> 16)); run -= 16; }
+    const int a = v < 0 ? -v : v, t2 = v < 0 ? v - 1 : v;
+    const int nb = 32 - __builtin_clz(a);
+    const uint32_t e = ac[(run << 4) | nb];
+    put<EMIT>(s, ((e & 0xffffu) << nb) | ((uint32_t)t2 & ((1u << nb) - 1u)), (int)(e >> 16) + nb);
+    run = 0;
+}
+
+// one block: q = its 64 int16 coefficients in zigzag order; dcdiff = DC - predictor
+template <bool EMIT>
+__device__ __forceinline__ void encode_block(BitSink& s, const uint4 (&q)[8], int dcdiff, const uint32_t* dc, const uint32_t* ac) {
+    {
+        const int a = dcdiff < 0 ? -dcdiff : dcdiff, t2 = dcdiff < 0 ? dcdiff - 1 : dcdiff;
+        const int nb = a ? 32 - __builtin_clz(a) : 0;
+        const uint32_t e = dc[nb];
+        put<EMIT>(s, ((e & 0xffffu) << nb) | ((uint32_t)t2 & ((1u << nb) - 1u)), (int)(e >> 16) + nb);
+    }
+    int run = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t w[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i + j > 0) coef_step<EMIT>(s, (int)(short)(w[j] & 0xffffu), run, ac);           // k = 8i + 2j (k = 0 is the DC)
+            coef_step<EMIT>(s, (int)(short)(w[j] >> 16), run, ac);
+        }
+    }
+    if (run > 0) put<EMIT>(s, ac[0] & 0xffffu, (int)(ac[0] >> 16));                            // end of block
+}
+
+// DC predictor of block b of MCU m: the previous block of the same component in scan order
+__device__ __forceinline__ int dc_pred(const short* dcs, long m, int b) {
+    if (b >= 1 && b <= 3) return dcs[m * 8 + b - 1];
+    return m > 0 ? dcs[(m - 1) * 8 + (b == 0 ? 3 : b)] : 0;
+}
+
+// 256-thread block helpers (deterministic: no atomics).  s_w: >= 8 words of LDS.
+__device__ __forceinline__ uint32_t block256_sum(uint32_t v, uint32_t* s_w) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__device__ __forceinline__ uint32_t block256_exscan(uint32_t v, uint32_t* s_w) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t inc = v;
     for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-    if (lane == 63) s_wave[wv] = inc;
     __syncthreads();
-    if (wv == 0) {
-        uint32_t w = lane < 16 ? s_wave[lane] : 0, wi = w;
-        for (int o = 1; o < 16; o <<= 1) { uint32_t u = __shfl_up(wi, o); if (lane >= o) wi += u; }
-        if (lane < 16) s_wave[lane] = wi - w;
-        if (lane == 15) s_wave[16] = wi;
-    }
+    if (lane == 63) s_w[4 + wv] = inc;
     __syncthreads();
-    uint32_t r = s_wave[wv] + inc - v;
-    *total = s_wave[16];
-    __syncthreads();
-    return r;
+    uint32_t base = 0;
+    for (int i = 0; i < wv; ++i) base += s_w[4 + i];
+    return base + inc - v;
+}
+// prefix = sum of tiles[0..mine), total = sum of tiles[0..n): every block derives its own offset from the per-tile sums
+__device__ __forceinline__ void tile_prefix(const uint32_t* tiles, int n, int mine, uint32_t* s_w, uint32_t& prefix, uint32_t& total) {
+    uint32_t p = 0, t = 0;
+    for (int i = threadIdx.x; i < n; i += 256) { uint32_t v = tiles[i]; t += v; if (i < mine) p += v; }
+    prefix = block256_sum(p, s_w);
+    total = block256_sum(t, s_w);
 }
 
-__global__ void __launch_bounds__(1024)
-jpeg_scan_kernel(uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
-    __shared__ uint32_t s_wave[17];
-    __shared__ uint32_t s_dc[2][12];
-    uint8_t* wsf = ws + (long)blockIdx.x * g.ws_frame;
+template <bool EMIT>
+__global__ void __launch_bounds__(256)
+jpeg_entropy_kernel(uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
+    __shared__ uint32_t sAc[2][256];
+    __shared__ uint32_t sDc[2][12];
+    __shared__ uint32_t s_w[8];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 512; i += 256) sAc[i >> 8][i & 255] = tb.ac[i >> 8][i & 255];
+    if (tid < 24) sDc[tid / 12][tid % 12] = tb.dc[tid / 12][tid % 12];
+    __syncthreads();
+    uint8_t* wsf = ws + (long)blockIdx.y * g.ws_frame;
+    const long nblk = (long)g.nmcu * 6;
+    const long gb = (long)blockIdx.x * 256 + tid;                     // block index in scan order: 6 * mcu + b
+    const bool active = gb < nblk;
+    const long gbc = active ? gb : nblk - 1;
+    const long m = gbc / 6;
+    const int b = (int)(gbc % 6), tbl = b >= 4;
+    const uint4* src = (const uint4*)wsf + gbc * 8;
+    uint4 q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = src[i];
     const short* dcs = (const short*)(wsf + g.off_dcs);
-    uint32_t* acbits = (uint32_t*)(wsf + g.off_acbits);
-    uint32_t* off = (uint32_t*)(wsf + g.off_mcuoff);
-    if (threadIdx.x < 24) s_dc[threadIdx.x / 12][threadIdx.x % 12] = tb.dc[threadIdx.x / 12][threadIdx.x % 12];
-    __syncthreads();
-    // walk 1 (coalesced): total bits of every MCU = AC bits + the six DC codes (DC prediction runs across MCUs)
-    for (int m = threadIdx.x; m < g.nmcu; m += 1024) {
-        const short* c = dcs + (long)m * 8;
-        int py = 0, pb = 0, pr = 0;
-        if (m > 0) { py = c[-8 + 3]; pb = c[-8 + 4]; pr = c[-8 + 5]; }
-        uint32_t bits = acbits[m];
-        for (int b = 0; b < 4; ++b) { int d = c[b]; bits += dc_bits(d - py, s_dc[0]); py = d; }
-        bits += dc_bits(c[4] - pb, s_dc[1]) + dc_bits(c[5] - pr, s_dc[1]);
-        acbits[m] = bits;
+    const int dcdiff = (int)(short)(q[0].x & 0xffffu) - dc_pred(dcs, m, b);
+    uint16_t* blkbits = (uint16_t*)(wsf + g.off_blkbits);
+    uint32_t* tiles = (uint32_t*)(wsf + g.off_tiles);
+    BitSink s;
+    s.count = 0;
+    if (!EMIT) {
+        encode_block<false>(s, q, dcdiff, sDc[tbl], sAc[tbl]);
+        if (active) blkbits[gb] = (uint16_t)s.count;
+        const uint32_t sum = block256_sum(active ? s.count : 0u, s_w);
+        if (tid == 0) tiles[blockIdx.x] = sum;
+        return;
     }
-    __threadfence_block();
-    __syncthreads();
-    // walk 2: each thread owns a contiguous run of MCUs
-    const int per = (g.nmcu + 1023) / 1024;
-    const int m0 = threadIdx.x * per, m1 = min(m0 + per, g.nmcu);
-    uint32_t sum = 0;
-    for (int m = m0; m < m1; ++m) sum += acbits[m];
-    uint32_t total;
-    uint32_t base = block_exscan(sum, s_wave, &total);
-    for (int m = m0; m < m1; ++m) { off[m] = base; base += acbits[m]; }
-    if (threadIdx.x == 0) off[g.nmcu] = (total + 7u) & ~7u;           // flush_bits pads the last byte with 1-bits
+    uint32_t prefix, total;
+    tile_prefix(tiles, (int)gridDim.x, (int)blockIdx.x, s_w, prefix, total);
+    const uint32_t G = prefix + block256_exscan(active ? (uint32_t)blkbits[gb] : 0u, s_w);
+    if (!active) return;
+    s.stream = (uint32_t*)(wsf + g.off_stream);
+    s.w = (long)(G >> 5);
+    s.acc = 0;
+    s.fill = (int)(G & 31u);
+    s.first = true;
+    encode_block<true>(s, q, dcdiff, sDc[tbl], sAc[tbl]);
+    if (gb == nblk - 1) {                                             // jchuff.c flush_bits: fill the last byte with ones
+        const int pad = (int)((8u - ((uint32_t)s.fill & 7u)) & 7u);
+        if (pad) put<true>(s, (1u << pad) - 1u, pad);
+    }
+    if (s.fill > 0 && s.acc) atomicOr(&s.stream[s.w], s.acc);
 }
 
-// ---- stage 3 -----------------------------------------------------------------------------------
+// stage 3: zero the words of the stream that will be used; block 0 publishes the (byte-padded) total bit count
 __global__ void __launch_bounds__(256)
 jpeg_zero_kernel(uint8_t* __restrict__ ws, JpegGeom g) {
+    __shared__ uint32_t s_w[8];
     uint8_t* wsf = ws + (long)blockIdx.y * g.ws_frame;
-    const uint32_t total = ((const uint32_t*)(wsf + g.off_mcuoff))[g.nmcu];
+    uint32_t prefix, total;
+    tile_prefix((const uint32_t*)(wsf + g.off_tiles), cdiv_dev((long)g.nmcu * 6, 256), 0, s_w, prefix, total);
+    total = (total + 7u) & ~7u;                                       // flush_bits pads the last byte with 1-bits
+    if (blockIdx.x == 0 && threadIdx.x == 0) *(uint32_t*)(wsf + g.off_total) = total;
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;             // word index, 16 bytes per thread
     long used = ((long)total + 31) / 32 + 4;                          // + slack: the last chunk is read whole
     used = (used + 15) / 16 * 16;
     if (i < used && i < g.cap_words) *(uint4*)(wsf + g.off_stream + i * 4) = make_uint4(0, 0, 0, 0);
-}
-
-// ---- stage 4: Huffman coding ----------------------------------------------------------------------
-// Bit order everywhere: stream bit p lives in word p >> 5 at bit 31 - (p & 31) (MSB first).
-__device__ __forceinline__ void lds_put(uint32_t* buf, int pos, unsigned long long bits, int len) {
-    if (len == 0) return;
-    unsigned long long F = bits << (64 - len);                        // left-aligned field
-    int w = pos >> 5, o = pos & 31;
-    unsigned long long hi = F >> o;
-    uint32_t w0 = (uint32_t)(hi >> 32), w1 = (uint32_t)hi, w2 = o ? (uint32_t)((F << (64 - o)) >> 32) : 0u;
-    if (w0) atomicOr(&buf[w], w0);
-    if (w1) atomicOr(&buf[w + 1], w1);
-    if (w2) atomicOr(&buf[w + 2], w2);
-}
-
-__global__ void __launch_bounds__(256)
-jpeg_huff_kernel(uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
-    __shared__ uint32_t sAc[2][256];
-    __shared__ uint32_t sDc[2][12];
-    __shared__ uint32_t sBuf[4][MCU_LDS_WORDS + 4];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int i = tid; i < 512; i += 256) sAc[i >> 8][i & 255] = tb.ac[i >> 8][i & 255];
-    if (tid < 24) sDc[tid / 12][tid % 12] = tb.dc[tid / 12][tid % 12];
-    uint32_t* buf = sBuf[wv];
-    for (int i = lane; i < MCU_LDS_WORDS + 4; i += 64) buf[i] = 0;
-    __syncthreads();
-    const int m = blockIdx.x * 4 + wv;
-    if (m >= g.nmcu) return;
-    uint8_t* wsf = ws + (long)blockIdx.y * g.ws_frame;
-    const short* c = (const short*)wsf + (long)m * 384;
-    const uint32_t* off = (const uint32_t*)(wsf + g.off_mcuoff);
-    uint32_t* stream = (uint32_t*)(wsf + g.off_stream);
-
-    int prev[3] = {0, 0, 0};
-    if (m > 0) { const short* d = (const short*)(wsf + g.off_dcs) + (long)(m - 1) * 8; prev[0] = d[3]; prev[1] = d[4]; prev[2] = d[5]; }
-    unsigned long long bitsv[6];
-    int lens[6], inc[6];
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-        const int tbl = b >= 4, comp = b < 4 ? 0 : b - 3;
-        int v = c[b * 64 + lane];
-        int dcv = __builtin_amdgcn_readfirstlane(v);
-        unsigned long long nz = __ballot(v != 0 && lane > 0);
-        unsigned long long bits = 0;
-        int len = 0;
-        if (lane == 0) {                                              // DC: category code + the low bits of (diff, or diff-1 if negative)
-            int diff = v - prev[comp];
-            int a = diff < 0 ? -diff : diff, t2 = diff < 0 ? diff - 1 : diff;
-            int nb = a ? 32 - __builtin_clz(a) : 0;
-            uint32_t e = sDc[tbl][nb];
-            bits = ((unsigned long long)(e & 0xffff) << nb) | (unsigned)(t2 & ((1 << nb) - 1));
-            len = (int)(e >> 16) + nb;
-        } else if (v != 0) {
-            int nb, run;
-            int sym = ac_symbol(v, lane, nz, nb, run);
-            uint32_t zrl = sAc[tbl][0xF0], e = sAc[tbl][sym];
-            for (int z = run >> 4; z > 0; --z) { bits = (bits << (zrl >> 16)) | (zrl & 0xffff); len += (int)(zrl >> 16); }
-            int t2 = v < 0 ? v - 1 : v;
-            bits = (((bits << (e >> 16)) | (e & 0xffff)) << nb) | (unsigned)(t2 & ((1 << nb) - 1));
-            len += (int)(e >> 16) + nb;
-        }
-        const int last = nz ? 63 - __builtin_clzll(nz) : 0;          // the lane that owns the end-of-block code
-        if (lane == last && last != 63) { uint32_t e = sAc[tbl][0]; bits = (bits << (e >> 16)) | (e & 0xffff); len += (int)(e >> 16); }
-        prev[comp] = dcv;
-        bitsv[b] = bits; lens[b] = len; inc[b] = len;
-    }
-    for (int o = 1; o < 64; o <<= 1) {                                // six inclusive scans in lockstep (independent shuffles in flight)
-        int u[6];
-#pragma unroll
-        for (int b = 0; b < 6; ++b) u[b] = __shfl_up(inc[b], o);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) if (lane >= o) inc[b] += u[b];
-    }
-    int pos = 0;
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-        lds_put(buf, pos + inc[b] - lens[b], bitsv[b], lens[b]);
-        pos += __builtin_amdgcn_readlane(inc[b], 63);
-    }
-    const uint32_t G = off[m];
-    if (m == g.nmcu - 1) {                                            // jchuff.c flush_bits: fill the last byte with ones
-        int pad = (int)(off[g.nmcu] - (G + (uint32_t)pos));
-        if (lane == 0 && pad) lds_put(buf, pos, (1ull << pad) - 1, pad);
-        pos += pad;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    const int s = (int)(G & 31u);
-    const long gw = (long)(G >> 5);
-    const int nw = (s + pos + 31) >> 5;
-    for (int j = lane; j < nw; j += 64) {
-        uint32_t cur = buf[j];
-        uint32_t val = s ? (((j > 0 ? buf[j - 1] : 0u) << (32 - s)) | (cur >> s)) : cur;
-        if (j == 0 || j == nw - 1) { if (val) atomicOr(&stream[gw + j], val); }
-        else stream[gw + j] = val;
-    }
 }
 
 // ---- stages 5-7: byte stuffing -------------------------------------------------------------------
@@ -501,58 +476,56 @@ __device__ __forceinline__ uint32_t count_ff(uint32_t w) {
 
 __global__ void __launch_bounds__(256)
 jpeg_ffcount_kernel(uint8_t* __restrict__ ws, JpegGeom g) {
+    __shared__ uint32_t s_w[8];
     uint8_t* wsf = ws + (long)blockIdx.y * g.ws_frame;
-    const uint32_t nbytes = ((const uint32_t*)(wsf + g.off_mcuoff))[g.nmcu] >> 3;
+    const uint32_t nbytes = *(const uint32_t*)(wsf + g.off_total) >> 3;
+    if ((long)blockIdx.x * 256 * 64 >= nbytes) return;                // whole thread block beyond the stream
     const long chunk = (long)blockIdx.x * 256 + threadIdx.x;
-    if (chunk * 64 >= nbytes) return;
-    const uint4* p = (const uint4*)(wsf + g.off_stream + chunk * 64);
     uint32_t n = 0;
-    for (int i = 0; i < 4; ++i) {
-        uint4 v = p[i];
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        for (int k = 0; k < 4; ++k) {
-            long byte0 = chunk * 64 + i * 16 + k * 4;
-            if (byte0 + 4 <= nbytes) n += count_ff(w[k]);
-            else for (int q = 0; q < 4; ++q) if (byte0 + q < nbytes) n += ((w[k] >> (24 - 8 * q)) & 0xffu) == 0xffu;
+    if (chunk * 64 < nbytes) {
+        const uint4* p = (const uint4*)(wsf + g.off_stream + chunk * 64);
+        for (int i = 0; i < 4; ++i) {
+            uint4 v = p[i];
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int k = 0; k < 4; ++k) {
+                long byte0 = chunk * 64 + i * 16 + k * 4;
+                if (byte0 + 4 <= nbytes) n += count_ff(w[k]);
+                else for (int q = 0; q < 4; ++q) if (byte0 + q < nbytes) n += ((w[k] >> (24 - 8 * q)) & 0xffu) == 0xffu;
+            }
+        }
+        ((uint32_t*)(wsf + g.off_ffcnt))[chunk] = n;
+    }
+    const uint32_t sum = block256_sum(n, s_w);
+    if (threadIdx.x == 0) ((uint32_t*)(wsf + g.off_fftiles))[blockIdx.x] = sum;
+}
+
+// byte-stuffed copy behind the header; block 0 also writes the header, the EOI marker and the size
+__global__ void __launch_bounds__(256)
+jpeg_stuff_kernel(const uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb, uint8_t* __restrict__ out, long out_stride,
+                  int* __restrict__ sizes) {
+    __shared__ uint32_t s_w[8];
+    const uint8_t* wsf = ws + (long)blockIdx.y * g.ws_frame;
+    const uint32_t nbytes = *(const uint32_t*)(wsf + g.off_total) >> 3;
+    if ((long)blockIdx.x * 256 * 64 >= nbytes) return;
+    const int ntiles = (int)((((long)nbytes + 63) / 64 + 255) / 256);
+    uint32_t prefix, total_ff;
+    tile_prefix((const uint32_t*)(wsf + g.off_fftiles), ntiles, (int)blockIdx.x, s_w, prefix, total_ff);
+    const long size = (long)HDR_LEN + nbytes + total_ff + 2;
+    const bool fits = size <= out_stride;
+    uint8_t* o = out + (long)blockIdx.y * out_stride;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) sizes[blockIdx.y] = fits ? (int)size : -1;
+        if (fits) {
+            for (int i = threadIdx.x; i < HDR_LEN; i += 256) o[i] = tb.header[i];
+            if (threadIdx.x == 0) { o[size - 2] = 0xff; o[size - 1] = 0xd9; }
         }
     }
-    ((uint32_t*)(wsf + g.off_ffcnt))[chunk] = n;
-}
-
-__global__ void __launch_bounds__(1024)
-jpeg_ffscan_kernel(uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb, uint8_t* __restrict__ out, long out_stride,
-                   int* __restrict__ sizes) {
-    __shared__ uint32_t s_wave[17];
-    uint8_t* wsf = ws + (long)blockIdx.x * g.ws_frame;
-    const uint32_t nbytes = ((const uint32_t*)(wsf + g.off_mcuoff))[g.nmcu] >> 3;
-    uint32_t* cnt = (uint32_t*)(wsf + g.off_ffcnt);
-    const int nch = (int)((nbytes + 63) / 64);
-    const int per = (nch + 1023) / 1024;
-    const int c0 = threadIdx.x * per, c1 = min(c0 + per, nch);
-    uint32_t sum = 0;
-    for (int i = c0; i < c1; ++i) sum += cnt[i];
-    uint32_t total;
-    uint32_t base = block_exscan(sum, s_wave, &total);
-    for (int i = c0; i < c1; ++i) { uint32_t n = cnt[i]; cnt[i] = base; base += n; }
-    const long size = (long)HDR_LEN + nbytes + total + 2;
-    uint8_t* o = out + (long)blockIdx.x * out_stride;
-    const bool fits = size <= out_stride;
-    if (threadIdx.x == 0) { sizes[blockIdx.x] = fits ? (int)size : -1; cnt[nch] = fits ? 1u : 0u; }
-    if (!fits) return;
-    for (int i = threadIdx.x; i < HDR_LEN; i += 1024) o[i] = tb.header[i];
-    if (threadIdx.x == 0) { o[size - 2] = 0xff; o[size - 1] = 0xd9; }
-}
-
-__global__ void __launch_bounds__(256)
-jpeg_stuff_kernel(const uint8_t* __restrict__ ws, JpegGeom g, uint8_t* __restrict__ out, long out_stride) {
-    const uint8_t* wsf = ws + (long)blockIdx.y * g.ws_frame;
-    const uint32_t nbytes = ((const uint32_t*)(wsf + g.off_mcuoff))[g.nmcu] >> 3;
     const long chunk = (long)blockIdx.x * 256 + threadIdx.x;
-    if (chunk * 64 >= nbytes) return;
-    const uint32_t* cnt = (const uint32_t*)(wsf + g.off_ffcnt);
-    const int nch = (int)((nbytes + 63) / 64);
-    if (cnt[nch] == 0u) return;                                       // output too small: nothing is written
-    uint8_t* o = out + (long)blockIdx.y * out_stride + HDR_LEN + chunk * 64 + cnt[chunk];
+    const bool live = chunk * 64 < nbytes;
+    const uint32_t mine = live ? ((const uint32_t*)(wsf + g.off_ffcnt))[chunk] : 0u;
+    const uint32_t before = prefix + block256_exscan(mine, s_w);
+    if (!live || !fits) return;                                       // output too small: nothing but the size (-1) is written
+    o += HDR_LEN + chunk * 64 + before;
     const uint4* p = (const uint4*)(wsf + g.off_stream + chunk * 64);
     const int n = (int)min((long)64, (long)nbytes - chunk * 64);
     for (int i = 0; i < 4; ++i) {
@@ -598,12 +571,12 @@ extern "C" int d2s_jpeg_encode(const void* frames, int fmt, int batch, int H, in
     dim3 g1(cdiv(g.mc, DCT_MCUS), g.mr, batch);
     if (fmt == D2S_FMT_U8_HWC) hipLaunchKernelGGL(jpeg_dct_kernel<D2S_FMT_U8_HWC>, g1, dim3(256), 0, st, frames, ws, g, tb);
     else hipLaunchKernelGGL(jpeg_dct_kernel<D2S_FMT_F32_HWC>, g1, dim3(256), 0, st, frames, ws, g, tb);
-    hipLaunchKernelGGL(jpeg_scan_kernel, dim3(batch), dim3(1024), 0, st, ws, g, tb);
+    const dim3 ge(cdiv((long)g.nmcu * 6, 256), batch), gc(cdiv(g.n_chunks, 256), batch);
+    hipLaunchKernelGGL(jpeg_entropy_kernel<false>, ge, dim3(256), 0, st, ws, g, tb);
     hipLaunchKernelGGL(jpeg_zero_kernel, dim3(cdiv(g.cap_words, 1024), batch), dim3(256), 0, st, ws, g);
-    hipLaunchKernelGGL(jpeg_huff_kernel, dim3(cdiv(g.nmcu, 4), batch), dim3(256), 0, st, ws, g, tb);
-    hipLaunchKernelGGL(jpeg_ffcount_kernel, dim3(cdiv(g.n_chunks, 256), batch), dim3(256), 0, st, ws, g);
-    hipLaunchKernelGGL(jpeg_ffscan_kernel, dim3(batch), dim3(1024), 0, st, ws, g, tb, out, (long)out_stride, sizes);
-    hipLaunchKernelGGL(jpeg_stuff_kernel, dim3(cdiv(g.n_chunks, 256), batch), dim3(256), 0, st, (const uint8_t*)ws, g, out, (long)out_stride);
+    hipLaunchKernelGGL(jpeg_entropy_kernel<true>, ge, dim3(256), 0, st, ws, g, tb);
+    hipLaunchKernelGGL(jpeg_ffcount_kernel, gc, dim3(256), 0, st, ws, g);
+    hipLaunchKernelGGL(jpeg_stuff_kernel, gc, dim3(256), 0, st, (const uint8_t*)ws, g, tb, out, (long)out_stride, sizes);
     D2S_CHECK_LAUNCH();
     return D2S_OK;
 }
