@@ -136,6 +136,7 @@ def main():
                     help="extra measurement (N=1): BASELINE config 5, this many frames per step drawn with seed 0 from "
                          "{1280x720, 1920x1080, 2560x1440} -- one batched model pass, per-size pre-process and warp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sink-quality", type=int, default=90, help="also time the step with the MJPEG sink behind it (0 = off)")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 
@@ -280,6 +281,39 @@ def main():
                            "ms_per_step": 1e3 * dtm / stepsm,
                            "workload": f"{NM} frames/step, sizes seed 0: " + ", ".join(f"{len(groups[s])}x{s[1]}x{s[0]}" for s in sizes)
                                        + f"; one {cfg.name} {args.precision} batch at {h}x{w}; {args.mode}"}
+
+    if rank == 0 and world == 1 and args.sink_quality > 0:
+        # the Streamer modes' sink (cv2.imencode -> here the HIP JPEG encoder) behind the same step,
+        # frame never leaving HBM.  Reported beside the headline number, not in it (the metric ends at make_sbs).
+        q = args.sink_quality
+        sink_step = lambda i: ops.jpeg_encode(step(i), q)
+        dts = timed(sink_step, max(3, args.warmup // 4), args.steps)
+        frames_out = step(0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            jb, jsz = ops.jpeg_encode(frames_out, q)
+        e1.record()
+        torch.cuda.synchronize()
+        enc_us = e0.elapsed_time(e1) * 1e3 / 20 / B
+        jbytes = float(jsz.float().mean())
+        result["sink_jpeg"] = {"value": args.steps * B / dts, "unit": "stereo frames/s incl. JPEG encode", "quality": q,
+                               "encode_us_per_frame": enc_us, "jpeg_mb_per_frame": jbytes / 1e6,
+                               "roofline": {"bound": "hbm", "achieved": (oh * ow * 3 + jbytes) / enc_us / 1e3, "peak": PEAK_HBM_GBS,
+                                            "unit": "GB/s", "frac": (oh * ow * 3 + jbytes) / enc_us / 1e3 / PEAK_HBM_GBS},
+                               "note": "noise frames: the largest entropy-coded stream a frame can produce"}
+        try:                                             # libjpeg-turbo on one host core, same frame (Pillow, if present)
+            import io
+            from PIL import Image
+            host = frames_out[0].cpu().numpy()
+            t0 = time.perf_counter()
+            buf = io.BytesIO()
+            Image.fromarray(host).save(buf, "JPEG", quality=q, subsampling="4:2:0", optimize=False)
+            result["sink_jpeg"]["cpu_libjpeg_turbo_ms_per_frame"] = 1e3 * (time.perf_counter() - t0)
+            result["sink_jpeg"]["identical_to_libjpeg_turbo"] = buf.getvalue() == jb[0, :int(jsz[0])].cpu().numpy().tobytes()
+        except ImportError:
+            pass
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, weights, p, H, W, args.mode)

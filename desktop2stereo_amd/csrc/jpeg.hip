@@ -461,10 +461,13 @@ jpeg_zero_kernel(uint8_t* __restrict__ ws, JpegGeom g) {
     tile_prefix((const uint32_t*)(wsf + g.off_tiles), cdiv_dev((long)g.nmcu * 6, 256), 0, s_w, prefix, total);
     total = (total + 7u) & ~7u;                                       // flush_bits pads the last byte with 1-bits
     if (blockIdx.x == 0 && threadIdx.x == 0) *(uint32_t*)(wsf + g.off_total) = total;
-    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;             // word index, 16 bytes per thread
     long used = ((long)total + 31) / 32 + 4;                          // + slack: the last chunk is read whole
-    used = (used + 15) / 16 * 16;
-    if (i < used && i < g.cap_words) *(uint4*)(wsf + g.off_stream + i * 4) = make_uint4(0, 0, 0, 0);
+    used = min((used + 15) / 16 * 16, g.cap_words);
+    const long base = (long)blockIdx.x * 4096;                        // 4096 words per block, 4 x 16 bytes per thread
+    for (int r = 0; r < 4; ++r) {
+        long i = base + (long)(r * 256 + threadIdx.x) * 4;
+        if (i < used) *(uint4*)(wsf + g.off_stream + i * 4) = make_uint4(0, 0, 0, 0);
+    }
 }
 
 // ---- stages 5-7: byte stuffing -------------------------------------------------------------------
@@ -573,7 +576,7 @@ extern "C" int d2s_jpeg_encode(const void* frames, int fmt, int batch, int H, in
     else hipLaunchKernelGGL(jpeg_dct_kernel<D2S_FMT_F32_HWC>, g1, dim3(256), 0, st, frames, ws, g, tb);
     const dim3 ge(cdiv((long)g.nmcu * 6, 256), batch), gc(cdiv(g.n_chunks, 256), batch);
     hipLaunchKernelGGL(jpeg_entropy_kernel<false>, ge, dim3(256), 0, st, ws, g, tb);
-    hipLaunchKernelGGL(jpeg_zero_kernel, dim3(cdiv(g.cap_words, 1024), batch), dim3(256), 0, st, ws, g);
+    hipLaunchKernelGGL(jpeg_zero_kernel, dim3(cdiv(g.cap_words, 4096), batch), dim3(256), 0, st, ws, g);
     hipLaunchKernelGGL(jpeg_entropy_kernel<true>, ge, dim3(256), 0, st, ws, g, tb);
     hipLaunchKernelGGL(jpeg_ffcount_kernel, gc, dim3(256), 0, st, ws, g);
     hipLaunchKernelGGL(jpeg_stuff_kernel, gc, dim3(256), 0, st, (const uint8_t*)ws, g, tb, out, (long)out_stride, sizes);
