@@ -29,6 +29,10 @@ struct Layer {
     // scales; deq[i][n] = s_act(site feeding linear i) * s_w[i][n] is filled in by d2s_engine_calibrate
     PackedW w8[4];
     std::vector<float> sw[4];
+    // LayerNorm folded into the linears that consume it (bf16 engines): W' = W diag(gamma) packed like qkv / fc1,
+    // bias' = b + W beta in *_ln.bias, csum[n] = sum_k bf16(W'[n][k]) (the values the MFMA actually sums)
+    PackedW qkv_ln, fc1_ln;
+    float *csum_qkv = nullptr, *csum_fc1 = nullptr;
     float* deq[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -98,6 +102,8 @@ struct d2s_engine {
     int last_batch = 0;
     // D2S_PREC_FP8 (BASELINE config 3): encoder linears on e4m3 operands once calibrated
     bool fp8 = false, fp8_ready = false, calib = false;
+    bool lnf = false;                 // LayerNorm folded into the producing / consuming linears (bf16, not fp8)
+    float* lnstats = nullptr;         // [slots][M][2] partial row sums written by the residual-update GEMMs
     float* amax = nullptr;                         // device [layers][4]: max |.| of LN1 out, attention out, LN2 out, GELU out
     std::vector<float> act_scale;                  // host   [layers][4]: amax / 448
     // per-kernel-class timing with HIP events (d2s_engine_profile): off in the throughput path
@@ -296,7 +302,7 @@ GemmEpi rowsE(void* out, int out_type, long ldc, const float* bias) {
 int gemm(d2s_engine* e, const GemmA& a, const PackedW& w, int M, const GemmEpi& ep, hipStream_t st) {
     int Kl = w.K % (e->prec == D2S_PREC_BF16 ? 8 : 4) ? w.Kpad : w.K;   // ragged K (patch embed): A is zero padded to Kpad
     GemmEpi ep2 = ep;
-    if (ep.map == MAP_ROWS) {                      // launcher decides whether to split K; each stream has its own partials
+    if (ep.map == MAP_ROWS && !ep.stats_out) {     // launcher decides whether to split K; each stream has its own partials
         ep2.part = (e->side && st == e->side) ? e->splitk_ws_side : e->splitk_ws;
         ep2.part_elems = e->splitk_elems;
     }
@@ -414,17 +420,25 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     // D2S_PREC_FP8: the producers of the four linears' A operands write e4m3 (x / s_act, saturated); the linears run on
     // e4m3 operands and de-quantise in their epilogue (deq[n] = s_act * s_w[n]); QKV still emits bf16 for the attention
     const bool f8 = e->fp8 && !e->calib;
+    // measured (ViT-B @294x518): folding wins 7 % at 1 frame, 3-5 % at 2-4, is even at 8 and loses 2 % at 16 (the LN
+    // kernels' launch floor is amortised there and the wider epilogues are not) -> folded up to 8 frames
+    const bool lnf = e->lnf && !e->fp8 && !e->calib && prec == D2S_PREC_BF16 && B <= 8;
+    int ln_slots = 0;
     for (int l = 0; l < d.layers; ++l) {
         const Layer& ly = e->L[l];
         const float* sa = f8 ? &e->act_scale[(size_t)l * 4] : nullptr;     // s_act of LN1 out, attention out, LN2 out, GELU out
         float* am = e->calib ? e->amax + (size_t)l * 4 : nullptr;
-        PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln1g, ly.ln1b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[0] : 0.f));
+        // lnf: the previous layer's FC2 epilogue left the raw bf16 residual in lnbuf and the row statistics in lnstats;
+        // LN1 then happens inside the QKV linear (layer 0 has no such producer and runs the LN kernel)
+        const bool ln1_folded = lnf && l > 0 && ln_slots <= 16;
+        if (!ln1_folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln1g, ly.ln1b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[0] : 0.f));
         if (am) RC(launch_amax(prec, e->lnbuf, (long)M * D, am + 0, st));
         {
-            GemmEpi ep = rowsE(e->qkv, f8 ? OUT_BF16 : OUT_T, 3 * D, ly.qkv.bias);
+            GemmEpi ep = rowsE(e->qkv, f8 ? OUT_BF16 : OUT_T, 3 * D, ln1_folded ? ly.qkv_ln.bias : ly.qkv.bias);
             ep.map = MAP_QKV; ep.vt = e->vt; ep.ntok = N; ep.npad = e->Npad; ep.qk_cols = 2 * D; ep.heads = d.heads;
+            if (ln1_folded) { ep.ln_stats = e->lnstats; ep.ln_slots = ln_slots; ep.ln_csum = ly.csum_qkv; ep.ln_eps = d.ln_eps; ep.ln_dim = D; }
             if (f8) { ep.deq = ly.deq[0]; RC(gemm8(e, plainA(e->lnbuf, D), ly.w8[0], M, ep, st)); }
-            else RC(gemm(e, plainA(e->lnbuf, D), ly.qkv, M, ep, st));
+            else RC(gemm(e, plainA(e->lnbuf, D), ln1_folded ? ly.qkv_ln : ly.qkv, M, ep, st));
         }
         PROF(PC_ATTN, 4.0 * B * d.heads * (double)N * N * 64, 0,
              launch_attention(prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st, f8 ? 1.0f / sa[1] : 0.f));
@@ -432,21 +446,25 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         {
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.proj.bias);
             ep.scale = ly.ls1; ep.res1 = e->resid;
+            if (lnf) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; }
             if (f8) { ep.deq = ly.deq[1]; RC(gemm8(e, plainA(e->attn, D), ly.w8[1], M, ep, st)); }
             else RC(gemm(e, plainA(e->attn, D), ly.proj, M, ep, st));
         }
-        PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln2g, ly.ln2b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[2] : 0.f));
+        const bool ln2_folded = lnf && ln_slots <= 16;              // (more than 16 column blocks: the LN kernel runs instead)
+        if (!ln2_folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln2g, ly.ln2b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[2] : 0.f));
         if (am) RC(launch_amax(prec, e->lnbuf, (long)M * D, am + 2, st));
         {
-            GemmEpi ep = rowsE(e->mlp, OUT_T, d.mlp, ly.fc1.bias);
+            GemmEpi ep = rowsE(e->mlp, OUT_T, d.mlp, ln2_folded ? ly.fc1_ln.bias : ly.fc1.bias);
             ep.act = ACT_GELU;
+            if (ln2_folded) { ep.ln_stats = e->lnstats; ep.ln_slots = ln_slots; ep.ln_csum = ly.csum_fc1; ep.ln_eps = d.ln_eps; ep.ln_dim = D; }
             if (f8) { ep.deq = ly.deq[2]; ep.out_qscale = 1.0f / sa[3]; RC(gemm8(e, plainA(e->lnbuf, D), ly.w8[2], M, ep, st)); }
-            else RC(gemm(e, plainA(e->lnbuf, D), ly.fc1, M, ep, st));
+            else RC(gemm(e, plainA(e->lnbuf, D), ln2_folded ? ly.fc1_ln : ly.fc1, M, ep, st));
         }
         if (am) RC(launch_amax(prec, e->mlp, (long)M * d.mlp, am + 3, st));
         {
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.fc2.bias);
             ep.scale = ly.ls2; ep.res1 = e->resid;
+            if (lnf && l + 1 < d.layers) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; }
             if (f8) { ep.deq = ly.deq[3]; RC(gemm8(e, plainA(e->mlp, d.mlp), ly.w8[3], M, ep, st)); }
             else RC(gemm(e, plainA(e->mlp, d.mlp), ly.fc2, M, ep, st));
         }
@@ -539,7 +557,11 @@ extern "C" int d2s_engine_create(const d2s_model_desc* desc, int device_id, d2s_
     D2S_HIP(hipSetDevice(device_id));
     d2s_engine* e = new d2s_engine();
     e->d = *desc; e->device = device_id;
-    e->fp8 = desc->precision == D2S_PREC_FP8;                  // bf16 engine whose encoder linears switch to e4m3 operands
+    e->fp8 = desc->precision == D2S_PREC_FP8;
+    {   // LayerNorm fusion: bf16 engines only (fp32 is the parity class; the e4m3 path quantises the LN output itself)
+        const char* no = getenv("D2S_NO_LNFUSE");
+        e->lnf = desc->precision == D2S_PREC_BF16 && !(no && atoi(no) != 0);
+    }                  // bf16 engine whose encoder linears switch to e4m3 operands
     e->prec = e->fp8 ? D2S_PREC_BF16 : desc->precision;
     const char* t = getenv("D2S_TAPS");
     e->taps = t && atoi(t) != 0;
@@ -602,6 +624,29 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
         RC(pack_linear(e, p + "attention.output.dense.weight", p + "attention.output.dense.bias", D, D, ly.proj));
         RC(pack_linear(e, p + "mlp.fc1.weight", p + "mlp.fc1.bias", d.mlp, D, ly.fc1));
         RC(pack_linear(e, p + "mlp.fc2.weight", p + "mlp.fc2.bias", D, d.mlp, ly.fc2));
+        if (e->lnf) {
+            // LN(x) W^T + b  =  rstd * (x W'^T - mean * colsum(W')) + (b + W beta),  W' = W diag(gamma)
+            auto fold = [&](const HostT* g, const HostT* bt, int Nn, auto at, const float* bias, PackedW& out, float** csum) -> int {
+                std::vector<float> b2(Nn), cs(Nn);
+                for (int n = 0; n < Nn; ++n) {
+                    double sb = bias[n], sc = 0.0;
+                    for (int k = 0; k < D; ++k) { sb += (double)bt->data[k] * at(n, k); sc += bf2f(f2bf(g->data[k] * at(n, k))); }
+                    b2[n] = (float)sb; cs[n] = (float)sc;
+                }
+                int rc = pack_matrix(e, Nn, D, [&](int n, int k) { return g->data[k] * at(n, k); }, b2.data(), out);
+                if (rc) return rc;
+                rc = dev_alloc(e, (void**)csum, (size_t)Nn * sizeof(float));
+                if (rc) return rc;
+                D2S_HIP(hipMemcpy(*csum, cs.data(), (size_t)Nn * sizeof(float), hipMemcpyHostToDevice));
+                return D2S_OK;
+            };
+            const HostT *g1 = find(e, p + "norm1.weight"), *b1 = find(e, p + "norm1.bias"), *g2 = find(e, p + "norm2.weight"), *b2 = find(e, p + "norm2.bias");
+            const HostT *w1t = find(e, p + "mlp.fc1.weight"), *b1t = find(e, p + "mlp.fc1.bias");
+            if (!g1 || !b1 || !g2 || !b2 || !w1t || !b1t) return D2S_E_MISSING;
+            RC(fold(g1, b1, 3 * D, [&](int n, int k) { return ws[n / D][(size_t)(n % D) * D + k]; }, bias.data(), ly.qkv_ln, &ly.csum_qkv));
+            const float* w1p = w1t->data.data();
+            RC(fold(g2, b2, d.mlp, [&](int n, int k) { return w1p[(size_t)n * D + k]; }, b1t->data.data(), ly.fc1_ln, &ly.csum_fc1));
+        }
         if (e->fp8) {
             const float* wo = find(e, p + "attention.output.dense.weight")->data.data();
             const float* w1 = find(e, p + "mlp.fc1.weight")->data.data();
@@ -644,6 +689,7 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
     const size_t M = (size_t)B * N, Mp = (size_t)B * P;
     RC(dev_alloc(e, (void**)&e->resid, M * D * 4));
     RC(dev_alloc(e, &e->lnbuf, M * D * es));
+    if (e->lnf) RC(dev_alloc(e, (void**)&e->lnstats, (size_t)(D / 16 + 1) * M * 2 * sizeof(float)));
     RC(dev_alloc(e, &e->qkv, M * 3 * D * es));
     RC(dev_alloc(e, &e->vt, (size_t)B * D * e->Npad * es, true));     // zero beyond N, never written there
     RC(dev_alloc(e, &e->attn, M * D * es));

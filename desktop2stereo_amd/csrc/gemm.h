@@ -47,6 +47,14 @@ struct GemmEpi {
     // into real values before bias.  out_qscale = 1 / s_out for an e4m3 output (OUT_T with fp8 operands).
     const float* deq;
     float out_qscale;
+    // LayerNorm folded into the linears either side of it (bf16 encoder; DESIGN.md §3.1 "LayerNorm fusion").
+    // Producer (OUT_F32, MAP_ROWS -- the residual update): every stored value also goes to out2 as bf16 (same offsets),
+    // and each block writes the (sum v, sum v^2) of its BN columns for every row: stats_out[column block][M][2]; the
+    // launcher reports the number of column blocks through stats_slots (host int; the consumer takes at most 16).
+    void* out2; float* stats_out; int* stats_slots;
+    // Consumer: A rows are the RAW bf16 residual and W is gamma-folded, so LN(x) W = rstd * (x W' - mean * colsum(W'));
+    // the kernel applies v = rstd[m] * (acc - mean[m] * ln_csum[n]) before bias (bias already holds b + W beta).
+    const float* ln_stats; int ln_slots; const float* ln_csum; float ln_eps; int ln_dim;
 };
 
 // precision: D2S_PREC_FP32 (T = float) / D2S_PREC_BF16 (T = bf16) / D2S_PREC_FP8_OPERANDS (T = e4m3).  tile: 0 = auto.

@@ -132,6 +132,7 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float
     if (e.res2) { float r[4]; load4((const OT*)e.res2 + off, r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
     if constexpr (std::is_same<OT, fp8_t>::value) { v[0] *= e.out_qscale; v[1] *= e.out_qscale; v[2] *= e.out_qscale; v[3] *= e.out_qscale; }
     store4((OT*)e.out + off, v);
+    if constexpr (std::is_same<OT, float>::value) { if (e.out2) store4((bf16_t*)e.out2 + off, v); }   // raw bf16 residual for the LN-folded consumer
 }
 
 // out_type -> element type of the output / residuals
@@ -313,6 +314,24 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     const int kt0 = (int)(((long)nkt_all * blockIdx.y) / ksplit);
     const int nkt = (int)(((long)nkt_all * (blockIdx.y + 1)) / ksplit) - kt0;
     const int fr = lane & 15, fg = lane >> 4;
+    // LN-folded consumer: the producer left (sum, sum of squares) per row and column block in e.ln_stats[slot][M][2].
+    // The 4 lane groups of a row share the slots (slot = fg + 4q); the loads are issued here, before the K loop, and
+    // summed after it.  (Registers, not LDS: a second __shared__ object makes the compiler track the LDS-DMA writes
+    // and put s_waitcnt vmcnt(0) in front of every fragment read.)
+    constexpr bool LN_ON = WN > 1;                  // the WN == 1 (fused-head) tiles never see an LN-folded linear
+    constexpr int LNS = LN_ON ? 4 : 1;              // <= 16 column blocks
+    float2 lnp[FM][LNS];
+    if (LN_ON && e.ln_stats) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = bm0 + wave_m * (BM / WM) + i * 16 + fr;
+#pragma unroll
+            for (int q = 0; q < LNS; ++q) {
+                const int sl = fg + 4 * q;
+                lnp[i][q] = (m < M && sl < e.ln_slots) ? ((const float2*)e.ln_stats)[(long)sl * M + m] : make_float2(0.f, 0.f);
+            }
+        }
+    }
     // RELU is a literal: the K loop exists twice (with / without ReLU-on-load) so that plain linears do not pay
     // 4 v_pk_max per A fragment (a third of the loop's VALU work) for an identity
 #define D2S_COMPUTE(KT, RELU)                                                                                    \
@@ -394,11 +413,22 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
         }
     }
 
+    float2 ln_s[FM];
     // compile-time indices (a plain `#pragma unroll` over this large body is not honoured for the
     // 32-fragment tiles, and a run-time index would put the accumulators in scratch)
     static_for<FM>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int m = bm0 + wave_m * (BM / WM) + i * 16 + fr;
+        float s1 = 0.f, s2 = 0.f;                  // LN-folded producer: this lane's share of the row's sum / sum of squares
+        float ln_mean = 0.f, ln_rstd = 1.f;
+        if (LN_ON && e.ln_csum) {
+            float t1 = (lnp[i][0].x + lnp[i][1 % LNS].x) + (lnp[i][2 % LNS].x + lnp[i][3 % LNS].x);
+            float t2 = (lnp[i][0].y + lnp[i][1 % LNS].y) + (lnp[i][2 % LNS].y + lnp[i][3 % LNS].y);
+            t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+            ln_mean = t1 / (float)e.ln_dim;
+            ln_rstd = rsqrtf(fmaxf(t2 / (float)e.ln_dim - ln_mean * ln_mean, 0.f) + e.ln_eps);
+        }
         if (m < M) {
             static_for<FN>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
@@ -406,11 +436,40 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
                 if (n0 < N) {
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     if (ksplit > 1) store4(e.part + ((long)blockIdx.y * M + m) * N + n0, v);     // reduced by splitk_reduce_kernel
-                    else epilogue_dispatch<T>(e, m, n0, v);
+                    else {
+                        if (LN_ON && e.ln_csum) {
+                            float cs[4]; load4(e.ln_csum + n0, cs);
+                            v[0] = ln_rstd * (v[0] - ln_mean * cs[0]); v[1] = ln_rstd * (v[1] - ln_mean * cs[1]);
+                            v[2] = ln_rstd * (v[2] - ln_mean * cs[2]); v[3] = ln_rstd * (v[3] - ln_mean * cs[3]);
+                        }
+                        epilogue_dispatch<T>(e, m, n0, v);
+                        s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                        s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    }
                 }
             });
         }
+        if (LN_ON && e.stats_out) {                 // the 4 lane groups of a row hold 4 columns each of every fragment
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            ln_s[i] = make_float2(s1, s2);
+        }
     });
+    if (LN_ON && e.stats_out) {
+        // the block's WN waves cover BN columns of the same rows: add them up through the (now idle) stage memory so the
+        // consumer reads one partial per column block.  Fixed order -> bit-reproducible.
+        float2* red = (float2*)lds;
+        __syncthreads();                            // every wave is done reading its last fragments
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+            if (fg == 0) red[wave_n * BM + wave_m * (BM / WM) + i * 16 + fr] = ln_s[i];
+        __syncthreads();
+        for (int r = tid; r < BM; r += 64 * NW) {
+            float2 t = red[r];
+            for (int w = 1; w < WN; ++w) { t.x += red[w * BM + r].x; t.y += red[w * BM + r].y; }
+            if (bm0 + r < M) ((float2*)e.stats_out)[(long)(bn0 / BN) * M + bm0 + r] = t;
+        }
+    }
 }
 
 // split-K second pass: sum the fp32 partials of all splits and run the fused epilogue once
@@ -579,6 +638,7 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
         return;
     }
     GemmEpi e1 = e; e1.ksplit = 1;
+    if (e.stats_slots) *e.stats_slots = WN > 1 ? cdiv(N, BN) : 1 << 20;        // WN == 1 tiles write no statistics: the caller falls back
     hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn);
 }
 

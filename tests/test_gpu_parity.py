@@ -284,6 +284,32 @@ def test_tiny_engine_bf16(dev, golden_dir):
         assert d.max() <= 0.06 and d.mean() <= 0.008, (fi, d.max(), d.mean())   # 19-token KAT model: little averaging
 
 
+def test_layernorm_fusion_equals_separate_kernels(dev, monkeypatch):
+    """bf16 engines fold LN1 / LN2 into the linears either side (statistics from the residual-update GEMM's epilogue,
+    gamma folded into W, mean / rstd applied in the consumer's epilogue) for batches <= 8.  Same arithmetic up to bf16
+    rounding of the raw vs the normalised residual: compare against the engine with the LN kernels (D2S_NO_LNFUSE=1)."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS, engine_shape
+    from desktop2stereo_amd.weights import make_weights
+    for model, B in (("vits", 2), ("vitb", 1)):
+        cfg = MODELS[model]
+        wts = make_weights(cfg, 0)
+        h, w, _ = engine_shape(1080, 1920, 518)
+        x = ops.preprocess(torch.stack([_t(synth.structured_frame(1080, 1920, s), dev) for s in range(B)]), 518)
+        outs = []
+        for off in ("0", "1"):
+            monkeypatch.setenv("D2S_NO_LNFUSE", off)
+            eng = ops.Engine(cfg, wts, h, w, B, "bf16")
+            outs.append(eng(x).cpu().numpy())
+            again = eng(x).cpu().numpy()
+            assert np.array_equal(outs[-1], again)                    # fixed-order partial sums: bit-reproducible
+            eng.close()
+        scale = float(np.abs(outs[1]).max())
+        d = np.abs(outs[0] - outs[1])
+        print(f"[{model} B={B}] fused vs separate LN: max {d.max() / scale:.4f} mean {d.mean() / scale:.5f} of the depth range")
+        assert d.max() <= 0.03 * scale and d.mean() <= 0.004 * scale, (d.max() / scale, d.mean() / scale)
+
+
 @pytest.mark.parametrize("name,model,res", [("tiny_r518", "tiny", 518), ("vits_r518", "vits", 518),
                                             ("vits_r336", "vits", 336), ("vitb_r518", "vitb", 518),
                                             ("vitl_r518_4k", "vitl", 518)])
