@@ -420,9 +420,10 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     // D2S_PREC_FP8: the producers of the four linears' A operands write e4m3 (x / s_act, saturated); the linears run on
     // e4m3 operands and de-quantise in their epilogue (deq[n] = s_act * s_w[n]); QKV still emits bf16 for the attention
     const bool f8 = e->fp8 && !e->calib;
-    // measured (ViT-B @294x518): folding wins 7 % at 1 frame, 3-5 % at 2-4, is even at 8 and loses 2 % at 16 (the LN
-    // kernels' launch floor is amortised there and the wider epilogues are not) -> folded up to 8 frames
-    const bool lnf = e->lnf && !e->fp8 && !e->calib && prec == D2S_PREC_BF16 && B <= 8;
+    // measured (ViT-B @294x518): folding wins 7 % at 1 frame, 3-5 % at 2-4, 2 % at 8, is even at 16 and loses 1 % at 32
+    // (the LN kernels' launch floor is amortised there and the wider epilogues are not) -> folded up to 16 frames
+    static const int lnf_maxb = getenv("D2S_LNF_MAXB") ? atoi(getenv("D2S_LNF_MAXB")) : 16;      // tuning aid
+    const bool lnf = e->lnf && !e->fp8 && !e->calib && prec == D2S_PREC_BF16 && B <= lnf_maxb;
     int ln_slots = 0;
     for (int l = 0; l < d.layers; ++l) {
         const Layer& ly = e->L[l];

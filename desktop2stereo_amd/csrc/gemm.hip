@@ -414,6 +414,15 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     }
 
     float2 ln_s[FM];
+    float ln_cs[FN][4];                             // colsum(W') of this lane's columns: independent of the row fragment
+    if (LN_ON && e.ln_csum) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n0 = bn0 + wave_n * (BN / WN) + j * 16 + fg * 4;
+            if (n0 < N) load4(e.ln_csum + n0, ln_cs[j]);
+            else { ln_cs[j][0] = ln_cs[j][1] = ln_cs[j][2] = ln_cs[j][3] = 0.f; }
+        }
+    }
     // compile-time indices (a plain `#pragma unroll` over this large body is not honoured for the
     // 32-fragment tiles, and a run-time index would put the accumulators in scratch)
     static_for<FM>([&](auto ic) {
@@ -438,9 +447,8 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
                     if (ksplit > 1) store4(e.part + ((long)blockIdx.y * M + m) * N + n0, v);     // reduced by splitk_reduce_kernel
                     else {
                         if (LN_ON && e.ln_csum) {
-                            float cs[4]; load4(e.ln_csum + n0, cs);
-                            v[0] = ln_rstd * (v[0] - ln_mean * cs[0]); v[1] = ln_rstd * (v[1] - ln_mean * cs[1]);
-                            v[2] = ln_rstd * (v[2] - ln_mean * cs[2]); v[3] = ln_rstd * (v[3] - ln_mean * cs[3]);
+                            v[0] = ln_rstd * (v[0] - ln_mean * ln_cs[j][0]); v[1] = ln_rstd * (v[1] - ln_mean * ln_cs[j][1]);
+                            v[2] = ln_rstd * (v[2] - ln_mean * ln_cs[j][2]); v[3] = ln_rstd * (v[3] - ln_mean * ln_cs[j][3]);
                         }
                         epilogue_dispatch<T>(e, m, n0, v);
                         s1 += (v[0] + v[1]) + (v[2] + v[3]);

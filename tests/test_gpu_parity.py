@@ -286,7 +286,7 @@ def test_tiny_engine_bf16(dev, golden_dir):
 
 def test_layernorm_fusion_equals_separate_kernels(dev, monkeypatch):
     """bf16 engines fold LN1 / LN2 into the linears either side (statistics from the residual-update GEMM's epilogue,
-    gamma folded into W, mean / rstd applied in the consumer's epilogue) for batches <= 8.  Same arithmetic up to bf16
+    gamma folded into W, mean / rstd applied in the consumer's epilogue) for batches <= 16.  Same arithmetic up to bf16
     rounding of the raw vs the normalised residual: compare against the engine with the LN kernels (D2S_NO_LNFUSE=1)."""
     from desktop2stereo_amd import ops, synth
     from desktop2stereo_amd.config import MODELS, engine_shape
