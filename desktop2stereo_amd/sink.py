@@ -50,12 +50,46 @@ def encode_jpeg(arr, quality: int = 90) -> bytes:
 
 class MJPEGEncoder:
     """The encode half of ``MJPEGStreamer`` (reference streamer.py:37-44, 230-257): fixed quality, latest-frame
-    semantics; the HTTP half is out of scope."""
+    semantics.  The reference encodes on a separate thread (``_encoder_loop``) while the main loop produces the next
+    frame; here the encode is queued on the encoder's own HIP stream, so its small kernels fill the gaps of the next
+    frame's model pass instead of extending the frame time.  The HTTP half is out of scope."""
 
     def __init__(self, quality: int = 90):
         self.quality = int(quality)
         self.encoded_frame: Optional[bytes] = None
+        self._stream: Optional[torch.cuda.Stream] = None
+        self._pending = None
 
-    def set_frame(self, frame) -> bytes:
-        self.encoded_frame = encode_jpeg(frame, self.quality)
+    def set_frame(self, frame) -> None:
+        """Queue the encode of one HWC RGB frame (device tensor or numpy) behind the work already issued on the current
+        stream; returns at once.  The frame's memory must stay untouched until ``wait()`` (or the next ``set_frame``)."""
+        t = _to_device(frame)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=t.device)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self._stream):
+            self._stream.wait_event(ready)
+            out, sizes = ops.jpeg_encode(t, self.quality)
+            done = torch.cuda.Event()
+            done.record()
+        t.record_stream(self._stream)
+        self._pending = (t, out, sizes, done)
+
+    def busy_event(self) -> Optional[torch.cuda.Event]:
+        """Event that fires when the queued encode has finished reading its frame (wait on it before overwriting it)."""
+        return self._pending[3] if self._pending else None
+
+    def wait(self) -> Optional[bytes]:
+        """Finish the queued encode and publish it as ``encoded_frame`` (what ``_generate`` serves, streamer.py:259-283)."""
+        if self._pending is None:
+            return self.encoded_frame
+        t, out, sizes, done = self._pending
+        self._pending = None
+        done.synchronize()
+        n = int(sizes[0])
+        if n < 0:                                                       # incompressible frame: hard bound, synchronously
+            self.encoded_frame = encode_jpeg(t, self.quality)
+        else:
+            self.encoded_frame = out[0, :n].cpu().numpy().tobytes()
         return self.encoded_frame

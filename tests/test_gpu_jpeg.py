@@ -101,3 +101,17 @@ def test_pipeline_to_jpeg_device_resident(tmp_path):
     a = sink.encode_jpeg_batch(sbs_u8, 90)
     b = sink.encode_jpeg_batch(sbs_f32, 90)
     assert a == b and a[0][:2] == b"\xff\xd8" and a[0][-2:] == b"\xff\xd9"
+
+
+def test_async_encoder_overlaps_and_matches():
+    """MJPEGEncoder.set_frame queues the encode on the encoder's stream (the reference's encoder thread); same bytes."""
+    from desktop2stereo_amd import sink
+    from oracle import jpeg_oracle as J
+    rng = np.random.default_rng(9)
+    enc = sink.MJPEGEncoder(quality=80)
+    frames = [torch.from_numpy(rng.integers(0, 256, (72, 104, 3), dtype=np.uint8)).cuda() for _ in range(3)]
+    for f in frames:
+        enc.set_frame(f)
+        got = enc.wait()
+        assert got == J.encode_jpeg(f.cpu().numpy(), 80)
+    assert enc.wait() == got and enc.busy_event() is None
