@@ -115,3 +115,17 @@ def test_async_encoder_overlaps_and_matches():
         got = enc.wait()
         assert got == J.encode_jpeg(f.cpu().numpy(), 80)
     assert enc.wait() == got and enc.busy_event() is None
+
+
+def test_4k_full_tab_frame():
+    """BASELINE config 3's output, 3840 x 4320 (Full-TAB of a 4K source): 64 800 MCUs, offsets past 2^24 bits."""
+    PIL = pytest.importorskip("PIL.Image")
+    from desktop2stereo_amd import sink
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:4320, 0:3840]
+    rgb = np.stack([(xx // 9) % 256, (yy // 11) % 256, ((3 * xx + yy) // 17) % 256], -1).astype(np.int64)
+    rgb = np.clip(rgb + rng.integers(-10, 11, rgb.shape), 0, 255).astype(np.uint8)
+    got = sink.encode_jpeg(rgb, 90)
+    buf = io.BytesIO()
+    PIL.fromarray(rgb).save(buf, "JPEG", quality=90, subsampling="4:2:0", optimize=False)
+    assert got == buf.getvalue(), f"{len(got)} vs {len(buf.getvalue())} bytes"
