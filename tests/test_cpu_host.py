@@ -51,6 +51,19 @@ def test_sbs_shape_matches_reference_padding(lib):
                 assert sbs_shape(H, W, sbs_params(display_mode=mode, fill_16_9=fill)) == want, (H, W, mode, fill)
 
 
+def test_jpeg_bound_host_logic(lib):
+    """d2s_jpeg_bound is pure host arithmetic: 16x16 MCUs, 6 blocks each, <= 216 bytes per block before stuffing."""
+    from desktop2stereo_amd.ops import jpeg_bound
+    for (H, W) in [(1080, 3840), (1, 1), (17, 33), (4320, 3840)]:
+        out_b, ws_b = jpeg_bound(H, W)
+        nmcu = -(-H // 16) * -(-W // 16)
+        assert out_b >= 623 + 2 + 2 * nmcu * 6 * 216                     # header + EOI + every stream byte stuffed
+        assert ws_b >= nmcu * 6 * 64 * 2 + nmcu * 6 * 216 and ws_b % 256 == 0
+    ob, wb = C.c_int64(), C.c_int64()
+    assert lib.d2s_jpeg_bound(0, 10, C.byref(ob), C.byref(wb)) != 0 and lib.d2s_last_error()
+    assert lib.d2s_jpeg_bound(70000, 10, C.byref(ob), C.byref(wb)) != 0                  # JPEG dimensions are 16-bit
+
+
 def test_errors_are_loud(lib):
     sp = _lib.SbsParams(0.064, 2.0, 0.0, 7, 0)
     oh, ow = C.c_int(), C.c_int()
