@@ -49,23 +49,51 @@ __device__ __forceinline__ float lerp2(float a, float b, float c, float d, float
     float top = a + (b - a) * fx, bot = c + (d - c) * fx;
     return top + (bot - top) * fy;
 }
+// The two texels of a row are adjacent except across the GL_REPEAT seam: one 8-byte load per row (gfx950 runs with
+// unaligned access enabled: a dwordx2 at a 4-byte / a byte address is one instruction) instead of two 4-byte / six
+// 1-byte loads -- the kernel is bound by the number of gather instructions, not by bytes.
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ float tex_depth(const float* __restrict__ dep, int H, int W, float u, float v) {
     TexTap t = tex_tap(u, v, H, W);
-    const float* r0 = dep + (long)t.y0 * W;
-    const float* r1 = dep + (long)t.y1 * W;
+    const float* r0 = dep + t.y0 * W;                // (H * W < 2^31 / 3 is checked by the launcher: 32-bit texel indices)
+    const float* r1 = dep + t.y1 * W;
+    if (t.x1 == t.x0 + 1) {
+        f32x2u a = *(const f32x2u*)(r0 + t.x0), b = *(const f32x2u*)(r1 + t.x0);
+        return lerp2(a.x, a.y, b.x, b.y, t.fx, t.fy);
+    }
     return lerp2(r0[t.x0], r0[t.x1], r1[t.x0], r1[t.x1], t.fx, t.fy);
 }
 __device__ __forceinline__ void tex_color(const uint8_t* __restrict__ rgb, int H, int W, float u, float v, float o[3]) {
     TexTap t = tex_tap(u, v, H, W);
-    const uint8_t* a = rgb + ((long)t.y0 * W + t.x0) * 3;
-    const uint8_t* b = rgb + ((long)t.y0 * W + t.x1) * 3;
-    const uint8_t* c = rgb + ((long)t.y1 * W + t.x0) * 3;
-    const uint8_t* d = rgb + ((long)t.y1 * W + t.x1) * 3;
+    const int ia = (t.y0 * W + t.x0) * 3, ic = (t.y1 * W + t.x0) * 3, end = H * W * 3;
+    if (t.x1 == t.x0 + 1 && ia + 8 <= end && ic + 8 <= end) {          // (the 8-byte window must stay inside the frame)
+        uint2 p, q;
+        __builtin_memcpy(&p, rgb + ia, 8);
+        __builtin_memcpy(&q, rgb + ic, 8);
+        const float a[3] = {(float)(p.x & 255u), (float)((p.x >> 8) & 255u), (float)((p.x >> 16) & 255u)};
+        const float b[3] = {(float)(p.x >> 24), (float)(p.y & 255u), (float)((p.y >> 8) & 255u)};
+        const float c[3] = {(float)(q.x & 255u), (float)((q.x >> 8) & 255u), (float)((q.x >> 16) & 255u)};
+        const float d[3] = {(float)(q.x >> 24), (float)(q.y & 255u), (float)((q.y >> 8) & 255u)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] = lerp2(a[k], b[k], c[k], d[k], t.fx, t.fy);
+        return;
+    }
+    const uint8_t* a = rgb + ia;
+    const uint8_t* b = rgb + (t.y0 * W + t.x1) * 3;
+    const uint8_t* c = rgb + ic;
+    const uint8_t* d = rgb + (t.y1 * W + t.x1) * 3;
 #pragma unroll
     for (int k = 0; k < 3; ++k) o[k] = lerp2((float)a[k], (float)b[k], (float)c[k], (float)d[k], t.fx, t.fy);
 }
 __device__ __forceinline__ float smoothstepf(float e0, float e1, float x) {
     float t = fminf(fmaxf((x - e0) / (e1 - e0), 0.f), 1.f);
+    return t * t * (3.f - 2.f * t);
+}
+// constant edges: 1 / (e1 - e0) is a literal (an IEEE division is ~20 instructions here and the kernel is VALU-bound:
+// profiles/r1_09: 610 VALU instructions per pixel before, 7 of these per pixel)
+#define SMOOTHSTEP_C(E0, E1, X) smoothstep_inv((E0), (float)(1.0 / ((double)(E1) - (double)(E0))), (X))
+__device__ __forceinline__ float smoothstep_inv(float e0, float inv, float x) {
+    float t = fminf(fmaxf((x - e0) * inv, 0.f), 1.f);
     return t * t * (3.f - 2.f * t);
 }
 __device__ __forceinline__ bool oob(float u, float v) { return u < 0.f || v < 0.f || u > 1.f || v > 1.f; }
@@ -137,7 +165,8 @@ __device__ __forceinline__ void dibr_pixel(const uint8_t* __restrict__ rgb, cons
     float dinv = -d;
     float shaped = dinv * (1.0f + 0.35f * (1.0f - d));                                // :554
     float shift = shaped + g.conv;
-    float fall = smoothstepf(0.f, 0.05f, u) * smoothstepf(1.f, 0.95f, u);             // :560-562
+    float fall = 1.f;                                                                 // :560-562 (exactly 1 away from the edges)
+    if (u < 0.05f || u > 0.95f) fall = SMOOTHSTEP_C(0.f, 0.05f, u) * SMOOTHSTEP_C(1.f, 0.95f, u);
     float px = eye_offset * shift * g.strength * fall;                                // :563
     float su = u - px * g.c, sv = v - px * g.s;                                       // :564
     float conf;                                                                        // :419-435
@@ -145,7 +174,7 @@ __device__ __forceinline__ void dibr_pixel(const uint8_t* __restrict__ rgb, cons
     else {
         const float s2x = parx * g.psx * 2.0f, s2y = pary * g.psy * 2.0f;
         float jump = fabsf(tex_depth(dep, g.H, g.W, u - s2x, v - s2y) - tex_depth(dep, g.H, g.W, u + s2x, v + s2y));
-        conf = smoothstepf(0.04f, 0.10f, jump);
+        conf = SMOOTHSTEP_C(0.04f, 0.10f, jump);
     }
     float col[3];
     tex_color(rgb, g.H, g.W, su, sv, col);                                            // :570
@@ -155,9 +184,12 @@ __device__ __forceinline__ void dibr_pixel(const uint8_t* __restrict__ rgb, cons
 #pragma unroll
         for (int k = 0; k < 3; ++k) col[k] = col[k] * (1.0f - conf) + fill[k] * conf; // mix (:575)
     }
-    float bx = smoothstepf(-0.001f, 0.001f, su) * smoothstepf(1.001f, 0.999f, su);    // :582
-    float by = smoothstepf(-0.001f, 0.001f, sv) * smoothstepf(1.001f, 0.999f, sv);
-    float alpha = fminf(bx, by);
+    float alpha = 1.f;                                                                // :582 (exactly 1 inside the frame)
+    if (su < 0.001f || su > 0.999f || sv < 0.001f || sv > 0.999f) {
+        float bx = SMOOTHSTEP_C(-0.001f, 0.001f, su) * SMOOTHSTEP_C(1.001f, 0.999f, su);
+        float by = SMOOTHSTEP_C(-0.001f, 0.001f, sv) * SMOOTHSTEP_C(1.001f, 0.999f, sv);
+        alpha = fminf(bx, by);
+    }
     if (g.feather) {                                                                   // :587-616
         float fu = u, fv = 1.0f - v, fw = g.feather_w;
         float fo = smoothstepf(0.f, fw, fu) * smoothstepf(0.f, fw, 1.0f - fu) * smoothstepf(0.f, fw, fv) * smoothstepf(0.f, fw, 1.0f - fv);
@@ -208,6 +240,7 @@ extern "C" int d2s_dibr_warp(const uint8_t* rgb, const float* depth, int batch, 
                              void* out, int out_fmt, void* stream) {
     D2S_REQUIRE(rgb && depth && p && out, "null pointer");
     D2S_REQUIRE(batch > 0 && H > 1 && W > 1, "bad shape");
+    D2S_REQUIRE((long)H * W * 3 + 8 < (1L << 31), "frame too large (32-bit texel indices)");
     D2S_REQUIRE(out_fmt == D2S_FMT_U8_HWC || out_fmt == D2S_FMT_F32_HWC, "bad out_fmt (U8_HWC or F32_HWC)");
     D2S_REQUIRE(p->search_radius >= 0.f && p->search_radius < 16.f, "search_radius must be in [0,16)");
     DibrGeom g;
