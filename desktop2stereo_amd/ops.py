@@ -209,11 +209,14 @@ def jpeg_bound(H: int, W: int) -> Tuple[int, int]:
     return ob.value, wb.value
 
 
-def jpeg_encode(frames: torch.Tensor, quality: int = 90, out_stride: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+def jpeg_encode(frames: torch.Tensor, quality: int = 90, out_stride: Optional[int] = None,
+                workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """f3, the MJPEG sink (reference streamer.py:249-256, 285-291 — cv2.imencode('.jpg', ...)): RGB frames
     [B,H,W,3] or [H,W,3], uint8 or float32 0..255 (rounded half-even + saturated like cv2's convertTo), on the
     device -> (bytes [B, out_stride] uint8, sizes [B] int32), both on the device, no host sync.  The first
-    sizes[b] bytes of row b are the JPEG libjpeg-turbo would write for that frame at that quality (4:2:0)."""
+    sizes[b] bytes of row b are the JPEG libjpeg-turbo would write for that frame at that quality (4:2:0).
+    workspace: uint8 device scratch of >= B * jpeg_bound(H, W)[1] + 256 bytes owned by the caller (one per stream that
+    encodes concurrently); default: a module-level buffer, good for one stream at a time."""
     _need_cuda(frames, "frames")
     if frames.shape[-1] != 3 or frames.dim() not in (3, 4) or frames.dtype not in (torch.uint8, torch.float32):
         raise ValueError("jpeg_encode: frames must be uint8/float32 [B,H,W,3] or [H,W,3]")
@@ -222,11 +225,16 @@ def jpeg_encode(frames: torch.Tensor, quality: int = 90, out_stride: Optional[in
     safe, ws_frame = jpeg_bound(H, W)
     # default stride: the unstuffed worst case + 1/16 for 0xFF stuffing; sizes[b] = -1 reports an overflow
     stride = int(out_stride) if out_stride else (safe // 2 + safe // 32 + 1024)
-    key = (f.device.index or 0, ws_frame * B)
-    ws = _JPEG_WS.get(key)
-    if ws is None:
-        _JPEG_WS.clear()
-        ws = _JPEG_WS[key] = torch.empty(ws_frame * B + 256, dtype=torch.uint8, device=f.device)
+    if workspace is not None:
+        if workspace.dtype != torch.uint8 or not workspace.is_cuda or workspace.numel() < ws_frame * B + 256:
+            raise ValueError(f"jpeg_encode: workspace must be a uint8 device tensor of >= {ws_frame * B + 256} bytes")
+        ws = workspace
+    else:
+        key = (f.device.index or 0, ws_frame * B)
+        ws = _JPEG_WS.get(key)
+        if ws is None:
+            _JPEG_WS.clear()
+            ws = _JPEG_WS[key] = torch.empty(ws_frame * B + 256, dtype=torch.uint8, device=f.device)
     pad = (-ws.data_ptr()) % 256
     out = torch.empty((B, stride), dtype=torch.uint8, device=f.device)
     sizes = torch.empty((B,), dtype=torch.int32, device=f.device)

@@ -58,6 +58,7 @@ class MJPEGEncoder:
         self.quality = int(quality)
         self.encoded_frame: Optional[bytes] = None
         self._stream: Optional[torch.cuda.Stream] = None
+        self._ws: Optional[torch.Tensor] = None        # this encoder's own scratch: it runs beside other streams' encodes
         self._pending = None
 
     def set_frame(self, frame) -> None:
@@ -68,9 +69,12 @@ class MJPEGEncoder:
             self._stream = torch.cuda.Stream(device=t.device)
         ready = torch.cuda.Event()
         ready.record()
+        need = ops.jpeg_bound(t.shape[-3], t.shape[-2])[1] * (t.shape[0] if t.dim() == 4 else 1) + 256
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=t.device)
         with torch.cuda.stream(self._stream):
             self._stream.wait_event(ready)
-            out, sizes = ops.jpeg_encode(t, self.quality)
+            out, sizes = ops.jpeg_encode(t, self.quality, workspace=self._ws)
             done = torch.cuda.Event()
             done.record()
         t.record_stream(self._stream)
