@@ -559,7 +559,7 @@ extern "C" int d2s_jpeg_bound(int H, int W, int64_t* out_bytes, int64_t* workspa
 extern "C" int d2s_jpeg_encode(const void* frames, int fmt, int batch, int H, int W, int quality, uint8_t* out,
                                int64_t out_stride, int32_t* sizes, void* workspace, int64_t workspace_bytes, void* stream) {
     D2S_REQUIRE(frames && out && sizes && workspace, "d2s_jpeg_encode: null pointer");
-    D2S_REQUIRE(batch > 0 && H > 0 && W > 0 && H < 65536 && W < 65536, "d2s_jpeg_encode: bad shape");
+    D2S_REQUIRE(batch > 0 && batch <= 65535 && H > 0 && W > 0 && H < 65536 && W < 65536, "d2s_jpeg_encode: bad shape");
     D2S_REQUIRE(fmt == D2S_FMT_U8_HWC || fmt == D2S_FMT_F32_HWC, "d2s_jpeg_encode: frames must be U8_HWC or F32_HWC");
     D2S_REQUIRE(quality >= 1 && quality <= 100, "d2s_jpeg_encode: quality must be 1..100");
     D2S_REQUIRE(out_stride >= HDR_LEN + 2, "d2s_jpeg_encode: out_stride too small");
