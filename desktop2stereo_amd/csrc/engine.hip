@@ -34,7 +34,14 @@ struct Layer {
     PackedW qkv_ln, fc1_ln;
     float *csum_qkv = nullptr, *csum_fc1 = nullptr;
     float* deq[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the same folding on the e4m3 path: [0] QKV, [1] FC1.  A operand = e4m3 of the RAW residual (static scale from the
+    // calibration pass, sites 4 / 5), W' quantised per output channel, csum8 over the de-quantised W'
+    PackedW w8_ln[2];
+    std::vector<float> sw_ln[2];
+    float *csum8[2] = {nullptr, nullptr}, *deq_ln[2] = {nullptr, nullptr};
 };
+
+constexpr int NSITE = 6;   // calibration sites per layer: LN1 out, attention out, LN2 out, GELU out, residual after proj, residual after FC2
 
 }  // namespace
 
@@ -423,22 +430,23 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     // measured (ViT-B @294x518): folding wins 7 % at 1 frame, 3-5 % at 2-4, 2 % at 8, is even at 16 and loses 1 % at 32
     // (the LN kernels' launch floor is amortised there and the wider epilogues are not) -> folded up to 16 frames
     static const int lnf_maxb = getenv("D2S_LNF_MAXB") ? atoi(getenv("D2S_LNF_MAXB")) : 16;      // tuning aid
-    const bool lnf = e->lnf && !e->fp8 && !e->calib && prec == D2S_PREC_BF16 && B <= lnf_maxb;
+    static const bool no_lnf = getenv("D2S_NO_LNFUSE") && atoi(getenv("D2S_NO_LNFUSE")) != 0;
+    const bool lnf = ((e->lnf && !e->fp8) || (f8 && !no_lnf)) && !e->calib && prec == D2S_PREC_BF16 && B <= lnf_maxb;
     int ln_slots = 0;
     for (int l = 0; l < d.layers; ++l) {
         const Layer& ly = e->L[l];
-        const float* sa = f8 ? &e->act_scale[(size_t)l * 4] : nullptr;     // s_act of LN1 out, attention out, LN2 out, GELU out
-        float* am = e->calib ? e->amax + (size_t)l * 4 : nullptr;
+        const float* sa = f8 ? &e->act_scale[(size_t)l * NSITE] : nullptr; // s_act of LN1 out, attention out, LN2 out, GELU out, residual x 2
+        float* am = e->calib ? e->amax + (size_t)l * NSITE : nullptr;
         // lnf: the previous layer's FC2 epilogue left the raw bf16 residual in lnbuf and the row statistics in lnstats;
         // LN1 then happens inside the QKV linear (layer 0 has no such producer and runs the LN kernel)
         const bool ln1_folded = lnf && l > 0 && ln_slots <= 16;
         if (!ln1_folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln1g, ly.ln1b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[0] : 0.f));
         if (am) RC(launch_amax(prec, e->lnbuf, (long)M * D, am + 0, st));
         {
-            GemmEpi ep = rowsE(e->qkv, f8 ? OUT_BF16 : OUT_T, 3 * D, ln1_folded ? ly.qkv_ln.bias : ly.qkv.bias);
+            GemmEpi ep = rowsE(e->qkv, f8 ? OUT_BF16 : OUT_T, 3 * D, ln1_folded ? (f8 ? ly.w8_ln[0].bias : ly.qkv_ln.bias) : ly.qkv.bias);
             ep.map = MAP_QKV; ep.vt = e->vt; ep.ntok = N; ep.npad = e->Npad; ep.qk_cols = 2 * D; ep.heads = d.heads;
-            if (ln1_folded) { ep.ln_stats = e->lnstats; ep.ln_slots = ln_slots; ep.ln_csum = ly.csum_qkv; ep.ln_eps = d.ln_eps; ep.ln_dim = D; }
-            if (f8) { ep.deq = ly.deq[0]; RC(gemm8(e, plainA(e->lnbuf, D), ly.w8[0], M, ep, st)); }
+            if (ln1_folded) { ep.ln_stats = e->lnstats; ep.ln_slots = ln_slots; ep.ln_csum = f8 ? ly.csum8[0] : ly.csum_qkv; ep.ln_eps = d.ln_eps; ep.ln_dim = D; }
+            if (f8) { ep.deq = ln1_folded ? ly.deq_ln[0] : ly.deq[0]; RC(gemm8(e, plainA(e->lnbuf, D), ln1_folded ? ly.w8_ln[0] : ly.w8[0], M, ep, st)); }
             else RC(gemm(e, plainA(e->lnbuf, D), ln1_folded ? ly.qkv_ln : ly.qkv, M, ep, st));
         }
         PROF(PC_ATTN, 4.0 * B * d.heads * (double)N * N * 64, 0,
@@ -447,28 +455,30 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         {
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.proj.bias);
             ep.scale = ly.ls1; ep.res1 = e->resid;
-            if (lnf) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; }
+            if (lnf) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[4] : 0.f; }
             if (f8) { ep.deq = ly.deq[1]; RC(gemm8(e, plainA(e->attn, D), ly.w8[1], M, ep, st)); }
             else RC(gemm(e, plainA(e->attn, D), ly.proj, M, ep, st));
         }
         const bool ln2_folded = lnf && ln_slots <= 16;              // (more than 16 column blocks: the LN kernel runs instead)
         if (!ln2_folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln2g, ly.ln2b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[2] : 0.f));
+        if (am) RC(launch_amax(D2S_PREC_FP32, e->resid, (long)M * D, am + 4, st));       // (raw residual: the LN-folded FC1's A operand)
         if (am) RC(launch_amax(prec, e->lnbuf, (long)M * D, am + 2, st));
         {
-            GemmEpi ep = rowsE(e->mlp, OUT_T, d.mlp, ln2_folded ? ly.fc1_ln.bias : ly.fc1.bias);
+            GemmEpi ep = rowsE(e->mlp, OUT_T, d.mlp, ln2_folded ? (f8 ? ly.w8_ln[1].bias : ly.fc1_ln.bias) : ly.fc1.bias);
             ep.act = ACT_GELU;
-            if (ln2_folded) { ep.ln_stats = e->lnstats; ep.ln_slots = ln_slots; ep.ln_csum = ly.csum_fc1; ep.ln_eps = d.ln_eps; ep.ln_dim = D; }
-            if (f8) { ep.deq = ly.deq[2]; ep.out_qscale = 1.0f / sa[3]; RC(gemm8(e, plainA(e->lnbuf, D), ly.w8[2], M, ep, st)); }
+            if (ln2_folded) { ep.ln_stats = e->lnstats; ep.ln_slots = ln_slots; ep.ln_csum = f8 ? ly.csum8[1] : ly.csum_fc1; ep.ln_eps = d.ln_eps; ep.ln_dim = D; }
+            if (f8) { ep.deq = ln2_folded ? ly.deq_ln[1] : ly.deq[2]; ep.out_qscale = 1.0f / sa[3]; RC(gemm8(e, plainA(e->lnbuf, D), ln2_folded ? ly.w8_ln[1] : ly.w8[2], M, ep, st)); }
             else RC(gemm(e, plainA(e->lnbuf, D), ln2_folded ? ly.fc1_ln : ly.fc1, M, ep, st));
         }
         if (am) RC(launch_amax(prec, e->mlp, (long)M * d.mlp, am + 3, st));
         {
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.fc2.bias);
             ep.scale = ly.ls2; ep.res1 = e->resid;
-            if (lnf && l + 1 < d.layers) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; }
+            if (lnf && l + 1 < d.layers) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[5] : 0.f; }
             if (f8) { ep.deq = ly.deq[3]; RC(gemm8(e, plainA(e->mlp, d.mlp), ly.w8[3], M, ep, st)); }
             else RC(gemm(e, plainA(e->mlp, d.mlp), ly.fc2, M, ep, st));
         }
+        if (am) RC(launch_amax(D2S_PREC_FP32, e->resid, (long)M * D, am + 5, st));       // (raw residual: the next layer's LN-folded QKV)
         if (e->taps) D2S_HIP(hipMemcpyAsync(e->tap_hidden + (size_t)(l + 1) * N * D, e->resid, (size_t)N * D * 4, hipMemcpyDeviceToDevice, st));
         if (tap_i < 4 && l + 1 == d.out_indices[tap_i]) {     // HF Dinov2Backbone: shared final LN, drop cls
             PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, e->lnfg, e->lnfb, e->tapbuf[tap_i], Mp, D, d.ln_eps, P, N, 1, st));
@@ -657,11 +667,33 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
             RC(pack_matrix_fp8(e, d.mlp, D, [&](int n, int k) { return w1[(size_t)n * D + k]; }, ly.fc1.bias, ly.w8[2], ly.sw[2]));
             RC(pack_matrix_fp8(e, D, d.mlp, [&](int n, int k) { return w2[(size_t)n * d.mlp + k]; }, ly.fc2.bias, ly.w8[3], ly.sw[3]));
             for (int i = 0; i < 4; ++i) RC(dev_alloc(e, (void**)&ly.deq[i], (size_t)ly.w8[i].N * sizeof(float), true));
+            // LN-folded e4m3 copies of QKV / FC1 (see Layer): W' = W diag(gamma), bias' = b + W beta, csum over the de-quantised W'
+            auto fold8 = [&](const HostT* g, const HostT* bt, int Nn, auto at, const float* bias, int slot) -> int {
+                RC(pack_matrix_fp8(e, Nn, D, [&](int n, int k) { return g->data[k] * at(n, k); }, nullptr, ly.w8_ln[slot], ly.sw_ln[slot]));
+                std::vector<float> b2(Nn), cs(Nn);
+                for (int n = 0; n < Nn; ++n) {
+                    double sb = bias[n], sc = 0.0;
+                    const float sw = ly.sw_ln[slot][n];
+                    for (int k = 0; k < D; ++k) { sb += (double)bt->data[k] * at(n, k); sc += e4m32f(f2e4m3(g->data[k] * at(n, k) / sw)); }
+                    b2[n] = (float)sb; cs[n] = (float)(sc * sw);
+                }
+                RC(dev_alloc(e, (void**)&ly.w8_ln[slot].bias, (size_t)Nn * sizeof(float)));
+                D2S_HIP(hipMemcpy(ly.w8_ln[slot].bias, b2.data(), (size_t)Nn * sizeof(float), hipMemcpyHostToDevice));
+                RC(dev_alloc(e, (void**)&ly.csum8[slot], (size_t)Nn * sizeof(float)));
+                D2S_HIP(hipMemcpy(ly.csum8[slot], cs.data(), (size_t)Nn * sizeof(float), hipMemcpyHostToDevice));
+                RC(dev_alloc(e, (void**)&ly.deq_ln[slot], (size_t)Nn * sizeof(float), true));
+                return D2S_OK;
+            };
+            const HostT *g1 = find(e, p + "norm1.weight"), *bn1 = find(e, p + "norm1.bias"), *g2 = find(e, p + "norm2.weight"), *bn2 = find(e, p + "norm2.bias");
+            const HostT* b1t = find(e, p + "mlp.fc1.bias");
+            if (!g1 || !bn1 || !g2 || !bn2 || !b1t) return D2S_E_MISSING;
+            RC(fold8(g1, bn1, 3 * D, [&](int n, int k) { return ws[n / D][(size_t)(n % D) * D + k]; }, bias.data(), 0));
+            RC(fold8(g2, bn2, d.mlp, [&](int n, int k) { return w1[(size_t)n * D + k]; }, b1t->data.data(), 1));
         }
     }
     if (e->fp8) {
-        RC(dev_alloc(e, (void**)&e->amax, (size_t)d.layers * 4 * sizeof(float), true));
-        e->act_scale.assign((size_t)d.layers * 4, 0.f);
+        RC(dev_alloc(e, (void**)&e->amax, (size_t)d.layers * NSITE * sizeof(float), true));
+        e->act_scale.assign((size_t)d.layers * NSITE, 0.f);
     }
     RC(upload_f32(e, "backbone.layernorm.weight", D, &e->lnfg));
     RC(upload_f32(e, "backbone.layernorm.bias", D, &e->lnfb));
@@ -690,7 +722,7 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
     const size_t M = (size_t)B * N, Mp = (size_t)B * P;
     RC(dev_alloc(e, (void**)&e->resid, M * D * 4));
     RC(dev_alloc(e, &e->lnbuf, M * D * es));
-    if (e->lnf) RC(dev_alloc(e, (void**)&e->lnstats, (size_t)(D / 16 + 1) * M * 2 * sizeof(float)));
+    if (e->lnf || e->fp8) RC(dev_alloc(e, (void**)&e->lnstats, (size_t)(D / 16 + 1) * M * 2 * sizeof(float)));
     RC(dev_alloc(e, &e->qkv, M * 3 * D * es));
     RC(dev_alloc(e, &e->vt, (size_t)B * D * e->Npad * es, true));     // zero beyond N, never written there
     RC(dev_alloc(e, &e->attn, M * D * es));
@@ -821,7 +853,7 @@ extern "C" int d2s_engine_calibrate(d2s_engine* e, const float* x, int batch, vo
     hipStream_t st = (hipStream_t)stream;
     const int L = e->d.layers;
     // one bf16 forward over the calibration frames, recording max |activation| at the four quantisation sites per layer
-    D2S_HIP(hipMemsetAsync(e->amax, 0, (size_t)L * 4 * sizeof(float), st));
+    D2S_HIP(hipMemsetAsync(e->amax, 0, (size_t)L * NSITE * sizeof(float), st));
     const bool prof = e->prof_on;
     e->prof_on = false;
     e->calib = true;
@@ -829,20 +861,28 @@ extern "C" int d2s_engine_calibrate(d2s_engine* e, const float* x, int batch, vo
     e->calib = false;
     e->prof_on = prof;
     if (rc != D2S_OK) return rc;
-    std::vector<float> am((size_t)L * 4);
+    std::vector<float> am((size_t)L * NSITE);
     D2S_HIP(hipMemcpyAsync(am.data(), e->amax, am.size() * sizeof(float), hipMemcpyDeviceToHost, st));
     D2S_HIP(hipStreamSynchronize(st));
     for (int l = 0; l < L; ++l) {
         Layer& ly = e->L[l];
-        for (int s = 0; s < 4; ++s) {
-            float a = am[(size_t)l * 4 + s];
+        for (int s = 0; s < NSITE; ++s) {
+            float a = am[(size_t)l * NSITE + s];
             if (!(a > 0.f) || !std::isfinite(a)) { set_error("d2s_engine_calibrate: degenerate activation range"); return D2S_E_INVALID; }
-            e->act_scale[(size_t)l * 4 + s] = a / FP8_MAX;
+            e->act_scale[(size_t)l * NSITE + s] = a / FP8_MAX;
         }
         for (int i = 0; i < 4; ++i) {                         // linear i reads site i (qkv <- LN1, proj <- attention, fc1 <- LN2, fc2 <- GELU)
             std::vector<float> dq(ly.sw[i].size());
-            for (size_t n = 0; n < dq.size(); ++n) dq[n] = e->act_scale[(size_t)l * 4 + i] * ly.sw[i][n];
+            for (size_t n = 0; n < dq.size(); ++n) dq[n] = e->act_scale[(size_t)l * NSITE + i] * ly.sw[i][n];
             D2S_HIP(hipMemcpy(ly.deq[i], dq.data(), dq.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        // LN-folded linears read the raw residual: FC1 <- site 4 of this layer, QKV <- site 5 of the previous layer
+        for (int i = 0; i < 2; ++i) {
+            if (i == 0 && l == 0) continue;
+            const float sraw = i == 0 ? e->act_scale[(size_t)(l - 1) * NSITE + 5] : e->act_scale[(size_t)l * NSITE + 4];
+            std::vector<float> dq(ly.sw_ln[i].size());
+            for (size_t n = 0; n < dq.size(); ++n) dq[n] = sraw * ly.sw_ln[i][n];
+            D2S_HIP(hipMemcpy(ly.deq_ln[i], dq.data(), dq.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
     e->fp8_ready = true;

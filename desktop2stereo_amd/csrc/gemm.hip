@@ -100,9 +100,10 @@ template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v;
 template <> __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float v) { return f2bf(v); }
 template <> __device__ __forceinline__ fp8_t cvt_out<fp8_t>(float v) { return (fp8_t)(pk_fp8x4(v, 0.f, 0.f, 0.f) & 255u); }
 
+// skip_deq: the caller (LN-folded consumer on e4m3 operands) already turned the accumulators into real units
 template <typename OT>
-__device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float v[4]) {
-    if (e.deq) { float q[4]; load4(e.deq + n0, q); v[0] *= q[0]; v[1] *= q[1]; v[2] *= q[2]; v[3] *= q[3]; }   // fp8 operands -> real units
+__device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float v[4], bool skip_deq = false) {
+    if (e.deq && !skip_deq) { float q[4]; load4(e.deq + n0, q); v[0] *= q[0]; v[1] *= q[1]; v[2] *= q[2]; v[3] *= q[3]; }   // fp8 operands -> real units
     if (e.bias) { float b[4]; load4(e.bias + n0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
     if (e.act == ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
     else if (e.act == ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -132,15 +133,22 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float
     if (e.res2) { float r[4]; load4((const OT*)e.res2 + off, r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
     if constexpr (std::is_same<OT, fp8_t>::value) { v[0] *= e.out_qscale; v[1] *= e.out_qscale; v[2] *= e.out_qscale; v[3] *= e.out_qscale; }
     store4((OT*)e.out + off, v);
-    if constexpr (std::is_same<OT, float>::value) { if (e.out2) store4((bf16_t*)e.out2 + off, v); }   // raw bf16 residual for the LN-folded consumer
+    if constexpr (std::is_same<OT, float>::value) {            // raw residual copy for the LN-folded consumer: bf16, or e4m3 * scale
+        if (e.out2) {
+            if (e.out2_qscale > 0.f) {
+                float q[4] = {v[0] * e.out2_qscale, v[1] * e.out2_qscale, v[2] * e.out2_qscale, v[3] * e.out2_qscale};
+                store4((fp8_t*)e.out2 + off, q);
+            } else store4((bf16_t*)e.out2 + off, v);
+        }
+    }
 }
 
 // out_type -> element type of the output / residuals
 template <typename T>
-__device__ __forceinline__ void epilogue_dispatch(const GemmEpi& e, int m, int n0, float v[4]) {
-    if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v);
-    else if (e.out_type == OUT_BF16) epilogue4<bf16_t>(e, m, n0, v);
-    else epilogue4<T>(e, m, n0, v);
+__device__ __forceinline__ void epilogue_dispatch(const GemmEpi& e, int m, int n0, float v[4], bool skip_deq = false) {
+    if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v, skip_deq);
+    else if (e.out_type == OUT_BF16) epilogue4<bf16_t>(e, m, n0, v, skip_deq);
+    else epilogue4<T>(e, m, n0, v, skip_deq);
 }
 
 // XCD-aware block -> tile map.  Workgroup b is dispatched to XCD b % 8 (observed, used for speed
@@ -446,11 +454,13 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     if (ksplit > 1) store4(e.part + ((long)blockIdx.y * M + m) * N + n0, v);     // reduced by splitk_reduce_kernel
                     else {
-                        if (LN_ON && e.ln_csum) {
+                        const bool ln = LN_ON && e.ln_csum != nullptr;
+                        if (ln) {
+                            if (e.deq) { float q[4]; load4(e.deq + n0, q); v[0] *= q[0]; v[1] *= q[1]; v[2] *= q[2]; v[3] *= q[3]; }   // e4m3 operands -> real units first
                             v[0] = ln_rstd * (v[0] - ln_mean * ln_cs[j][0]); v[1] = ln_rstd * (v[1] - ln_mean * ln_cs[j][1]);
                             v[2] = ln_rstd * (v[2] - ln_mean * ln_cs[j][2]); v[3] = ln_rstd * (v[3] - ln_mean * ln_cs[j][3]);
                         }
-                        epilogue_dispatch<T>(e, m, n0, v);
+                        epilogue_dispatch<T>(e, m, n0, v, ln);
                         s1 += (v[0] + v[1]) + (v[2] + v[3]);
                         s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                     }
