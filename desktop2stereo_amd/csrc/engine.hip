@@ -60,7 +60,7 @@ struct d2s_engine {
     float *cls = nullptr, *pos = nullptr;          // pos: [N, D] interpolated (row 0 = cls position)
     std::vector<Layer> L;
     float *lnfg = nullptr, *lnfb = nullptr;
-    struct { PackedW proj, resize, conv; } re[4];
+    struct { PackedW proj, resize, conv; PackedW proj_ln; float* csum = nullptr; } re[4];   // proj_ln: final LayerNorm folded in (bf16, batch 1)
     struct { PackedW proj, r1c1, r1c2, r2c1, r2c2; } fu[4];
     PackedW head1, head2;
     float* w3 = nullptr;
@@ -80,7 +80,8 @@ struct d2s_engine {
     // Neck branches of taps 0..2 (+ the RCU1 of their fusion layer) only depend on their tap, not on later encoder
     // layers: they run on a second stream under the remaining layers (batch 1 leaves most CUs idle per launch).
     hipStream_t side = nullptr;
-    hipEvent_t ev_tap[4] = {nullptr, nullptr, nullptr, nullptr}, ev_side = nullptr;
+    hipEvent_t ev_tap[4] = {nullptr, nullptr, nullptr, nullptr}, ev_ln[4] = {nullptr, nullptr, nullptr, nullptr}, ev_side = nullptr;
+    int tap_slots = 0;                             // column blocks of the statistics the folded tap projection reads
     bool overlap = true;
     float* splitk_ws_side = nullptr;               // the side stream's own split-K partials
     void* r1[3] = {nullptr, nullptr, nullptr};     // RCU1(feat[i]) = feat[i] + conv2(relu(conv1(relu(feat[i])))), i = 0..2
@@ -377,10 +378,20 @@ int run_temporal(d2s_engine* e, int m, const void* x, void* out, hipStream_t st,
 // Tap i of the neck: reassemble (HF DepthAnythingReassembleStage) + 3x3 to fusion width (neck.convs), then -- for the
 // three shallower taps -- the first residual unit of their fusion layer, RCU1(m) = m + conv2(relu(conv1(relu(m)))),
 // which depends on this map only (HF DepthAnythingFeatureFusionLayer adds it to the deeper stage's output later).
-int neck_branch(d2s_engine* e, int i, int B, hipStream_t st) {
+// reassemble projection of tap i.  fold (bf16, batch 1): the shared final LayerNorm happens inside it -- A = the raw bf16
+// residual the last FC2 left in lnbuf (patch rows: skip the cls row), statistics from lnstats (same row offset)
+int neck_proj(d2s_engine* e, int i, int B, hipStream_t st, bool fold) {
     const d2s_model_desc& d = e->d;
-    const int D = d.hidden, F = d.fusion, gh = e->gh, gw = e->gw, Mp = B * e->P, c = d.neck[i];
-    RC(gemm(e, plainA(e->tapbuf[i], D), e->re[i].proj, Mp, rowsE(e->rproj[i], OUT_T, c, e->re[i].proj.bias), st));
+    const int D = d.hidden, Mp = B * e->P, c = d.neck[i];
+    if (!fold) return gemm(e, plainA(e->tapbuf[i], D), e->re[i].proj, Mp, rowsE(e->rproj[i], OUT_T, c, e->re[i].proj.bias), st);
+    GemmEpi ep = rowsE(e->rproj[i], OUT_T, c, e->re[i].proj_ln.bias);
+    ep.ln_stats = e->lnstats + 2; ep.ln_M = e->N; ep.ln_slots = e->tap_slots; ep.ln_csum = e->re[i].csum; ep.ln_eps = d.ln_eps; ep.ln_dim = D;
+    return gemm(e, plainA((const bf16_t*)e->lnbuf + D, D), e->re[i].proj_ln, Mp, ep, st);
+}
+
+int neck_rest(d2s_engine* e, int i, int B, hipStream_t st) {
+    const d2s_model_desc& d = e->d;
+    const int F = d.fusion, gh = e->gh, gw = e->gw, Mp = B * e->P, c = d.neck[i];
     const void* src = e->rproj[i];
     int Hs = gh, Ws = gw;
     if (i < 2) {
@@ -433,6 +444,12 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     static const bool no_lnf = getenv("D2S_NO_LNFUSE") && atoi(getenv("D2S_NO_LNFUSE")) != 0;
     const bool lnf = ((e->lnf && !e->fp8) || (f8 && !no_lnf)) && !e->calib && prec == D2S_PREC_BF16 && B <= lnf_maxb;
     int ln_slots = 0;
+    // batch 1, bf16: the four tap LayerNorms fold into the reassemble projections the same way (the statistics and the raw
+    // residual of a tap layer are still in lnbuf / lnstats when its projection runs; the main stream waits for that launch
+    // -- ev_ln -- before the next layer's projection GEMM overwrites them)
+    const bool tap_fold = lnf && !f8 && e->lnf && B == 1;
+    bool tap_folded[4] = {false, false, false, false};
+    int pending_ln = -1;
     for (int l = 0; l < d.layers; ++l) {
         const Layer& ly = e->L[l];
         const float* sa = f8 ? &e->act_scale[(size_t)l * NSITE] : nullptr; // s_act of LN1 out, attention out, LN2 out, GELU out, residual x 2
@@ -453,6 +470,7 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
              launch_attention(prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st, f8 ? 1.0f / sa[1] : 0.f));
         if (am) RC(launch_amax(prec, e->attn, (long)M * D, am + 1, st));
         {
+            if (pending_ln >= 0) { D2S_HIP(hipStreamWaitEvent(st, e->ev_ln[pending_ln], 0)); pending_ln = -1; }
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.proj.bias);
             ep.scale = ly.ls1; ep.res1 = e->resid;
             if (lnf) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[4] : 0.f; }
@@ -474,27 +492,34 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         {
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.fc2.bias);
             ep.scale = ly.ls2; ep.res1 = e->resid;
-            if (lnf && l + 1 < d.layers) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[5] : 0.f; }
+            if (lnf && (l + 1 < d.layers || tap_fold)) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[5] : 0.f; }
             if (f8) { ep.deq = ly.deq[3]; RC(gemm8(e, plainA(e->mlp, d.mlp), ly.w8[3], M, ep, st)); }
             else RC(gemm(e, plainA(e->mlp, d.mlp), ly.fc2, M, ep, st));
         }
         if (am) RC(launch_amax(D2S_PREC_FP32, e->resid, (long)M * D, am + 5, st));       // (raw residual: the next layer's LN-folded QKV)
         if (e->taps) D2S_HIP(hipMemcpyAsync(e->tap_hidden + (size_t)(l + 1) * N * D, e->resid, (size_t)N * D * 4, hipMemcpyDeviceToDevice, st));
         if (tap_i < 4 && l + 1 == d.out_indices[tap_i]) {     // HF Dinov2Backbone: shared final LN, drop cls
-            PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, e->lnfg, e->lnfb, e->tapbuf[tap_i], Mp, D, d.ln_eps, P, N, 1, st));
+            const bool fold = tap_fold && ln_slots <= 16;
+            tap_folded[tap_i] = fold;
+            e->tap_slots = ln_slots;
+            if (!fold) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, e->lnfg, e->lnfb, e->tapbuf[tap_i], Mp, D, d.ln_eps, P, N, 1, st));
             // this tap's neck branch runs under the remaining encoder layers.  VDA: the temporal modules of branches 2 and 3
             // share the tm_* workspaces, so branch 3 queues behind branch 2 on the side stream instead of racing it.
             if (use_side && (tap_i < 3 || d.temporal)) {
                 D2S_HIP(hipEventRecord(e->ev_tap[tap_i], st));
                 D2S_HIP(hipStreamWaitEvent(e->side, e->ev_tap[tap_i], 0));
-                RC(neck_branch(e, tap_i, B, e->side));
+                RC(neck_proj(e, tap_i, B, e->side, fold));
+                if (fold) { D2S_HIP(hipEventRecord(e->ev_ln[tap_i], e->side)); pending_ln = tap_i; }
+                RC(neck_rest(e, tap_i, B, e->side));
+            } else {
+                RC(neck_proj(e, tap_i, B, st, fold));           // (its inputs are overwritten by the next layer; the rest can wait)
             }
             ++tap_i;
         }
     }
     // ---- neck branches that did not run on the side stream, then join it
     for (int i = 0; i < 4; ++i)
-        if (!(use_side && (i < 3 || d.temporal))) RC(neck_branch(e, i, B, st));
+        if (!(use_side && (i < 3 || d.temporal))) RC(neck_rest(e, i, B, st));
     if (use_side) {
         D2S_HIP(hipEventRecord(e->ev_side, e->side));
         D2S_HIP(hipStreamWaitEvent(st, e->ev_side, 0));
@@ -706,6 +731,26 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
         if (i == 3) RC(pack_conv3(e, p + "resize.weight", p + "resize.bias", c, c, e->re[i].resize));
         RC(pack_conv3(e, "neck.convs." + std::to_string(i) + ".weight", "", F, c, e->re[i].conv));
     }
+    if (e->lnf) {                                       // final LayerNorm folded into the four reassemble projections (batch 1)
+        const HostT *gf = find(e, "backbone.layernorm.weight"), *bf = find(e, "backbone.layernorm.bias");
+        if (!gf || !bf) return D2S_E_MISSING;
+        for (int i = 0; i < 4; ++i) {
+            std::string p = "neck.reassemble_stage.layers." + std::to_string(i) + ".projection.";
+            const HostT *wt = find(e, p + "weight"), *bt = find(e, p + "bias");
+            if (!wt || !bt) return D2S_E_MISSING;
+            const int c = d.neck[i];
+            const float* wp = wt->data.data();
+            std::vector<float> b2(c), cs(c);
+            for (int n = 0; n < c; ++n) {
+                double sb = bt->data[n], sc = 0.0;
+                for (int k = 0; k < D; ++k) { sb += (double)bf->data[k] * wp[(size_t)n * D + k]; sc += bf2f(f2bf(gf->data[k] * wp[(size_t)n * D + k])); }
+                b2[n] = (float)sb; cs[n] = (float)sc;
+            }
+            RC(pack_matrix(e, c, D, [&](int n, int k) { return gf->data[k] * wp[(size_t)n * D + k]; }, b2.data(), e->re[i].proj_ln));
+            RC(dev_alloc(e, (void**)&e->re[i].csum, (size_t)c * sizeof(float)));
+            D2S_HIP(hipMemcpy(e->re[i].csum, cs.data(), (size_t)c * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
     for (int i = 0; i < 4; ++i) {
         std::string p = "neck.fusion_stage.layers." + std::to_string(i) + ".";
         RC(pack_linear(e, p + "projection.weight", p + "projection.bias", F, F, e->fu[i].proj));
@@ -751,6 +796,7 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
         if (e->overlap) {
             D2S_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
             for (int i = 0; i < 4; ++i) D2S_HIP(hipEventCreateWithFlags(&e->ev_tap[i], hipEventDisableTiming));
+            for (int i = 0; i < 4; ++i) D2S_HIP(hipEventCreateWithFlags(&e->ev_ln[i], hipEventDisableTiming));
             D2S_HIP(hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
         }
     }
@@ -824,6 +870,7 @@ extern "C" int d2s_engine_destroy(d2s_engine* e) {
     if (!e) return D2S_OK;
     if (e->side) (void)hipStreamSynchronize(e->side);
     for (int i = 0; i < 4; ++i) if (e->ev_tap[i]) (void)hipEventDestroy(e->ev_tap[i]);
+    for (int i = 0; i < 4; ++i) if (e->ev_ln[i]) (void)hipEventDestroy(e->ev_ln[i]);
     if (e->ev_side) (void)hipEventDestroy(e->ev_side);
     if (e->side) (void)hipStreamDestroy(e->side);
     for (void* p : e->allocs) (void)hipFree(p);

@@ -56,6 +56,7 @@ struct GemmEpi {
     // Consumer: A rows are the RAW bf16 residual and W is gamma-folded, so LN(x) W = rstd * (x W' - mean * colsum(W'));
     // the kernel applies v = rstd[m] * (acc - mean[m] * ln_csum[n]) before bias (bias already holds b + W beta).
     const float* ln_stats; int ln_slots; const float* ln_csum; float ln_eps; int ln_dim;
+    int ln_M;                                     // rows per slot of ln_stats when it is not this GEMM's M (0: M)
 };
 
 // precision: D2S_PREC_FP32 (T = float) / D2S_PREC_BF16 (T = bf16) / D2S_PREC_FP8_OPERANDS (T = e4m3).  tile: 0 = auto.

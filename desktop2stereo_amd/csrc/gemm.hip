@@ -336,7 +336,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
 #pragma unroll
             for (int q = 0; q < LNS; ++q) {
                 const int sl = fg + 4 * q;
-                lnp[i][q] = (m < M && sl < e.ln_slots) ? ((const float2*)e.ln_stats)[(long)sl * M + m] : make_float2(0.f, 0.f);
+                lnp[i][q] = (m < M && sl < e.ln_slots) ? ((const float2*)e.ln_stats)[(long)sl * (e.ln_M ? e.ln_M : M) + m] : make_float2(0.f, 0.f);
             }
         }
     }
