@@ -129,3 +129,35 @@ def test_4k_full_tab_frame():
     buf = io.BytesIO()
     PIL.fromarray(rgb).save(buf, "JPEG", quality=90, subsampling="4:2:0", optimize=False)
     assert got == buf.getvalue(), f"{len(got)} vs {len(buf.getvalue())} bytes"
+
+
+def test_property_gpu_equals_libjpeg_turbo():
+    """Property test (hypothesis): shapes up to 200 x 300, any quality, several content classes, uint8 or float input ->
+    the device encoder's bytes are libjpeg-turbo's (through Pillow)."""
+    PIL = pytest.importorskip("PIL.Image")
+    pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from desktop2stereo_amd import sink
+
+    @settings(max_examples=40, deadline=None)
+    @given(h=st.integers(1, 200), w=st.integers(1, 300), q=st.integers(1, 100), seed=st.integers(0, 2**31 - 1),
+           kind=st.sampled_from(["noise", "flat", "ramp", "checker", "smooth"]), as_float=st.booleans())
+    def check(h, w, q, seed, kind, as_float):
+        rng = np.random.default_rng(seed)
+        if kind == "noise":
+            rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        elif kind == "flat":
+            rgb = np.broadcast_to(rng.integers(0, 256, 3, dtype=np.uint8), (h, w, 3)).copy()
+        elif kind == "ramp":
+            rgb = ((np.arange(w)[None, :, None] * 7 + np.arange(h)[:, None, None] * 5 + np.arange(3)[None, None, :] * 40) % 256).astype(np.uint8)
+        elif kind == "checker":
+            rgb = (((np.arange(w)[None, :, None] + np.arange(h)[:, None, None]) % 2) * 255 * np.ones(3, dtype=np.int64)).astype(np.uint8)
+        else:
+            yy, xx = np.mgrid[0:h, 0:w]
+            rgb = np.stack([128 + 100 * np.sin(xx / 17.0), 128 + 100 * np.cos(yy / 11.0), 128 + 60 * np.sin((xx + yy) / 23.0)], -1).astype(np.uint8)
+        buf = io.BytesIO()
+        PIL.fromarray(rgb).save(buf, "JPEG", quality=q, subsampling="4:2:0", optimize=False)
+        frame = rgb.astype(np.float32) if as_float else rgb
+        assert sink.encode_jpeg(frame, q) == buf.getvalue(), (h, w, q, kind, as_float)
+
+    check()

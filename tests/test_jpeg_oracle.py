@@ -55,3 +55,30 @@ def test_pillow_agrees_when_present(golden_dir):
     buf = io.BytesIO()
     PIL.fromarray(rgb).save(buf, "JPEG", quality=90, subsampling="4:2:0", optimize=False)
     assert J.encode_jpeg(rgb, 90) == buf.getvalue()
+
+
+def test_oracle_vs_pillow_property():
+    """Property test (hypothesis): any small RGB image, any quality -> the oracle's bytes are libjpeg-turbo's bytes."""
+    PIL = pytest.importorskip("PIL.Image")
+    hyp = pytest.importorskip("hypothesis")
+    import io
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(h=st.integers(1, 40), w=st.integers(1, 40), q=st.integers(1, 100), seed=st.integers(0, 2**31 - 1),
+           kind=st.sampled_from(["noise", "flat", "ramp", "checker"]))
+    def check(h, w, q, seed, kind):
+        rng = np.random.default_rng(seed)
+        if kind == "noise":
+            rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        elif kind == "flat":
+            rgb = np.broadcast_to(rng.integers(0, 256, 3, dtype=np.uint8), (h, w, 3)).copy()
+        elif kind == "ramp":
+            rgb = ((np.arange(w)[None, :, None] * 7 + np.arange(h)[:, None, None] * 5 + np.arange(3)[None, None, :] * 40) % 256).astype(np.uint8)
+        else:
+            rgb = (((np.arange(w)[None, :, None] + np.arange(h)[:, None, None]) % 2) * 255 * np.ones(3, dtype=np.int64)).astype(np.uint8)
+        buf = io.BytesIO()
+        PIL.fromarray(rgb).save(buf, "JPEG", quality=q, subsampling="4:2:0", optimize=False)
+        assert J.encode_jpeg(rgb, q) == buf.getvalue()
+
+    check()
