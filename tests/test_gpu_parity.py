@@ -213,6 +213,35 @@ def test_warp_fast_equals_generic_and_fused_upsample(dev):
         assert np.array_equal(both[b], one)
 
 
+def test_warp_property_random_shapes_and_parameters(dev):
+    """Property test (hypothesis): the HIP warp == the numpy restatement of make_sbs_core within its float32 coordinate
+    noise for any small frame shape (odd sizes, W % 4 != 0 -> generic kernel), display mode, fill_16_9, IPD, depth ratio
+    and convergence, with full-resolution or model-resolution depth."""
+    pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from desktop2stereo_amd import ops, synth, _lib
+    from oracle import d2s_oracle as O
+
+    @settings(max_examples=30, deadline=None)
+    @given(h=st.integers(8, 96), w=st.integers(8, 160), mode=st.sampled_from(["Half-SBS", "Full-SBS", "Half-TAB", "Full-TAB"]),
+           fill=st.booleans(), ipd=st.floats(0.02, 0.09), ratio=st.floats(0.5, 8.0), conv=st.floats(-0.2, 0.2),
+           seed=st.integers(0, 10**6), small_depth=st.booleans())
+    def check(h, w, mode, fill, ipd, ratio, conv, seed, small_depth):
+        img_np = synth.structured_frame(h, w, seed)
+        dep_np = synth.smooth_depth(h, w, seed) if not small_depth else synth.smooth_depth(max(2, h // 3), max(2, w // 3), seed)
+        img, dep = _t(img_np, dev), _t(dep_np, dev)
+        sp = ops.sbs_params(ipd, ratio, conv, mode, fill)
+        got = ops.make_sbs(img, dep, sp, _lib.FMT_F32_HWC).cpu().numpy()
+        dfull = dep_np if not small_depth else ops.upsample_depth(dep, h, w).cpu().numpy()
+        want = O.make_sbs_core(img_np.transpose(2, 0, 1).astype(np.float32), dfull, ipd, ratio, mode, fill, conv).transpose(1, 2, 0)
+        assert got.shape == want.shape, (got.shape, want.shape)
+        assert np.abs(got - want).max() <= 0.05, (h, w, mode, fill, np.abs(got - want).max())
+        u8 = ops.make_sbs(img, dep, sp, _lib.FMT_U8_HWC).cpu().numpy()
+        assert np.abs(u8.astype(int) - O.to_u8(want).astype(int)).max() <= 1
+
+    check()
+
+
 # ------------------------------------------------------------------------------------------------
 def test_gemm_probe(dev):
     """MFMA GEMM kernel vs float64 numpy: asymmetric operands (transpose-detecting), ragged M/N/K."""
