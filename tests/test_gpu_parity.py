@@ -132,6 +132,34 @@ def test_post_process_edge_cases(dev):
     assert np.abs(got - O.post_process_depth(neg, p.foreground_scale, p.aa_strength)).max() <= 5e-6
 
 
+def test_post_process_property(dev):
+    """Property test (hypothesis): percentile normalise + gamma + foreground scale + Gaussian anti-alias == the numpy
+    restatement for any map shape, value distribution (ties, negatives, constant maps), strengths and the metric flag."""
+    pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from desktop2stereo_amd import ops
+    from desktop2stereo_amd.config import PipelineParams
+    from oracle import d2s_oracle as O
+
+    @settings(max_examples=40, deadline=None)
+    @given(h=st.integers(1, 120), w=st.integers(1, 160), fg=st.floats(-0.3, 0.5), aa=st.floats(0.0, 5.0), metric=st.booleans(),
+           dist=st.sampled_from(["uniform", "normal", "quantised", "constant", "sparse"]), seed=st.integers(0, 10**6))
+    def check(h, w, fg, aa, metric, dist, seed):
+        rng = np.random.default_rng(seed)
+        if dist == "uniform": raw = rng.uniform(0, 20, (h, w))
+        elif dist == "normal": raw = rng.normal(2, 3, (h, w))
+        elif dist == "quantised": raw = rng.integers(0, 6, (h, w)).astype(np.float64)          # many ties at the percentiles
+        elif dist == "constant": raw = np.full((h, w), 1.5)
+        else: raw = rng.uniform(0.1, 30, (h, w)) * (rng.random((h, w)) < 0.3)                   # mostly invalid (0) for metric
+        raw = raw.astype(np.float32)
+        pp = PipelineParams(foreground_scale=fg, aa_strength=aa, metric=metric)
+        got = ops.post_process_depth(_t(raw, dev), pp).cpu().numpy().reshape(h, w)
+        want = O.post_process_depth(raw, fg, aa, metric=metric).reshape(h, w)
+        assert np.abs(got - want).max() <= 2e-5, (h, w, fg, aa, metric, dist, np.abs(got - want).max())
+
+    check()
+
+
 def test_ema_and_upsample(dev, golden_dir):
     from desktop2stereo_amd import ops
     from oracle import d2s_oracle as O
