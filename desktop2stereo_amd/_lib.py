@@ -31,6 +31,13 @@ class PostParams(C.Structure):
                 ("metric", C.c_int32)]
 
 
+RESAMPLE = {"bilinear": 0, "bicubic_aa": 1}      # D2S_RESAMPLE_*: _resize_patch_aligned_t's CPU branch / IS_CUDA branch
+
+
+class PreParams(C.Structure):
+    _fields_ = [("mean", C.c_float * 3), ("std", C.c_float * 3), ("resample", C.c_int32)]
+
+
 class SbsParams(C.Structure):
     _fields_ = [("ipd_uv", C.c_double), ("depth_ratio", C.c_float), ("convergence", C.c_float),
                 ("display_mode", C.c_int32), ("fill_16_9", C.c_int32)]
@@ -54,7 +61,7 @@ SYMBOLS = {
     "d2s_engine_destroy": (C.c_int, [_P]),
     "d2s_engine_memory": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "d2s_preprocess": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int,
-                                 C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
+                                 C.POINTER(PreParams), _P]),
     "d2s_process_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "d2s_process": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "d2s_overlay_text": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_char_p, _P]),
@@ -71,7 +78,7 @@ SYMBOLS = {
     "d2s_dibr_warp": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(DibrParams), _P, C.c_int, _P]),
     "d2s_jpeg_bound": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "d2s_jpeg_encode": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P, _P, C.c_int64, _P]),
-    "d2s_pipeline": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(PostParams),
+    "d2s_pipeline": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(PreParams), C.POINTER(PostParams),
                                C.POINTER(SbsParams), C.c_int, _P, C.c_int, _P, _P]),
     "d2s_engine_reset_stream": (C.c_int, [_P]),
     "d2s_engine_tap": (C.c_int, [_P, C.c_char_p, _P, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),

@@ -90,6 +90,11 @@ class PipelineParams:
     metric: bool = False               # is_metric(), depth.py:666-669 (1/d inversion in normalize)
     mean: Tuple[float, float, float] = IMAGENET_MEAN
     std: Tuple[float, float, float] = IMAGENET_STD
+    # which branch of _resize_patch_aligned_t (reference depth.py:676-706) the pre-process follows:
+    #   "bilinear"   -- the CPU / DirectML branch (::stride decimation + bilinear): what the reference's CPU path computes,
+    #                   the path BASELINE.json's parity bar names (default);
+    #   "bicubic_aa" -- the IS_CUDA branch (depth.py:698-699; true on a ROCm device): bicubic + antialias from the full frame
+    resample: str = "bilinear"
 
     def asdict(self):
         return asdict(self)

@@ -26,6 +26,25 @@ int hip_fail(hipError_t err, const char* what, const char* file, int line);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// The HIP current device is per host thread; the reference issues predict_depth and make_sbs from different threads.
+// Every entry point that takes an engine runs on the ENGINE's device whatever the calling thread's current device is, and
+// leaves the thread's device as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur != dev) { ok = hipSetDevice(dev) == hipSuccess; prev = cur; }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define D2S_ON_DEVICE(dev)                                                                  \
+    ::d2s::DeviceGuard _dev_guard(dev);                                                     \
+    if (!_dev_guard.ok) { ::d2s::set_error("hipSetDevice failed for the engine's device"); return D2S_E_HIP; }
+
 typedef unsigned short bf16_t;   // raw bf16 bits
 
 __host__ __device__ static inline bf16_t f2bf(float f) {

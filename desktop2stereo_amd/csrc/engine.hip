@@ -590,7 +590,7 @@ extern "C" int d2s_engine_create(const d2s_model_desc* desc, int device_id, d2s_
     D2S_REQUIRE(desc->head_hidden % 4 == 0 && desc->mlp % 8 == 0, "bad head_hidden / mlp");
     D2S_REQUIRE(desc->max_depth >= 0.f && !(desc->temporal && desc->max_depth > 0.f),
                 "max_depth must be >= 0, and 0 for a Video-Depth-Anything engine (its head ends in ReLU, dpt_temporal.py:136)");
-    D2S_HIP(hipSetDevice(device_id));
+    D2S_ON_DEVICE(device_id);
     d2s_engine* e = new d2s_engine();
     e->d = *desc; e->device = device_id;
     e->fp8 = desc->precision == D2S_PREC_FP8;
@@ -621,7 +621,7 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
     if (e->finalized) { set_error("engine already finalized"); return D2S_E_STATE; }
     const d2s_model_desc& d = e->d;
     D2S_REQUIRE(h > 0 && w > 0 && h % d.patch == 0 && w % d.patch == 0 && max_batch >= 1, "h, w must be patch multiples");
-    D2S_HIP(hipSetDevice(e->device));
+    D2S_ON_DEVICE(e->device);
     const int D = d.hidden, F = d.fusion;
     e->h = h; e->w = w; e->gh = h / d.patch; e->gw = w / d.patch; e->P = e->gh * e->gw; e->N = e->P + 1;
     e->Npad = (e->N + 63) / 64 * 64; e->maxB = max_batch;
@@ -868,6 +868,7 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
 
 extern "C" int d2s_engine_destroy(d2s_engine* e) {
     if (!e) return D2S_OK;
+    D2S_ON_DEVICE(e->device);
     if (e->side) (void)hipStreamSynchronize(e->side);
     for (int i = 0; i < 4; ++i) if (e->ev_tap[i]) (void)hipEventDestroy(e->ev_tap[i]);
     for (int i = 0; i < 4; ++i) if (e->ev_ln[i]) (void)hipEventDestroy(e->ev_ln[i]);
@@ -889,6 +890,7 @@ extern "C" int d2s_model_forward(d2s_engine* e, const float* x, float* depth, in
     if (!e->finalized) { set_error("d2s_model_forward before d2s_engine_finalize"); return D2S_E_STATE; }
     D2S_REQUIRE(batch >= 1 && batch <= e->maxB, "batch exceeds max_batch");
     D2S_REQUIRE(!e->d.temporal || batch == 1, "a Video-Depth-Anything engine is one stream: batch must be 1");
+    D2S_ON_DEVICE(e->device);
     return forward(e, x, depth, batch, (hipStream_t)stream);
 }
 
@@ -897,6 +899,7 @@ extern "C" int d2s_engine_calibrate(d2s_engine* e, const float* x, int batch, vo
     if (!e->finalized) { set_error("d2s_engine_calibrate before d2s_engine_finalize"); return D2S_E_STATE; }
     D2S_REQUIRE(e->fp8, "d2s_engine_calibrate: not a D2S_PREC_FP8 engine");
     D2S_REQUIRE(batch >= 1 && batch <= e->maxB && !e->d.temporal, "bad batch (or a Video-Depth-Anything engine)");
+    D2S_ON_DEVICE(e->device);
     hipStream_t st = (hipStream_t)stream;
     const int L = e->d.layers;
     // one bf16 forward over the calibration frames, recording max |activation| at the four quantisation sites per layer
@@ -944,8 +947,8 @@ extern "C" int d2s_engine_reset_stream(d2s_engine* e) {
 }
 
 extern "C" int d2s_pipeline(d2s_engine* e, const uint8_t* frames, int batch, int H, int W, int depth_resolution,
-                            const d2s_post_params* pp, const d2s_sbs_params* sp, int use_ema, void* out, int out_fmt,
-                            float* depth_full, void* stream) {
+                            const d2s_pre_params* pre, const d2s_post_params* pp, const d2s_sbs_params* sp, int use_ema,
+                            void* out, int out_fmt, float* depth_full, void* stream) {
     D2S_REQUIRE(e && frames && pp && sp && out, "null pointer");
     if (!e->finalized) { set_error("d2s_pipeline before d2s_engine_finalize"); return D2S_E_STATE; }
     D2S_REQUIRE(batch >= 1 && batch <= e->maxB, "batch exceeds max_batch");
@@ -963,9 +966,9 @@ extern "C" int d2s_pipeline(d2s_engine* e, const uint8_t* frames, int batch, int
     }
     int stride = longest / (depth_resolution * 2);
     if (stride < 1) stride = 1;
+    D2S_ON_DEVICE(e->device);
     hipStream_t st = (hipStream_t)stream;
-    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};   // depth.py:1798-1799
-    PROF(PC_PRE, 0, (double)batch * ((double)H * W * 3 + (double)e->h * e->w * 12), d2s_preprocess(frames, D2S_FMT_U8_HWC, batch, H, W, e->pre_x, e->h, e->w, stride, mean, stdv, stream));
+    PROF(PC_PRE, 0, (double)batch * ((double)H * W * 3 + (double)e->h * e->w * 12), d2s_preprocess(frames, D2S_FMT_U8_HWC, batch, H, W, e->pre_x, e->h, e->w, stride, pre, stream));
     RC(forward(e, e->pre_x, e->depth_small, batch, st));
     PROF(PC_POST, 0, 0, d2s_post_process(e->depth_small, batch, e->h, e->w, pp, e->post_ws, e->post_ws_bytes, stream));
     if (use_ema) {
@@ -986,6 +989,7 @@ extern "C" int d2s_pipeline(d2s_engine* e, const uint8_t* frames, int batch, int
 extern "C" int d2s_engine_tap(d2s_engine* e, const char* name, float* out, uint64_t out_elems, int* rows, int* cols, void* stream) {
     D2S_REQUIRE(e && name && out && rows && cols, "null pointer");
     if (!e->finalized || e->last_batch == 0) { set_error("d2s_engine_tap: no forward pass yet"); return D2S_E_STATE; }
+    D2S_ON_DEVICE(e->device);
     hipStream_t st = (hipStream_t)stream;
     std::string n(name);
     const int D = e->d.hidden, F = e->d.fusion;
@@ -1020,6 +1024,7 @@ extern "C" int d2s_engine_profile(d2s_engine* e, int enable) {
 extern "C" int d2s_engine_profile_read(d2s_engine* e, int max_classes, double* ms, double* flops, double* bytes,
                                        int64_t* launches, int* n_classes) {
     D2S_REQUIRE(e && ms && flops && bytes && launches && n_classes && max_classes >= PC_N, "bad argument");
+    D2S_ON_DEVICE(e->device);
     for (int c = 0; c < PC_N; ++c) { ms[c] = 0; flops[c] = 0; bytes[c] = 0; launches[c] = 0; }
     const char* dump = getenv("D2S_PROF_DUMP");             // tuning aid: one line per recorded launch on stderr
     int idx = 0;

@@ -66,6 +66,103 @@ preprocess_kernel(const void* __restrict__ frames, int B, int H, int W, int stri
 }
 
 // ------------------------------------------------------------------------------------------------
+// A2-A4, the IS_CUDA branch of _resize_patch_aligned_t (reference depth.py:698-699 -- the branch the reference takes on
+// a CUDA *or ROCm* device): ONE F.interpolate(bicubic, align_corners=False, antialias=True) from the full frame, i.e.
+// ATen's _upsample_bicubic2d_aa: separable Keys cubic (a = -0.5) stretched by the scale (support = 2 * scale source
+// pixels: 15 taps per axis at 1080p -> 294x518, 30 at 4K), weights normalised per output index, horizontal pass over
+// every contributing source row, then the vertical pass over those results; no clamp (the lobes overshoot 0..255).
+// One block = an AA_TH x AA_TW output tile of one frame: tap tables for its columns / rows are built once in LDS, the
+// horizontal pass of the tile's source-row span is staged in LDS ([rows][AA_TW][3] floats), the vertical pass reads it.
+// Same operation order per value as the two-pass ATen kernel (taps accumulated first to last, mul then add).
+// ------------------------------------------------------------------------------------------------
+constexpr int AA_TW = 32, AA_TH = 8;          // output tile (columns x rows); rows shrink for very large frames
+constexpr int AA_MAXTAPS = 64;                // taps per axis: ceil(4 * scale) + 2 <= 64  <=>  frames up to ~15x the model input
+constexpr int AA_MAXROWS = 128;               // source rows whose horizontal pass one tile stages
+
+struct AaAxis { int xmin, xsize; };
+// ATen HelperInterpCubic geometry for output index i (UpSampleKernel.cpp _compute_indices_min_size_weights_aa, float math)
+__device__ __forceinline__ AaAxis aa_cubic_taps(int i, float scale, int in_size, float* w /* [AA_MAXTAPS] */) {
+    const float support = scale >= 1.f ? 2.0f * scale : 2.0f;
+    const float invscale = scale >= 1.f ? 1.0f / scale : 1.f;
+    const float center = scale * ((float)i + 0.5f);
+    int lo = (int)((double)(center - support) + 0.5);           // ATen adds the double literal 0.5 before truncating
+    int hi = (int)((double)(center + support) + 0.5);
+    AaAxis t;
+    t.xmin = lo > 0 ? lo : 0;
+    t.xsize = (hi < in_size ? hi : in_size) - t.xmin;
+    if (t.xsize > AA_MAXTAPS) t.xsize = AA_MAXTAPS;             // (the launcher rejects scales that would need more)
+    float total = 0.f;
+    for (int j = 0; j < t.xsize; ++j) {
+        float x = fabsf(((float)(j + t.xmin) - center + 0.5f) * invscale);
+        const float a = -0.5f;
+        float v = x < 1.f ? ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f : (x < 2.f ? ((a * x - 5.f * a) * x + 8.f * a) * x - 4.f * a : 0.f);
+        w[j] = v; total += v;
+    }
+    if (total != 0.f) for (int j = 0; j < t.xsize; ++j) w[j] = w[j] / total;
+    return t;
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(256)
+preprocess_aa_kernel(const void* __restrict__ frames, int B, int H, int W, float* __restrict__ out, int h, int w,
+                     float sy, float sx, int th, float m0, float m1, float m2, float s0, float s1, float s2) {
+    __shared__ float wx[AA_TW][AA_MAXTAPS + 1], wy[AA_TH][AA_MAXTAPS + 1];
+    __shared__ int xmn[AA_TW], xsz[AA_TW], ymn[AA_TH], ysz[AA_TH];
+    __shared__ float hp[AA_MAXROWS][AA_TW][3];
+    const int tid = threadIdx.x;
+    const int tiles_x = (w + AA_TW - 1) / AA_TW, tiles_y = (h + th - 1) / th;
+    int bid = blockIdx.x;
+    const int tx0 = (bid % tiles_x) * AA_TW, ty0 = ((bid / tiles_x) % tiles_y) * th, b = bid / (tiles_x * tiles_y);
+    if (tid < AA_TW) {
+        int ox = tx0 + tid < w ? tx0 + tid : w - 1;
+        AaAxis t = aa_cubic_taps(ox, sx, W, wx[tid]);
+        xmn[tid] = t.xmin; xsz[tid] = t.xsize;
+    } else if (tid >= 64 && tid < 64 + th) {
+        int r = tid - 64, oy = ty0 + r < h ? ty0 + r : h - 1;
+        AaAxis t = aa_cubic_taps(oy, sy, H, wy[r]);
+        ymn[r] = t.xmin; ysz[r] = t.xsize;
+    }
+    __syncthreads();
+    const int nr_out = ty0 + th <= h ? th : h - ty0;
+    const int y_first = ymn[0], y_last = ymn[nr_out - 1] + ysz[nr_out - 1];     // source rows [y_first, y_last)
+    const int nrows = y_last - y_first;
+    const long fo = (long)b * H * W;
+    // horizontal pass of every contributing source row, for the tile's columns
+    for (int idx = tid; idx < nrows * AA_TW; idx += 256) {
+        const int r = idx / AA_TW, c = idx - r * AA_TW;
+        float ar = 0.f, ag = 0.f, ab = 0.f;
+        const int x0 = xmn[c], n = xsz[c];
+        for (int k = 0; k < n; ++k) {
+            float pr, pg, pb;
+            load_px<FMT>(frames, fo, H, W, y_first + r, x0 + k, pr, pg, pb);
+            const float wk = wx[c][k];
+            ar += wk * pr; ag += wk * pg; ab += wk * pb;
+        }
+        hp[r][c][0] = ar; hp[r][c][1] = ag; hp[r][c][2] = ab;
+    }
+    __syncthreads();
+    // vertical pass + /255 + (x - mean) / std
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    const long plane = (long)h * w;
+    for (int idx = tid; idx < nr_out * AA_TW; idx += 256) {
+        const int r = idx / AA_TW, c = idx - r * AA_TW;
+        if (tx0 + c >= w) continue;
+        const int r0 = ymn[r] - y_first, n = ysz[r];
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < n; ++k) {
+            const float wk = wy[r][k];
+            acc[0] += wk * hp[r0 + k][c][0]; acc[1] += wk * hp[r0 + k][c][1]; acc[2] += wk * hp[r0 + k][c][2];
+        }
+        float* o = out + (long)b * 3 * plane + (long)(ty0 + r) * w + tx0 + c;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = acc[ch] / 255.0f;
+            o[ch * plane] = (v - mean[ch]) / stdv[ch];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // A13: depth up-sample, bilinear align_corners=False
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -467,14 +564,40 @@ using namespace d2s;
 // C-ABI
 // ================================================================================================
 extern "C" int d2s_preprocess(const void* frames, int fmt, int batch, int H, int W, float* out, int h, int w,
-                              int decim_stride, const float mean[3], const float stdv[3], void* stream) {
-    D2S_REQUIRE(frames && out && mean && stdv, "null pointer");
+                              int decim_stride, const d2s_pre_params* pre, void* stream) {
+    D2S_REQUIRE(frames && out, "null pointer");
+    static const d2s_pre_params dflt = {{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}, D2S_RESAMPLE_BILINEAR};   // depth.py:1798-1799
+    if (!pre) pre = &dflt;
+    const float* mean = pre->mean;
+    const float* stdv = pre->std;
     D2S_REQUIRE(batch > 0 && H > 0 && W > 0 && h > 0 && w > 0 && decim_stride >= 1, "bad shape");
+    D2S_REQUIRE(pre->resample == D2S_RESAMPLE_BILINEAR || pre->resample == D2S_RESAMPLE_BICUBIC_AA, "bad resample mode");
+    hipStream_t st = (hipStream_t)stream;
+    if (pre->resample == D2S_RESAMPLE_BICUBIC_AA && !(h == H && w == W)) {
+        // the IS_CUDA branch resamples the FULL frame (no ::stride decimation, depth.py:698-699)
+        const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+        const float spy = sy >= 1.f ? 2.f * sy : 2.f, spx = sx >= 1.f ? 2.f * sx : 2.f;
+        D2S_REQUIRE((int)(2.f * spy) + 2 <= AA_MAXTAPS && (int)(2.f * spx) + 2 <= AA_MAXTAPS,
+                    "bicubic + antialias pre-process: frame more than ~15x the model input per axis");
+        int th = AA_TH;                                           // output rows per tile whose source-row span fits the LDS stage
+        while (th > 1 && (int)((float)th * sy + 2.f * spy) + 3 > AA_MAXROWS) th >>= 1;
+        D2S_REQUIRE((int)((float)th * sy + 2.f * spy) + 3 <= AA_MAXROWS, "bicubic + antialias pre-process: vertical scale too large");
+        dim3 grid((unsigned)((long)batch * cdiv(h, th) * cdiv(w, AA_TW))), block(256);
+#define LAUNCH_AA(F) hipLaunchKernelGGL(preprocess_aa_kernel<F>, grid, block, 0, st, frames, batch, H, W, out, h, w, sy, sx, th, \
+        mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2])
+        if (fmt == D2S_FMT_U8_HWC) LAUNCH_AA(D2S_FMT_U8_HWC);
+        else if (fmt == D2S_FMT_U8_CHW) LAUNCH_AA(D2S_FMT_U8_CHW);
+        else if (fmt == D2S_FMT_F32_CHW) LAUNCH_AA(D2S_FMT_F32_CHW);
+        else { set_error("d2s_preprocess: unsupported frame format"); return D2S_E_UNSUPPORTED; }
+#undef LAUNCH_AA
+        D2S_CHECK_LAUNCH();
+        return D2S_OK;
+    }
+    if (pre->resample == D2S_RESAMPLE_BICUBIC_AA) decim_stride = 1;   // (same size: both branches return the frame as is)
     int Hs = (H + decim_stride - 1) / decim_stride, Ws = (W + decim_stride - 1) / decim_stride;
     float sy = linear_scale(Hs, h, false), sx = linear_scale(Ws, w, false);
     long total = (long)batch * h * w;
     dim3 grid(cdiv(total, 256)), block(256);
-    hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_PRE(F) hipLaunchKernelGGL(preprocess_kernel<F>, grid, block, 0, st, frames, batch, H, W, decim_stride, \
         out, h, w, sy, sx, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2])
     if (fmt == D2S_FMT_U8_HWC) LAUNCH_PRE(D2S_FMT_U8_HWC);

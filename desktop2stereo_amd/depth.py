@@ -117,7 +117,7 @@ def _fp8_first_inputs(frames_u8: torch.Tensor, key) -> Optional[torch.Tensor]:
     if _state["precision"] != "fp8" or (_state["engine"] is not None and _state["engine_key"] == key):
         return None
     p = _state["params"]
-    return ops.preprocess(frames_u8, p.depth_resolution, _state["cfg"].patch, p.mean, p.std)
+    return ops.preprocess(frames_u8, p.depth_resolution, _state["cfg"].patch, p.mean, p.std, p.resample)
 
 
 def process(img_uint8, target_height: int) -> torch.Tensor:
@@ -182,7 +182,7 @@ def predict_depth(image_rgb, return_tuple=False, use_temporal_smooth: bool = Tru
         hwc = torch.from_numpy(np.ascontiguousarray(image_rgb)).to(device=_device(), non_blocking=True)
         rgb_tensor = hwc.permute(2, 0, 1)
         src = hwc
-    x = ops.preprocess(src, p.depth_resolution, _state["cfg"].patch if _state["cfg"] else 14, p.mean, p.std)
+    x = ops.preprocess(src, p.depth_resolution, _state["cfg"].patch if _state["cfg"] else 14, p.mean, p.std, p.resample)
     eng = _ensure_engine_built(x.shape[2], x.shape[3], x)
     depth = eng(x)
     depth = ops.post_process_depth(depth, p)[0]
@@ -228,7 +228,9 @@ def make_sbs(rgb_c, depth, ipd_uv=0.064, depth_ratio=2.0, convergence=0.0, fill_
     if isinstance(rgb_c, np.ndarray):
         rgb = torch.from_numpy(np.ascontiguousarray(rgb_c)).to(device=_device())       # HWC uint8 / float
         if rgb.dtype != torch.uint8:
-            rgb = rgb.float().permute(2, 0, 1).contiguous()
+            rgb = rgb.float()
+            if rgb.dim() == 3 and rgb.shape[2] == 3:              # HWC -> CHW only when it IS HWC (reference depth.py:2205-2207)
+                rgb = rgb.permute(2, 0, 1).contiguous()
     else:
         rgb = rgb_c.to(device=_device())
         if rgb.dtype != torch.uint8:
@@ -279,7 +281,7 @@ def pipeline_mixed(frames_list, display_mode=None, out_u8=True):
         groups.setdefault(tuple(t.shape[:2]), []).append(i)
     x = torch.empty((len(ts), 3, h, w), dtype=torch.float32, device=dev)
     for (H, W), idx in groups.items():
-        x[idx] = ops.preprocess(torch.stack([ts[i] for i in idx]), p.depth_resolution, cfg.patch, p.mean, p.std)
+        x[idx] = ops.preprocess(torch.stack([ts[i] for i in idx]), p.depth_resolution, cfg.patch, p.mean, p.std, p.resample)
     depth = ops.post_process_depth(eng(x), p)
     sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, display_mode or p.display_mode, p.fill_16_9)
     out = [None] * len(ts)

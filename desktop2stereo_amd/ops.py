@@ -15,12 +15,31 @@ import torch
 
 from . import _lib
 from ._lib import (FMT_F32_CHW, FMT_F32_HWC, FMT_U8_CHW, FMT_U8_HWC, MODE, PREC_BF16, PREC_FP32,
-                   ModelDesc, PostParams, SbsParams, check)
+                   ModelDesc, PostParams, PreParams, SbsParams, check)
 from .config import IMAGENET_MEAN, IMAGENET_STD, ModelConfig, PipelineParams, engine_shape
 
 
-def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+class _on:
+    """Scope of one native call on `device`: the HIP current device is per host thread and the reference issues
+    predict_depth and make_sbs from different threads, so the device of the tensors is made
+    current around the call and the stream handed to the library is THAT device's current stream (not the calling
+    thread's default device's).  `with _on(t.device) as st: lib.d2s_...(..., st)`."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.guard = torch.cuda.device(device)
+
+    def __enter__(self) -> C.c_void_p:
+        self.guard.__enter__()
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __exit__(self, *exc):
+        return self.guard.__exit__(*exc)
+
+
+def _same_device(a: torch.Tensor, b: torch.Tensor, what: str):
+    if a.device != b.device:
+        raise _lib.D2SError(f"{what}: tensors on different devices ({a.device} vs {b.device})")
 
 
 def _ptr(t: torch.Tensor) -> C.c_void_p:
@@ -35,6 +54,12 @@ def _need_cuda(t: torch.Tensor, what: str):
 def post_params(p: PipelineParams) -> PostParams:
     return PostParams(p.percentile, p.subsample_cap, p.gamma, p.foreground_scale, p.aa_strength, p.ema_alpha,
                       int(bool(p.metric)))
+
+
+def pre_params(mean=IMAGENET_MEAN, std=IMAGENET_STD, resample: str = "bilinear") -> PreParams:
+    if resample not in _lib.RESAMPLE:
+        raise ValueError(f"resample must be one of {list(_lib.RESAMPLE)}")
+    return PreParams((C.c_float * 3)(*mean), (C.c_float * 3)(*std), _lib.RESAMPLE[resample])
 
 
 def sbs_params(ipd_uv=0.064, depth_ratio=2.0, convergence=0.0, display_mode="Half-SBS", fill_16_9=False) -> SbsParams:
@@ -75,7 +100,8 @@ def process(img_bgr: torch.Tensor, target_height: int) -> torch.Tensor:
     oh, ow = C.c_int(), C.c_int()
     check(lib.d2s_process_shape(H0, W0, int(target_height), C.byref(oh), C.byref(ow)), "d2s_process_shape")
     out = torch.empty((3, oh.value, ow.value), dtype=torch.float32, device=img_bgr.device)
-    check(lib.d2s_process(_ptr(img_bgr), ch, H0, W0, int(target_height), _ptr(out), _stream()), "d2s_process")
+    with _on(img_bgr.device) as st:
+        check(lib.d2s_process(_ptr(img_bgr), ch, H0, W0, int(target_height), _ptr(out), st), "d2s_process")
     return out
 
 
@@ -90,20 +116,23 @@ def overlay_text(frame: torch.Tensor, text: str) -> torch.Tensor:
         fmt, B, H, W = _frame_fmt(frame)
         if B != 1:
             raise ValueError("overlay_text takes one frame")
-    check(_lib.load().d2s_overlay_text(_ptr(frame), fmt, H, W, text.encode(), _stream()), "d2s_overlay_text")
+    with _on(frame.device) as st:
+        check(_lib.load().d2s_overlay_text(_ptr(frame), fmt, H, W, text.encode(), st), "d2s_overlay_text")
     return frame
 
 
-def preprocess(frames: torch.Tensor, target: int, patch: int = 14, mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
-    """A2-A4 (reference depth.py:676-706, 1916-1948) -> float32 [B,3,h,w]."""
+def preprocess(frames: torch.Tensor, target: int, patch: int = 14, mean=IMAGENET_MEAN, std=IMAGENET_STD,
+               resample: str = "bilinear") -> torch.Tensor:
+    """A2-A4 (reference depth.py:676-706, 1916-1948) -> float32 [B,3,h,w].  resample: "bilinear" = the CPU branch of
+    _resize_patch_aligned_t (decimation + bilinear), "bicubic_aa" = its IS_CUDA branch (depth.py:698-699)."""
     _need_cuda(frames, "frames")
     frames = frames.contiguous()
     fmt, B, H, W = _frame_fmt(frames)
     h, w, stride = engine_shape(H, W, target, patch)
     out = torch.empty((B, 3, h, w), dtype=torch.float32, device=frames.device)
-    m = (C.c_float * 3)(*mean)
-    s = (C.c_float * 3)(*std)
-    check(_lib.load().d2s_preprocess(_ptr(frames), fmt, B, H, W, _ptr(out), h, w, stride, m, s, _stream()), "d2s_preprocess")
+    pre = pre_params(mean, std, resample)
+    with _on(frames.device) as st:
+        check(_lib.load().d2s_preprocess(_ptr(frames), fmt, B, H, W, _ptr(out), h, w, stride, C.byref(pre), st), "d2s_preprocess")
     return out
 
 
@@ -117,14 +146,17 @@ def post_process_depth(depth: torch.Tensor, p: PipelineParams) -> torch.Tensor:
     nbytes = lib.d2s_post_process_workspace(B, h, w)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=d.device)
     pp = post_params(p)
-    check(lib.d2s_post_process(_ptr(d), B, h, w, C.byref(pp), _ptr(ws), nbytes, _stream()), "d2s_post_process")
+    with _on(d.device) as st:
+        check(lib.d2s_post_process(_ptr(d), B, h, w, C.byref(pp), _ptr(ws), nbytes, st), "d2s_post_process")
     return d
 
 
 def ema_update(depth: torch.Tensor, state: torch.Tensor, initialised: bool, alpha: float) -> torch.Tensor:
     """A12 (reference depth.py:1865-1887); depth [h,w] is overwritten with the returned value."""
     h, w = depth.shape
-    check(_lib.load().d2s_ema_update(_ptr(depth), _ptr(state), int(initialised), h, w, alpha, _stream()), "d2s_ema_update")
+    _same_device(depth, state, "ema_update")
+    with _on(depth.device) as st:
+        check(_lib.load().d2s_ema_update(_ptr(depth), _ptr(state), int(initialised), h, w, alpha, st), "d2s_ema_update")
     return depth
 
 
@@ -135,7 +167,8 @@ def upsample_depth(depth: torch.Tensor, H: int, W: int) -> torch.Tensor:
     B = d.shape[0] if d.dim() == 3 else 1
     h, w = d.shape[-2:]
     out = torch.empty((B, H, W) if d.dim() == 3 else (H, W), dtype=torch.float32, device=d.device)
-    check(_lib.load().d2s_upsample_depth(_ptr(d), B, h, w, _ptr(out), H, W, _stream()), "d2s_upsample_depth")
+    with _on(d.device) as st:
+        check(_lib.load().d2s_upsample_depth(_ptr(d), B, h, w, _ptr(out), H, W, st), "d2s_upsample_depth")
     return out
 
 
@@ -143,6 +176,7 @@ def make_sbs(frames: torch.Tensor, depth: torch.Tensor, sp: SbsParams, out_fmt: 
     """A14 (+A13 fused when depth is at model resolution) (reference depth.py:2122-2184)."""
     _need_cuda(frames, "frames")
     _need_cuda(depth, "depth")
+    _same_device(frames, depth, "make_sbs")
     frames = frames.contiguous()
     d = depth.to(torch.float32).contiguous()
     fmt, B, H, W = _frame_fmt(frames)
@@ -160,8 +194,9 @@ def make_sbs(frames: torch.Tensor, depth: torch.Tensor, sp: SbsParams, out_fmt: 
         out = torch.empty((B, 3, oh, ow), dtype=torch.float32, device=frames.device)
     else:
         raise ValueError("bad out_fmt")
-    check(_lib.load().d2s_make_sbs(_ptr(frames), fmt, _ptr(d), dh, dw, B, H, W, C.byref(sp), _ptr(out), out_fmt, _stream()),
-          "d2s_make_sbs")
+    with _on(frames.device) as st:
+        check(_lib.load().d2s_make_sbs(_ptr(frames), fmt, _ptr(d), dh, dw, B, H, W, C.byref(sp), _ptr(out), out_fmt, st),
+              "d2s_make_sbs")
     return out if batched else out[0]
 
 
@@ -194,8 +229,10 @@ def dibr_warp(frames: torch.Tensor, depth: torch.Tensor, dp: "_lib.DibrParams", 
     oh, ow = C.c_int(), C.c_int()
     check(lib.d2s_dibr_shape(H, W, dp.display_mode, C.byref(oh), C.byref(ow)), "d2s_dibr_shape")
     out = torch.empty((B, oh.value, ow.value, 3), dtype=torch.uint8 if out_u8 else torch.float32, device=f.device)
-    check(lib.d2s_dibr_warp(_ptr(f), _ptr(d), B, H, W, C.byref(dp), _ptr(out), FMT_U8_HWC if out_u8 else FMT_F32_HWC,
-                            _stream()), "d2s_dibr_warp")
+    _same_device(f, d, "dibr_warp")
+    with _on(f.device) as st:
+        check(lib.d2s_dibr_warp(_ptr(f), _ptr(d), B, H, W, C.byref(dp), _ptr(out), FMT_U8_HWC if out_u8 else FMT_F32_HWC, st),
+              "d2s_dibr_warp")
     return out if batched else out[0]
 
 
@@ -238,9 +275,11 @@ def jpeg_encode(frames: torch.Tensor, quality: int = 90, out_stride: Optional[in
     pad = (-ws.data_ptr()) % 256
     out = torch.empty((B, stride), dtype=torch.uint8, device=f.device)
     sizes = torch.empty((B,), dtype=torch.int32, device=f.device)
-    check(_lib.load().d2s_jpeg_encode(_ptr(f), FMT_U8_HWC if f.dtype == torch.uint8 else FMT_F32_HWC, B, H, W, int(quality),
-                                      _ptr(out), stride, _ptr(sizes), C.c_void_p(ws.data_ptr() + pad), ws_frame * B, _stream()),
-          "d2s_jpeg_encode")
+    _same_device(f, ws, "jpeg_encode workspace")
+    with _on(f.device) as st:
+        check(_lib.load().d2s_jpeg_encode(_ptr(f), FMT_U8_HWC if f.dtype == torch.uint8 else FMT_F32_HWC, B, H, W, int(quality),
+                                          _ptr(out), stride, _ptr(sizes), C.c_void_p(ws.data_ptr() + pad), ws_frame * B, st),
+              "d2s_jpeg_encode")
     return out, sizes
 
 
@@ -265,13 +304,19 @@ class Engine:
         if precision not in ("bf16", "fp32", "fp8"):
             raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
         self._h = C.c_void_p()
-        check(self.lib.d2s_engine_create(C.byref(desc), device, C.byref(self._h)), "d2s_engine_create")
-        for name, arr in weights.items():
-            a = np.ascontiguousarray(arr, dtype=np.float32)
-            shape = (C.c_int64 * a.ndim)(*a.shape)
-            check(self.lib.d2s_engine_set_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim),
-                  f"d2s_engine_set_weight({name})")
-        check(self.lib.d2s_engine_finalize(self._h, h, w, max_batch), "d2s_engine_finalize")
+        with _on(self.device):
+            check(self.lib.d2s_engine_create(C.byref(desc), device, C.byref(self._h)), "d2s_engine_create")
+            for name, arr in weights.items():
+                a = np.ascontiguousarray(arr, dtype=np.float32)
+                shape = (C.c_int64 * a.ndim)(*a.shape)
+                check(self.lib.d2s_engine_set_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim),
+                      f"d2s_engine_set_weight({name})")
+            check(self.lib.d2s_engine_finalize(self._h, h, w, max_batch), "d2s_engine_finalize")
+
+    def _mine(self, t: torch.Tensor, what: str):
+        _need_cuda(t, what)
+        if t.device != self.device:
+            raise _lib.D2SError(f"{what} is on {t.device}, the engine lives on {self.device}")
 
     def memory_bytes(self) -> int:
         b = C.c_uint64()
@@ -279,7 +324,7 @@ class Engine:
         return b.value
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        _need_cuda(x, "pixel_values")
+        self._mine(x, "pixel_values")
         x = x.to(torch.float32).contiguous()
         if x.dim() == 3:
             x = x.unsqueeze(0)
@@ -287,25 +332,28 @@ class Engine:
         if tuple(x.shape[1:]) != (3, self.h, self.w):
             raise ValueError(f"engine was built for [B,3,{self.h},{self.w}], got {tuple(x.shape)}")
         out = torch.empty((B, self.h, self.w), dtype=torch.float32, device=x.device)
-        check(self.lib.d2s_model_forward(self._h, _ptr(x), _ptr(out), B, _stream()), "d2s_model_forward")
+        with _on(self.device) as st:
+            check(self.lib.d2s_model_forward(self._h, _ptr(x), _ptr(out), B, st), "d2s_model_forward")
         return out
 
     def calibrate(self, x: torch.Tensor):
         """fp8 engines: set the static activation scales from one bf16 pass over calibration inputs x [B,3,h,w]
         (normalised model inputs, e.g. ops.preprocess of representative frames).  Required before the first forward."""
-        _need_cuda(x, "calibration inputs")
+        self._mine(x, "calibration inputs")
         x = x.to(torch.float32).contiguous()
         if x.dim() == 3:
             x = x.unsqueeze(0)
         if tuple(x.shape[1:]) != (3, self.h, self.w):
             raise ValueError(f"engine was built for [B,3,{self.h},{self.w}], got {tuple(x.shape)}")
-        check(self.lib.d2s_engine_calibrate(self._h, _ptr(x), x.shape[0], _stream()), "d2s_engine_calibrate")
+        with _on(self.device) as st:
+            check(self.lib.d2s_engine_calibrate(self._h, _ptr(x), x.shape[0], st), "d2s_engine_calibrate")
 
     def tap(self, name: str) -> torch.Tensor:
         rows, cols = C.c_int(), C.c_int()
         n = max(self.cfg.hidden * (self.h // 14 * (self.w // 14) + 1), 16 * (self.h // 14) * (self.w // 14) * self.cfg.fusion)
         buf = torch.empty(n, dtype=torch.float32, device=self.device)
-        check(self.lib.d2s_engine_tap(self._h, name.encode(), _ptr(buf), n, C.byref(rows), C.byref(cols), _stream()), "d2s_engine_tap")
+        with _on(self.device) as st:
+            check(self.lib.d2s_engine_tap(self._h, name.encode(), _ptr(buf), n, C.byref(rows), C.byref(cols), st), "d2s_engine_tap")
         return buf[: rows.value * cols.value].view(rows.value, cols.value)
 
     def profile(self, enable: bool):
@@ -327,7 +375,7 @@ class Engine:
     def pipeline(self, frames: torch.Tensor, p: PipelineParams, sp: SbsParams, use_ema: bool = False,
                  out_fmt: int = FMT_U8_HWC, want_depth: bool = False, out: Optional[torch.Tensor] = None):
         """predict_depth + make_sbs for uint8 HWC frames [B,H,W,3] in one stream-ordered call."""
-        _need_cuda(frames, "frames")
+        self._mine(frames, "frames")
         if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
             raise ValueError("frames must be uint8 [B,H,W,3]")
         frames = frames.contiguous()
@@ -340,10 +388,14 @@ class Engine:
                 out = torch.empty((B, oh, ow, 3), dtype=torch.float32, device=frames.device)
             else:
                 out = torch.empty((B, 3, oh, ow), dtype=torch.float32, device=frames.device)
+        else:
+            self._mine(out, "out")
         depth = torch.empty((B, H, W), dtype=torch.float32, device=frames.device) if want_depth else None
         pp = post_params(p)
-        check(self.lib.d2s_pipeline(self._h, _ptr(frames), B, H, W, p.depth_resolution, C.byref(pp), C.byref(sp), int(use_ema),
-                                    _ptr(out), out_fmt, _ptr(depth) if want_depth else None, _stream()), "d2s_pipeline")
+        pre = pre_params(p.mean, p.std, p.resample)
+        with _on(self.device) as st:
+            check(self.lib.d2s_pipeline(self._h, _ptr(frames), B, H, W, p.depth_resolution, C.byref(pre), C.byref(pp), C.byref(sp),
+                                        int(use_ema), _ptr(out), out_fmt, _ptr(depth) if want_depth else None, st), "d2s_pipeline")
         return (out, depth) if want_depth else out
 
     def close(self):
@@ -365,6 +417,6 @@ def gemm_probe(A: torch.Tensor, Wt: torch.Tensor, bias: Optional[torch.Tensor], 
     out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     check(_lib.load().d2s_gemm_probe(_ptr(A.contiguous()), _ptr(Wt.contiguous()), _ptr(bias) if bias is not None else None,
                                      _ptr(out), M, N, K, {"bf16": PREC_BF16, "fp32": PREC_FP32, "fp8": _lib.PREC_FP8}[precision], tile, iters,
-                                     _stream()),
+                                     C.c_void_p(torch.cuda.current_stream(A.device).cuda_stream)),
           "d2s_gemm_probe")
     return out

@@ -88,6 +88,17 @@ typedef struct d2s_post_params {
                                   and takes the order statistics over the valid values only (depth.py:844-847) */
 } d2s_post_params;
 
+/* Pre-processing constants of predict_depth (reference depth.py:676-706, 1794-1799, 1931-1948). */
+#define D2S_RESAMPLE_BILINEAR    0   /* _resize_patch_aligned_t's CPU / DirectML branch (depth.py:700-706): [::stride] decimation,
+                                        then bilinear align_corners=False -- what the reference's CPU path computes (parity default) */
+#define D2S_RESAMPLE_BICUBIC_AA  1   /* its IS_CUDA branch (depth.py:698-699; IS_CUDA is true on a ROCm device): one bicubic +
+                                        antialias F.interpolate from the full frame (ATen _upsample_bicubic2d_aa), no decimation */
+typedef struct d2s_pre_params {
+    float   mean[3];           /* (0.485, 0.456, 0.406); 0.5 for the dpt / zoedepth / depthpro ids (depth.py:1794-1799) */
+    float   std[3];            /* (0.229, 0.224, 0.225) */
+    int32_t resample;          /* D2S_RESAMPLE_* */
+} d2s_pre_params;
+
 /* Stereo parameters of make_sbs_core (reference depth.py:2122-2129). */
 typedef struct d2s_sbs_params {
     double  ipd_uv;            /* 0.064; double because the reference forms ipd_uv*W in Python floats */
@@ -150,13 +161,15 @@ int d2s_process(const uint8_t* bgr, int channels, int H0, int W0, int target_hei
  * by max(1,min(8,H//60)) at margin 2*scale, IN PLACE on one frame in any D2S_FMT_* layout. */
 int d2s_overlay_text(void* rgb, int fmt, int H, int W, const char* text, void* stream);
 
-/* A2-A4: ingest + _resize_patch_aligned_t CPU branch (strided decimation, bilinear
- * align_corners=False) + /255 + (x-mean)/std  (reference depth.py:676-706, 1916-1948).
+/* A2-A4: ingest + _resize_patch_aligned_t + /255 + (x-mean)/std  (reference depth.py:676-706, 1916-1948).
+ * pre->resample picks the branch of _resize_patch_aligned_t: D2S_RESAMPLE_BILINEAR = the CPU branch (strided decimation
+ * by decim_stride = longest // (2*target), then bilinear align_corners=False), D2S_RESAMPLE_BICUBIC_AA = the IS_CUDA
+ * branch (bicubic + antialias from the full frame; decim_stride is ignored).  pre == NULL: ImageNet mean / std, CPU branch.
  * frames: `batch` frames, format D2S_FMT_U8_HWC or D2S_FMT_U8_CHW or D2S_FMT_F32_CHW (0..255),
  * each H x W, contiguous.  out: float [batch,3,h,w] with (h,w) the engine shape. */
 int d2s_preprocess(const void* frames, int fmt, int batch, int H, int W,
                    float* out, int h, int w, int decim_stride,
-                   const float mean[3], const float std[3], void* stream);
+                   const d2s_pre_params* pre, void* stream);
 
 /* A5-A9: model(pixel_values=x).predicted_depth  (reference depth.py:1763-1781 -> HF
  * DepthAnythingForDepthEstimation).  x: float [batch,3,h,w]; depth: float [batch,h,w]. */
@@ -227,7 +240,8 @@ int d2s_jpeg_encode(const void* frames, int fmt, int batch, int H, int W, int qu
  * use_ema: run DepthStabilizer across the batch in frame order using the engine's stream state
  * (d2s_engine_reset_stream clears it). */
 int d2s_pipeline(d2s_engine* e, const uint8_t* frames, int batch, int H, int W,
-                 int depth_resolution, const d2s_post_params* pp, const d2s_sbs_params* sp,
+                 int depth_resolution, const d2s_pre_params* pre /* NULL: ImageNet constants, CPU-branch resize */,
+                 const d2s_post_params* pp, const d2s_sbs_params* sp,
                  int use_ema, void* out, int out_fmt, float* depth_full, void* stream);
 int d2s_engine_reset_stream(d2s_engine* e);
 

@@ -143,14 +143,18 @@ def bicubic_resize(x: np.ndarray, out_h: int, out_w: int, scale_factor=None) -> 
 # ----------------------------------------------------------------------------------------------
 # A2-A4  ingest / resize / normalise
 # ----------------------------------------------------------------------------------------------
-def resize_patch_aligned(img_chw: np.ndarray, target: int, patch: int = 14) -> np.ndarray:
-    """reference depth.py:676-706, CPU branch: strided decimation then bilinear
-    (align_corners=False, no antialias) in float32.  img_chw: [3,H,W] uint8 or float."""
+def resize_patch_aligned(img_chw: np.ndarray, target: int, patch: int = 14, cuda_branch: bool = False) -> np.ndarray:
+    """reference depth.py:676-706.  CPU / DirectML branch (default, :700-706): strided decimation then bilinear
+    (align_corners=False, no antialias) in float32.  cuda_branch=True (:698-699, what the reference runs when
+    IS_CUDA -- which includes ROCm devices): ONE F.interpolate(bicubic, align_corners=False, antialias=True) from the
+    full frame, no decimation, no clamp (the cubic lobes overshoot 0..255).  img_chw: [3,H,W] uint8 or float."""
     _, h, w = img_chw.shape
     new_h, new_w, stride = engine_shape(h, w, target, patch)
     x = np.asarray(img_chw)
     if new_h == h and new_w == w:
         return x.astype(F32)
+    if cuda_branch:
+        return separable_aa_resize(x.astype(F32), new_h, new_w, cubic=True)
     if stride > 1:
         x = x[:, ::stride, ::stride]
     return bilinear_resize(x.astype(F32), new_h, new_w, align_corners=False)
@@ -575,12 +579,14 @@ def to_u8(x: np.ndarray) -> np.ndarray:
 # ----------------------------------------------------------------------------------------------
 # A1 process() / A15 overlay_fps(): the rows either side of the path
 # ----------------------------------------------------------------------------------------------
-def _aa_weights(in_size: int, out_size: int):
-    """ATen _upsample_bilinear2d_aa per-output taps (third-party torch; UpSampleKernel.cpp
-    _compute_indices_min_size_weights_aa with the triangle filter): scale = in/out, support = scale (>= 1),
-    center = scale*(i+0.5), taps [xmin, xmin+xsize), weights normalised to sum 1."""
+def _aa_weights(in_size: int, out_size: int, cubic: bool = False):
+    """ATen _upsample_bilinear2d_aa / _upsample_bicubic2d_aa per-output taps (third-party torch; UpSampleKernel.cpp
+    _compute_indices_min_size_weights_aa): scale = in/out, support = (interp_size/2)*scale when down-scaling
+    (interp_size 2: triangle filter; 4: Keys cubic with a = -0.5, HelperInterpCubic::aa_filter), center = scale*(i+0.5),
+    taps [xmin, xmin+xsize), weights normalised to sum 1.  float32 like ATen's opmath for float tensors."""
     scale = F32(in_size) / F32(out_size)
-    support = scale if scale >= 1 else F32(1)
+    half = F32(2.0 if cubic else 1.0)
+    support = F32(half * scale) if scale >= 1 else half
     invscale = F32(1) / scale if scale >= 1 else F32(1)
     taps = []
     for i in range(out_size):
@@ -588,9 +594,35 @@ def _aa_weights(in_size: int, out_size: int):
         xmin = max(int(float(F32(center - support)) + 0.5), 0)
         xsize = min(int(float(F32(center + support)) + 0.5), in_size) - xmin
         x = np.abs(((np.arange(xsize, dtype=F32) + F32(xmin)) - center + F32(0.5)) * invscale).astype(F32)
-        w = np.where(x < 1, F32(1) - x, F32(0)).astype(F32)
+        if cubic:
+            a = F32(-0.5)
+            w1 = ((a + F32(2)) * x - (a + F32(3))) * x * x + F32(1)                      # |x| < 1
+            w2 = ((a * x - F32(5) * a) * x + F32(8) * a) * x - F32(4) * a                # 1 <= |x| < 2
+            w = np.where(x < 1, w1, np.where(x < 2, w2, F32(0))).astype(F32)
+        else:
+            w = np.where(x < 1, F32(1) - x, F32(0)).astype(F32)
         taps.append((xmin, (w / w.sum(dtype=F32)).astype(F32)))
     return taps
+
+
+def separable_aa_resize(x: np.ndarray, nh: int, nw: int, cubic: bool) -> np.ndarray:
+    """F.interpolate(mode=bilinear|bicubic, align_corners=False, antialias=True) on [C,H,W] float32: ATen's separable
+    kernel, horizontal pass then vertical pass (separable_upsample_generic_Nd_kernel_impl), taps accumulated in order."""
+    C, H0, W0 = x.shape
+    tx, ty = _aa_weights(W0, nw, cubic), _aa_weights(H0, nh, cubic)
+    hpass = np.empty((C, H0, nw), F32)
+    for j, (x0, w) in enumerate(tx):
+        acc = np.zeros((C, H0), F32)
+        for k in range(len(w)):
+            acc += w[k] * x[:, :, x0 + k]
+        hpass[:, :, j] = acc
+    out = np.empty((C, nh, nw), F32)
+    for i, (y0, w) in enumerate(ty):
+        acc = np.zeros((C, nw), F32)
+        for k in range(len(w)):
+            acc += w[k] * hpass[:, y0 + k, :]
+        out[:, i, :] = acc
+    return out
 
 
 def process_frame(img_bgr: np.ndarray, target_height: int) -> np.ndarray:
@@ -603,20 +635,7 @@ def process_frame(img_bgr: np.ndarray, target_height: int) -> np.ndarray:
         return x
     nh = (target_height // 2) * 2
     nw = (int(W0 * target_height / H0) // 2) * 2
-    tx, ty = _aa_weights(W0, nw), _aa_weights(H0, nh)
-    hpass = np.empty((3, H0, nw), F32)
-    for j, (x0, w) in enumerate(tx):
-        acc = np.zeros((3, H0), F32)
-        for k in range(len(w)):
-            acc += w[k] * x[:, :, x0 + k]
-        hpass[:, :, j] = acc
-    out = np.empty((3, nh, nw), F32)
-    for i, (y0, w) in enumerate(ty):
-        acc = np.zeros((3, nw), F32)
-        for k in range(len(w)):
-            acc += w[k] * hpass[:, y0 + k, :]
-        out[:, i, :] = acc
-    return out
+    return separable_aa_resize(x, nh, nw, cubic=False)
 
 
 _FONT = {  # reference depth.py:641-658 (5x3 glyphs)
@@ -652,8 +671,9 @@ class PipelineOracle:
     """predict_depth + make_sbs of the reference, CPU branch, float32 (autocast disabled)."""
 
     def __init__(self, cfg, weights, depth_resolution=518, foreground_scale=0.05, aa_strength=4.0,
-                 ema_alpha=0.9, metric=False, max_depth=0.0):
+                 ema_alpha=0.9, metric=False, max_depth=0.0, cuda_branch=False):
         self.model = DepthAnythingOracle(cfg, weights, max_depth)
+        self.cuda_branch = cuda_branch              # _resize_patch_aligned_t's IS_CUDA branch (bicubic + antialias)
         self.metric = metric
         self.target = depth_resolution
         self.fg = foreground_scale
@@ -662,7 +682,7 @@ class PipelineOracle:
 
     def model_input(self, img_hwc_u8: np.ndarray) -> np.ndarray:
         x = resize_patch_aligned(np.ascontiguousarray(img_hwc_u8.transpose(2, 0, 1)), self.target,
-                                 self.model.cfg.patch)
+                                 self.model.cfg.patch, self.cuda_branch)
         return normalise(x)
 
     def predict_depth(self, img_hwc_u8: np.ndarray, use_temporal_smooth=False, taps=None) -> np.ndarray:

@@ -38,14 +38,19 @@ def _versions():
             "numpy": np.__version__, "reference_pins": "transformers==4.56.2, torch 2.7.1"}
 
 
-def gen_model(model: str, res: int, frames, store_inputs: bool, full_taps: bool, out: str, fp32=True, metric=""):
-    """predict_depth taps for one (model, depth_resolution)."""
+def gen_model(model: str, res: int, frames, store_inputs: bool, full_taps: bool, out: str, fp32=True, metric="",
+              cuda_branch=False):
+    """predict_depth taps for one (model, depth_resolution).  cuda_branch: run _resize_patch_aligned_t's IS_CUDA branch
+    (bicubic + antialias, reference depth.py:698-699 -- what the reference does on a CUDA *or ROCm* device; the flag is
+    read at call time) instead of the CPU branch this container would take."""
     import torch
     from ref_harness import load_reference
     from desktop2stereo_amd import synth
     D = load_reference(model, res, seed=0, fp32=fp32, metric=metric)
+    if cuda_branch:
+        D.IS_CUDA = True
     data = {}
-    meta = {"model": model, "depth_resolution": res, "weights_seed": 0, "fp32": fp32, "metric": metric,
+    meta = {"model": model, "depth_resolution": res, "weights_seed": 0, "fp32": fp32, "metric": metric, "cuda_branch": cuda_branch,
             "max_depth": {"": 0.0, "Indoor": 20.0, "Outdoor": 80.0}[metric],
             "frames": [], "versions": _versions()}
     if metric:
@@ -78,6 +83,8 @@ def gen_model(model: str, res: int, frames, store_inputs: bool, full_taps: bool,
         pre = f"f{fi}_"
         if store_inputs:
             data[pre + "img"] = img
+        if cuda_branch:
+            data[pre + "resized_rows"] = xr[0, :, ::14].numpy()          # every 14th row of the resized (un-normalised) frame
         if full_taps:
             data[pre + "model_input"] = xn[0].numpy()
             with torch.no_grad():
@@ -88,8 +95,9 @@ def gen_model(model: str, res: int, frames, store_inputs: bool, full_taps: bool,
             data[pre + "norm"] = nrm.numpy()
             data[pre + "gamma"] = D.apply_gamma(nrm).numpy()
             data[pre + "fg"] = D.apply_foreground_scale(D.apply_gamma(nrm), D.FOREGROUND_SCALE).numpy()
-        data[pre + "raw_depth"] = raw[0].float().numpy()
-        data[pre + "post_depth"] = post.float().numpy()
+        if not (cuda_branch and fi > 0):                                  # (cuda_branch: depth for the first frame only)
+            data[pre + "raw_depth"] = raw[0].float().numpy()
+            data[pre + "post_depth"] = post.float().numpy()
         # end-to-end predict_depth with the EMA chain running across frames (depth.py:1983-1984)
         d_ema = D.predict_depth(img, use_temporal_smooth=True).float().numpy()
         if full_taps or h * w <= 200 * 400:
@@ -103,26 +111,26 @@ def gen_model(model: str, res: int, frames, store_inputs: bool, full_taps: bool,
     print("wrote", out, {k: v.shape for k, v in data.items()})
 
 
-def gen_warp(out: str):
+def gen_warp(out: str, shapes=None, big=("hd",), s1_cases=(0, 1)):
     """make_sbs / make_sbs_core outputs with a GIVEN depth (isolates A14)."""
     import torch
     from ref_harness import load_reference
     from desktop2stereo_amd import synth
     D = load_reference("tiny", 84, seed=0, fp32=True)
     data, meta = {}, {"cases": [], "versions": _versions()}
-    shapes = [("small169", 72, 128, 1), ("small43", 96, 128, 1), ("wide", 60, 160, 1),
-              ("odd", 75, 133, 1), ("hd", 1080, 1920, 135)]             # row stride of stored outputs
+    shapes = shapes or [("small169", 72, 128, 1), ("small43", 96, 128, 1), ("wide", 60, 160, 1),
+                        ("odd", 75, 133, 1), ("hd", 1080, 1920, 135)]   # row stride of stored outputs
     for name, h, w, rs in shapes:
         for kind in ("S2", "S1"):
-            if name != "hd" and kind == "S1":
+            if name not in big and kind == "S1":
                 continue
             img = synth.structured_frame(h, w, 7) if kind == "S2" else synth.noise_frame(h, w, 7)
             dep = synth.smooth_depth(h, w, 7)
-            if name != "hd":
+            if name not in big:
                 data[f"{name}_{kind}_img"] = img
                 data[f"{name}_{kind}_depth"] = dep
             for ci, (mode, fill, conv, ratio) in enumerate(WARP_CASES):
-                if name == "hd" and kind == "S1" and ci > 1:
+                if name in big and kind == "S1" and ci not in s1_cases:
                     continue
                 sbs = D.make_sbs(img, torch.from_numpy(dep), ipd_uv=0.064, depth_ratio=ratio,
                                  convergence=conv, fill_16_9=fill, display_mode=mode)
@@ -200,7 +208,13 @@ JOBS = {
     "tiny_r84_metric": lambda o: gen_model("tiny", 84, [("S2", 90, 160, 0), ("S2", 90, 160, 1), ("S1", 90, 160, 2)],
                                            True, True, o, metric="Indoor"),
     "vits_r518_metric": lambda o: gen_model("vits", 518, [("S2", 1080, 1920, 0)], False, False, o, metric="Outdoor"),
+    # the IS_CUDA pre-processing branch (bicubic + antialias from the full frame): 1080p, 4K, 1440p, 720p and an odd size
+    "vits_r518_cuda": lambda o: gen_model("vits", 518, [("S2", 1080, 1920, 0), ("S1", 2160, 3840, 1), ("S2", 1440, 2560, 2),
+                                                        ("S1", 720, 1280, 3), ("S2", 611, 1003, 4)], False, False, o, cuda_branch=True),
     "warp": gen_warp,
+    # BASELINE config 3's frame: 3840x2160, all four packings incl. Full-TAB 4320x3840 / Half-TAB (every 270th row stored;
+    # noise frame: Full-TAB and Half-TAB only)
+    "warp_uhd": lambda o: gen_warp(o, shapes=[("uhd", 2160, 3840, 270)], big=("uhd",), s1_cases=(2, 3)),
     "ingest": gen_ingest,
 }
 

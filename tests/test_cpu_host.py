@@ -36,6 +36,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_lib.ModelDesc) == 4 * (3 + 4 + 4 + 5) + 4 + 4 + 4 + 4  # ... ln_eps, precision, temporal, max_depth
     assert C.sizeof(_lib.PostParams) == 28 and _lib.PostParams.metric.offset == 24
     assert C.sizeof(_lib.SbsParams) == 24 and _lib.SbsParams.ipd_uv.offset == 0 and _lib.SbsParams.depth_ratio.offset == 8
+    assert C.sizeof(_lib.PreParams) == 28 and _lib.PreParams.std.offset == 12 and _lib.PreParams.resample.offset == 24
 
 
 def test_sbs_shape_matches_reference_padding(lib):
@@ -99,3 +100,30 @@ def test_weight_generator_matches_hf_layout():
     w1, w2 = make_weights(MODELS["tiny"], 0), make_weights(MODELS["tiny"], 0)
     assert all(np.array_equal(w1[k], w2[k]) for k in w1)
     assert not np.array_equal(make_weights(MODELS["tiny"], 1)["head.conv1.weight"], w1["head.conv1.weight"])
+
+
+def test_load_safetensors_from_hf_checkpoint(tmp_path):
+    """weights.load_safetensors on a file written by HF save_pretrained(safe_serialization=True) -- the format the
+    reference's convert.py:14-24 produces and depth.py:1649-1662 loads -- returns exactly the model's tensors."""
+    torch = pytest.importorskip("torch")
+    pytest.importorskip("transformers")
+    from transformers import DepthAnythingConfig, DepthAnythingForDepthEstimation
+    from desktop2stereo_amd.config import MODELS
+    from desktop2stereo_amd.weights import expected_shapes, load_safetensors
+    cfg = MODELS["tiny"]
+    hf = DepthAnythingConfig(
+        backbone_config=dict(model_type="dinov2", hidden_size=cfg.hidden, num_attention_heads=cfg.heads,
+                             num_hidden_layers=cfg.layers, image_size=518, patch_size=14, out_indices=list(cfg.out_indices),
+                             apply_layernorm=True, reshape_hidden_states=False),
+        reassemble_hidden_size=cfg.hidden, neck_hidden_sizes=list(cfg.neck), fusion_hidden_size=cfg.fusion,
+        head_hidden_size=cfg.head_hidden)
+    torch.manual_seed(1)
+    m = DepthAnythingForDepthEstimation(hf)
+    m.half().save_pretrained(str(tmp_path), safe_serialization=True)            # fp16 on disk, like the published checkpoints
+    got = load_safetensors(os.path.join(str(tmp_path), "model.safetensors"), cfg)
+    sd = m.state_dict()
+    assert set(got) == set(expected_shapes(cfg))
+    for k, v in got.items():
+        assert v.dtype == np.float32 and np.array_equal(v, sd[k].float().numpy()), k
+    with pytest.raises((KeyError, ValueError)):
+        load_safetensors(os.path.join(str(tmp_path), "model.safetensors"), MODELS["vits"])      # wrong architecture: loud

@@ -55,6 +55,54 @@ def test_preprocess_matches_oracle(dev):
         assert np.abs(got - want).max() <= 2e-5
 
 
+def test_preprocess_cuda_branch(dev, golden_dir):
+    """resample="bicubic_aa": _resize_patch_aligned_t's IS_CUDA branch (reference depth.py:698-699, what the reference runs
+    on a ROCm device) against rows the reference produced with IS_CUDA forced on (tests/golden/vits_r518_cuda: 1080p, 4K
+    without decimation, 1440p, 720p, an odd size), against the oracle on every pixel and input format, then the fp32
+    ViT-S engine behind it against the reference's depth for the 1080p frame, stage by stage and through d2s_pipeline."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import IMAGENET_MEAN, IMAGENET_STD, MODELS, PipelineParams, engine_shape
+    from desktop2stereo_amd.weights import make_weights
+    from oracle import d2s_oracle as O
+    z, meta = _golden(golden_dir, "vits_r518_cuda")
+    res = meta["depth_resolution"]
+    m = np.asarray(IMAGENET_MEAN, np.float32).reshape(3, 1, 1)
+    s = np.asarray(IMAGENET_STD, np.float32).reshape(3, 1, 1)
+    for fi, fr in enumerate(meta["frames"]):
+        gen = synth.structured_frame if fr["kind"] == "S2" else synth.noise_frame
+        img = gen(fr["h"], fr["w"], fr["seed"])
+        got = ops.preprocess(_t(img, dev), res, resample="bicubic_aa").cpu().numpy()[0]
+        want = O.normalise(O.resize_patch_aligned(np.ascontiguousarray(img.transpose(2, 0, 1)), res, cuda_branch=True))
+        assert np.abs(got - want).max() <= 2e-5, (fi, np.abs(got - want).max())            # same op order: round-off only
+        ref_rows = (z[f"f{fi}_resized_rows"] / np.float32(255.0) - m) / s                  # the reference's own rows, normalised
+        assert np.abs(got[:, ::14] - ref_rows).max() <= 2e-5, (fi, np.abs(got[:, ::14] - ref_rows).max())
+        if fi in (0, 4):                                                                   # CHW uint8 / CHW float inputs
+            chw = np.ascontiguousarray(img.transpose(2, 0, 1))
+            for t in (_t(chw, dev), _t(chw.astype(np.float32), dev)):
+                assert np.array_equal(ops.preprocess(t, res, resample="bicubic_aa").cpu().numpy()[0], got)
+    both = np.stack([synth.structured_frame(270, 480, 1), synth.noise_frame(270, 480, 2)])  # batch of two
+    got = ops.preprocess(_t(both, dev), 140, resample="bicubic_aa").cpu().numpy()
+    for b in range(2):
+        want = O.normalise(O.resize_patch_aligned(np.ascontiguousarray(both[b].transpose(2, 0, 1)), 140, cuda_branch=True))
+        assert np.abs(got[b] - want).max() <= 2e-5
+    # the model behind it: reference depth of the 1080p frame under the IS_CUDA pre-process
+    cfg = MODELS["vits"]
+    fr = meta["frames"][0]
+    img = _t(synth.structured_frame(fr["h"], fr["w"], fr["seed"]), dev)
+    h, w, _ = engine_shape(fr["h"], fr["w"], res)
+    p = PipelineParams(depth_resolution=res, resample="bicubic_aa")
+    eng = ops.Engine(cfg, make_weights(cfg, 0), h, w, 1, "fp32")
+    raw = eng(ops.preprocess(img, res, resample="bicubic_aa"))
+    post = ops.post_process_depth(raw, p).cpu().numpy()[0]
+    scale = float(z["f0_raw_depth"].max())
+    assert np.abs(raw.cpu().numpy()[0] - z["f0_raw_depth"]).max() <= 2e-4 * scale
+    assert np.abs(post - z["f0_post_depth"]).max() <= 1e-3
+    sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, "Half-SBS", True)
+    _, dfull = eng.pipeline(img.unsqueeze(0), p, sp, want_depth=True)                       # d2s_pipeline honours pre->resample
+    assert np.abs(dfull.cpu().numpy()[0] - O.upsample_depth(z["f0_post_depth"], fr["h"], fr["w"])).max() <= 1e-3
+    eng.close()
+
+
 def test_process_and_overlay_match_golden(dev, golden_dir):
     """A1 process() vs torch's anti-aliased bilinear called as the reference calls it (<= 2e-4 of 255), A15
     overlay_fps() vs the reference's function (exact), all four frame layouts."""
@@ -179,12 +227,13 @@ def test_ema_and_upsample(dev, golden_dir):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("generic", [False, True])
-def test_warp_matches_golden(dev, golden_dir, generic, monkeypatch):
-    """All display modes x fill_16_9 x convergence x aspect ratios, against the reference's outputs."""
+@pytest.mark.parametrize("generic,fixture", [(False, "warp"), (True, "warp"), (False, "warp_uhd")])
+def test_warp_matches_golden(dev, golden_dir, generic, fixture, monkeypatch):
+    """All display modes x fill_16_9 x convergence x aspect ratios, against the reference's outputs; warp_uhd =
+    BASELINE config 3's 3840x2160 frame in all four packings (Full-TAB 4320x3840, Half-TAB 2160x3840)."""
     from desktop2stereo_amd import ops, synth, _lib
     from oracle import d2s_oracle as O
-    z, meta = _golden(golden_dir, "warp")
+    z, meta = _golden(golden_dir, fixture)
     cache = {}
     for c in meta["cases"]:
         k = (c["shape"], c["kind"])
@@ -198,7 +247,7 @@ def test_warp_matches_golden(dev, golden_dir, generic, monkeypatch):
         out = ops.make_sbs(img, dep, sp, _lib.FMT_F32_HWC).cpu().numpy()
         assert list(out.shape) == c["out_shape"], c["key"]
         got = out[::c["row_stride"]]
-        tol = 0.08 if c["kind"] == "S1" else 0.03          # reference's own fp32 coordinate noise
+        tol = (0.08 if c["kind"] == "S1" else 0.03) * max(1.0, c["w"] / 1920.0)   # reference's own fp32 coordinate noise (grows with W)
         assert np.abs(got - ref).max() <= tol, (c["key"], np.abs(got - ref).max())
         # uint8 output (fast path unless generic): <= 1 LSB from the rounded reference
         if generic:

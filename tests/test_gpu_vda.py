@@ -64,6 +64,33 @@ def test_vda_longer_than_window_vs_oracle(dev):
     eng.close()
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 3e-4), ("bf16", 0.05)])
+def test_vda_window_wrap_vs_reference(dev, golden_dir, prec, tol):
+    """40 frames of the REFERENCE's own streaming VideoDepthAnything (tests/golden/vda_tiny_long, make_golden_vda.py):
+    frames 32..39 run after the 32-frame window has wrapped, so the in-place ring (oldest slot overwritten, projected
+    k' | v' rows) is held to the reference's update_cache shift order (vda2_s.py:177-187), not to the restatement."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS
+    from desktop2stereo_amd.vda_weights import make_vda_weights
+    from oracle import d2s_oracle as O
+    cfg = MODELS["tiny"]
+    z = np.load(os.path.join(golden_dir, "vda_tiny_long.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "vda_tiny_long.json")))
+    assert len(meta["frames"]) >= 34
+    eng = ops.Engine(cfg, make_vda_weights(cfg, 0), 42, 84, 1, prec, temporal=True)
+    worst = 0.0
+    for fi, fr in enumerate(meta["frames"]):
+        frame = synth.structured_frame(fr["h"], fr["w"], fr["seed"])
+        x = O.normalise(O.resize_patch_aligned(np.ascontiguousarray(frame.transpose(2, 0, 1)), meta["depth_resolution"]))
+        d = eng(_t(x, dev)).cpu().numpy()[0]
+        ref = z[f"f{fi}_depth"]
+        err = np.abs(d - ref).max() / max(1.0, float(ref.max()))
+        worst = max(worst, err)
+        assert err <= tol, (prec, fi, err)
+    print(f"[vda window wrap, {prec}] worst frame error {worst:.2e} of the range over {len(meta['frames'])} frames")
+    eng.close()
+
+
 def test_vda_vits_stream(dev, golden_dir):
     """ViT-S VDA at 196x336 (BASELINE config 4 shape), 3 frames, reference goldens."""
     path = os.path.join(golden_dir, "vda_vits.npz")

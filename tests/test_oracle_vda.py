@@ -33,3 +33,21 @@ def test_vda_tiny_stream(golden_dir):
         for a in range(2):
             assert np.abs(m.cache[a] - z[f"cache{ci}"]).max() <= 5e-5, ci
             ci += 1
+
+
+def test_vda_tiny_window_wrap(golden_dir):
+    """40 frames from the reference (> the 32-frame window): update_cache's shift order (vda2_s.py:177-187) as the
+    reference executes it pins the oracle's eviction order beyond frame 32."""
+    from desktop2stereo_amd import synth
+    from oracle import d2s_oracle as O
+    cfg = MODELS["tiny"]
+    z = np.load(os.path.join(golden_dir, "vda_tiny_long.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "vda_tiny_long.json")))
+    assert len(meta["frames"]) >= 34
+    orc = VideoDepthOracle(cfg, make_vda_weights(cfg, 0))
+    for fi, fr in enumerate(meta["frames"]):
+        frame = synth.structured_frame(fr["h"], fr["w"], fr["seed"])
+        x = O.normalise(O.resize_patch_aligned(np.ascontiguousarray(frame.transpose(2, 0, 1)), meta["depth_resolution"]))
+        d = orc.forward(x)
+        ref = z[f"f{fi}_depth"]
+        assert np.abs(d - ref).max() <= 5e-5 * max(1.0, float(ref.max())), (fi, np.abs(d - ref).max(), ref.max())
