@@ -1,84 +1,113 @@
 #!/usr/bin/env python
 """Throughput bench of the hot path: stereo frames/s, 1080p, Depth-Anything-v2 ViT-B, Full-SBS.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One step = one pass of predict_depth + make_sbs (d2s_pipeline) over one batch of synthetic uint8
-frames already resident in HBM.  Workload = BASELINE.json configs[1]: DA-v2 ViT-B bf16,
-1920x1080, batch 1, Full-SBS, Depth Resolution 518 (model input 294x518), seeded synthetic weights.
-Frames shard across ranks with no data-path collective (weak scaling: per-GPU work fixed).
+N > 1 with WORLD_SIZE unset: bench.py re-launches itself as N ranks (one per GPU) under torch.distributed.run on
+127.0.0.1; launched BY torch.distributed.run (the driver's way) it reads RANK / LOCAL_RANK / WORLD_SIZE from the env.
+
+One step = one pass of predict_depth + make_sbs (d2s_pipeline) over one batch of synthetic uint8 frames already
+resident in HBM.  Workload = BASELINE.json configs[1]: DA-v2 ViT-B bf16, 1920x1080, batch 1, Full-SBS, Depth
+Resolution 518 (model input 294x518), seeded synthetic weights.  Frames shard across ranks with no data-path
+collective (weak scaling: per-GPU work fixed).
 
 Rank 0 prints ONE JSON line: the contract fields plus
   roofline      -- the dominant kernel class, timed live with HIP events on the launch stream
                    (d2s_engine_profile) in a second pass over the same workload;
   kernels       -- the same numbers for every kernel class;
   roofline_warp -- the stereo-warp kernel against the HBM roofline;
+  ingest_rank0  -- the other deployment SURVEY.md section 8(e) asks to report: rank 0 holds all frames, scatters uint8
+                   frames / gathers packed stereo frames point-to-point over RCCL (shard.scatter_frames / gather_outputs);
+  rccl_ranks    -- the number of ranks an actual all-reduce counted;
   batched       -- (N=1 only) the same pipeline at --also-batch frames per step (throughput regime:
                    M = batch*778 tokens fills the chip), with its own roofline;
+  parity_class  -- (N=1 only) the same step on the fp32 engine, the one that meets north_star's 1e-3 depth tolerance;
   cpu_baseline  -- the numpy oracle (a port of the reference's CPU path) on a bounded sample,
-                   rank 0 at N=1 only.
+                   rank 0 at N=1 only: all host threads, and one thread (the reference ships torch.set_num_threads(1),
+                   depth.py:19).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp8": 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+# dense MFMA peaks, MI355X_MICROARCH.md.  "fp8": the engine's e4m3 linears run v_mfma_f32_16x16x32_fp8_fp8, the NON-scaled
+# form, which issues at the bf16 rate (guide: "non-scaled fp8 = BF16 rate") -- so it is priced against 2.5 PF, not the 5 PF
+# of the MX-scaled K=128 instruction it does not use.
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp8": 2500.0}
 PEAK_HBM_GBS = 8000.0                          # HBM3E spec
 SURVEY_GF_PER_FRAME = {("vitb", 518): 176.9, ("vits", 518): 45.8, ("vitl", 518): 635.9,
                        ("vitb", 336): 76.5, ("vits", 336): 19.8, ("vitl", 336): 275.2}
 
 
-def cpu_baseline(cfg, weights, p, H, W, mode, budget_s=15.0, max_frames=3):
-    """The oracle (numpy port of the reference CPU path) timed on this host's cores."""
+def cpu_baseline(cfg, weights, p, H, W, mode, budget_s=10.0, max_frames=3):
+    """The oracle (numpy port of the reference CPU path) timed on this host's cores: all threads, then one thread."""
     from desktop2stereo_amd import synth
     from oracle import d2s_oracle as O
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
     except Exception:
+        threadpool_limits = None
         threads = os.cpu_count() or 1
     orc = O.PipelineOracle(cfg, weights, p.depth_resolution, p.foreground_scale, p.aa_strength)
-    n, t_total = 0, 0.0
-    while n < max_frames and t_total < budget_s:
-        frame = synth.noise_frame(H, W, 100 + n)
-        t0 = time.perf_counter()
-        d = orc.predict_depth(frame)
-        orc.make_sbs(frame, d, ipd_uv=p.ipd, depth_ratio=p.depth_strength, convergence=p.convergence,
-                     display_mode=mode, fill_16_9=p.fill_16_9)
-        t_total += time.perf_counter() - t0
-        n += 1
-    return {"value": n / t_total, "unit": "stereo frames/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n} frame(s) {W}x{H} {cfg.name} fp32 numpy oracle, {mode}, {t_total:.1f} s of CPU work",
-            "host_cpus": os.cpu_count()}
+
+    def run(limit, budget, frames):
+        import contextlib
+        ctx = threadpool_limits(limits=limit) if (threadpool_limits and limit) else contextlib.nullcontext()
+        n, t_total = 0, 0.0
+        with ctx:
+            while n < frames and t_total < budget:
+                frame = synth.noise_frame(H, W, 100 + n)
+                t0 = time.perf_counter()
+                d = orc.predict_depth(frame)
+                orc.make_sbs(frame, d, ipd_uv=p.ipd, depth_ratio=p.depth_strength, convergence=p.convergence,
+                             display_mode=mode, fill_16_9=p.fill_16_9)
+                t_total += time.perf_counter() - t0
+                n += 1
+        return n, t_total
+
+    n, t = run(None, budget_s, max_frames)
+    out = {"value": n / t, "unit": "stereo frames/s", "cores": int(threads), "kind": "port",
+           "sample": f"{n} frame(s) {W}x{H} {cfg.name} fp32 numpy oracle, {mode}, {t:.1f} s of CPU work",
+           "host_cpus": os.cpu_count(),
+           "note": "kind 'port': the numpy restatement under oracle/ (the Python reference cannot travel to this box). It is a "
+                   "checker, not a tuned CPU implementation: the reference's own torch CPU path measured 1.6 fps (ViT-S, "
+                   "1 thread, bf16 autocast) in the build container (SURVEY.md section 6), several times this port's rate."}
+    if threadpool_limits is not None:
+        n1, t1 = run(1, budget_s, 1)
+        out["one_thread"] = {"value": n1 / t1, "unit": "stereo frames/s", "cores": 1,
+                             "sample": f"{n1} frame(s), {t1:.1f} s of CPU work; the reference ships torch.set_num_threads(1) (depth.py:19)"}
+    return out
 
 
 def pmc_traffic(kernel_class, B, default_workload):
-    """HBM-side bytes per launch from the committed PMC profile (FETCH_SIZE / WRITE_SIZE are collected in separate
-    rocprofv3 --pmc passes, profiles/r1_07_gemm_pmc.md -- they cannot be read inside this process); only for the
-    workload the profile was taken on (ViT-B bf16, Depth Resolution 518, batch 1 / 16), else None."""
-    if not default_workload or kernel_class != "gemm_linear":
+    """HBM-side bytes per launch from the committed PMC profile: FETCH_SIZE / WRITE_SIZE are collected in separate
+    rocprofv3 --pmc passes of tools/pmc_run.sh and reduced by tools/pmc_traffic.py (FETCH_SIZE doubled per the guide's gfx950
+    correction, WRITE_SIZE scaled by the calibration copy) -- they cannot be read inside this process; only for the
+    workload the profile was taken on (ViT-B bf16, Depth Resolution 518), else None."""
+    if not default_workload:
         return None
     try:
         with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["gemm_linear_traffic_bytes_per_launch"].get(str(B))
+            return json.load(f)["traffic_bytes_per_launch"][kernel_class].get(str(B))
     except (OSError, KeyError, ValueError):
         return None
 
 
-def profile_pass(eng, step, steps, B, precision, default_workload=False):
+def profile_pass(eng, step, steps, B, precision, sync, default_workload=False):
     """Second pass with HIP events around every kernel launch -> per-class table + roofline objects."""
-    import torch
     eng.profile(True)
     for i in range(steps):
         step(i)
-    torch.cuda.synchronize()
+    sync()
     prof = eng.profile_read()
     eng.profile(False)
     nf = steps * B
@@ -96,7 +125,8 @@ def profile_pass(eng, step, steps, B, precision, default_workload=False):
             k["gbs"] = r["bytes"] / (r["ms"] * 1e-3) / 1e9
             k["frac_of_hbm_peak"] = k["gbs"] / PEAK_HBM_GBS
         kernels[name] = k
-    out = {"kernels": kernels, "gpu_busy_ms_per_step": sum(k["ms_per_step"] for k in kernels.values())}
+    out = {"kernels": kernels, "gpu_busy_ms_per_step": sum(k["ms_per_step"] for k in kernels.values()),
+           "launches_per_step": sum(k["launches_per_step"] for k in kernels.values())}
     dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
     kd = kernels[dom]
     if "tflops" in kd:
@@ -105,17 +135,17 @@ def profile_pass(eng, step, steps, B, precision, default_workload=False):
                            "flop_per_launch": 1e9 * kd["gflop_per_frame"] * B / kd["launches_per_step"], "avg_launch_us": kd["avg_launch_us"]}
     else:
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kd.get("gbs"), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": kd.get("frac_of_hbm_peak"), "traffic": None, "avg_launch_us": kd["avg_launch_us"]}
+                           "frac": kd.get("frac_of_hbm_peak"), "traffic": pmc_traffic(dom, B, default_workload), "avg_launch_us": kd["avg_launch_us"]}
     if "stereo_warp" in kernels:
         kw = kernels["stereo_warp"]
         out["roofline_warp"] = {"kernel": "stereo_warp", "bound": "hbm", "achieved": kw["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": kw["frac_of_hbm_peak"], "traffic": None, "bytes_per_launch": 1e6 * kw["mb_per_frame"] * B,
-                                "avg_launch_us": kw["avg_launch_us"]}
+                                "frac": kw["frac_of_hbm_peak"], "traffic": pmc_traffic("stereo_warp", B, default_workload),
+                                "bytes_per_launch": 1e6 * kw["mb_per_frame"] * B, "avg_launch_us": kw["avg_launch_us"]}
     out["model_gflop_per_frame_counted"] = sum(k.get("gflop_per_frame", 0.0) for k in kernels.values())
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -129,122 +159,210 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--mode", default="Full-SBS")
+    ap.add_argument("--resample", default="bilinear", choices=["bilinear", "bicubic_aa"],
+                    help="pre-process branch of _resize_patch_aligned_t: the reference's CPU path (default) or its IS_CUDA branch")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--vda", action="store_true",
-                    help="streaming Video-Depth-Anything (BASELINE config 4): one stream per GPU, batch 1, 32-frame window")
+                    help="streaming Video-Depth-Anything (BASELINE config 4): one stream per GPU (shard.stream_owner), batch 1, 32-frame window")
     ap.add_argument("--mixed", type=int, default=0,
                     help="extra measurement (N=1): BASELINE config 5, this many frames per step drawn with seed 0 from "
                          "{1280x720, 1920x1080, 2560x1440} -- one batched model pass, per-size pre-process and warp")
+    ap.add_argument("--ingest", default="both", choices=["own", "rank0", "both"],
+                    help="own: every rank generates its frames (headline value, no data-path collective); rank0: rank 0 holds all "
+                         "frames, RCCL point-to-point scatter / gather each step; both: headline = own, rank0 reported beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-class", action="store_true")
     ap.add_argument("--sink-quality", type=int, default=90, help="also time the step with the MJPEG sink behind it (0 = off)")
     ap.add_argument("--no-profile", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def respawn_as_ranks(n: int):
+    """`python bench.py --gpus N` from a plain shell: become N ranks under torch.distributed.run (one process per GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    os.execvpe(cmd[0], cmd, env)
+
+
+def rank_body(args, engine_factory=None, device=None):
+    """What every rank runs.  engine_factory / device are injected only by the gloo rehearsal test (tests/test_shard_gloo.py:
+    a stand-in engine on CPU tensors exercises the rank logic -- sharding, scatter / gather, barriers, the max-over-ranks
+    clock, rank counting -- without a GPU); bench.py itself never passes them: the product path is the HIP engine or nothing."""
     import numpy as np
     import torch
     import torch.distributed as dist
-    from desktop2stereo_amd import _lib, ops, synth
+    from desktop2stereo_amd import shard, synth
     from desktop2stereo_amd.config import MODELS, PipelineParams, engine_shape
-    from desktop2stereo_amd.weights import make_weights
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm device (the HIP path has no fallback)")
-    _lib.load()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         f"or run `python bench.py --gpus {args.gpus}` without WORLD_SIZE set and let it spawn the ranks")
     # D2S_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
     backend = os.environ.get("D2S_DIST_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    fake = engine_factory is not None
+    if not fake:
+        from desktop2stereo_amd import _lib, ops
+        from desktop2stereo_amd.weights import make_weights
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm device (the HIP path has no fallback)")
+        _lib.load()
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" and ndev < world:
+            raise SystemExit(f"--gpus {world} but only {ndev} device(s) visible: one rank per GPU over RCCL needs {world}")
+        if backend != "nccl":
+            local_rank %= ndev
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
+    else:
+        dev = device or torch.device("cpu")
+        sync = lambda: None
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    rccl_ranks = 1
+    if world > 1:                                        # count the ranks with a real collective (RCCL when backend == nccl)
+        one = torch.ones(1, dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
+        if rccl_ranks != world:
+            raise SystemExit(f"all-reduce counted {rccl_ranks} ranks, expected {world}")
 
     cfg = MODELS[args.model]
     H, W, B = args.height, args.width, args.batch
     B2 = args.also_batch if (world == 1 and args.also_batch > B) else 0
-    p = PipelineParams(depth_resolution=args.res, display_mode=args.mode)
+    p = PipelineParams(depth_resolution=args.res, display_mode=args.mode, resample=args.resample)
     h, w, _ = engine_shape(H, W, args.res)
-    if args.vda:
-        from desktop2stereo_amd.vda_weights import make_vda_weights
-        if B != 1:
-            raise SystemExit("--vda is one stream per GPU: --batch must be 1")
-        B2 = 0
-        weights = make_vda_weights(cfg, 0)
-    else:
-        weights = make_weights(cfg, 0)
     NM = args.mixed if (world == 1 and not args.vda) else 0
-    eng = ops.Engine(cfg, weights, h, w, max_batch=max(B, B2, NM), precision=args.precision, device=local_rank, temporal=args.vda)
-    default_wl = (args.model, args.precision, args.res, H, W, args.vda) == ("vitb", "bf16", 518, 1080, 1920, False)
-    if args.precision == "fp8":     # static activation scales from two structured frames (outside the timed region)
-        eng.calibrate(torch.cat([ops.preprocess(torch.from_numpy(synth.structured_frame(H, W, s)).to(dev), args.res) for s in (0, 1)][:max(B, B2)]))
-    sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, args.mode, p.fill_16_9)
-    oh, ow = ops.sbs_shape(H, W, sp)
+    if args.vda and B != 1:
+        raise SystemExit("--vda is one stream per GPU: --batch must be 1")
+    if args.vda:
+        B2 = 0
+    if fake:
+        weights = None
+        eng = engine_factory(max(B, B2, NM))
+        sbs_params_, sbs_shape_ = eng.sbs_params, eng.sbs_shape
+    else:
+        if args.vda:
+            from desktop2stereo_amd.vda_weights import make_vda_weights
+            weights = make_vda_weights(cfg, 0)
+        else:
+            weights = make_weights(cfg, 0)
+        eng = ops.Engine(cfg, weights, h, w, max_batch=max(B, B2, NM), precision=args.precision, device=local_rank, temporal=args.vda)
+        sbs_params_, sbs_shape_ = ops.sbs_params, ops.sbs_shape
+    default_wl = (args.model, args.precision, args.res, H, W, args.vda, args.resample) == ("vitb", "bf16", 518, 1080, 1920, False, "bilinear")
+    if args.precision == "fp8" and not fake:     # static activation scales from two structured frames (outside the timed region)
+        eng.calibrate(torch.cat([ops.preprocess(torch.from_numpy(synth.structured_frame(H, W, s)).to(dev), args.res, resample=args.resample)
+                                 for s in (0, 1)][:max(B, B2)]))
+    sp = sbs_params_(p.ipd, p.depth_strength, p.convergence, args.mode, p.fill_16_9)
+    oh, ow = sbs_shape_(H, W, sp)
+    # config 4: stateful streams never split -- stream s lives on rank shard.stream_owner(s, world); with `world` streams that
+    # is one stream per rank, and this rank serves the stream(s) it owns
+    my_streams = [s for s in range(world) if shard.stream_owner(s, world) == rank] if args.vda else []
+    if args.vda and my_streams != [rank]:
+        raise SystemExit(f"stream_owner put streams {my_streams} on rank {rank}")
 
-    def make_step(nb):
+    def frames_for(seed0, nb):
+        return torch.from_numpy(np.stack([synth.noise_frame(H, W, seed0 + i) for i in range(nb)]))
+
+    def make_step(nb, engine=None):
+        engine = engine or eng
         # a small pool of distinct batches, resident in HBM before the timed region
-        pool = [torch.from_numpy(np.stack([synth.noise_frame(H, W, 1000 * rank + 100 * j + i) for i in range(nb)])).to(dev)
-                for j in range(4 if nb <= 4 else 2)]
+        pool = [frames_for(1000 * rank + 100 * j, nb).to(dev) for j in range(4 if nb <= 4 else 2)]
         out = torch.empty((nb, oh, ow, 3), dtype=torch.uint8, device=dev)
-        return lambda i: eng.pipeline(pool[i % len(pool)], p, sp, use_ema=False, out=out)
+        return lambda i: engine.pipeline(pool[i % len(pool)], p, sp, use_ema=False, out=out)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def timed(step, warmup, steps):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
         for i in range(warmup):
             step(i)
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
             step(i)
-        torch.cuda.synchronize()
+        sync()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-            dist.barrier()
+            barrier()
         return dt
 
-    step = make_step(B)
-    dt = timed(step, args.warmup, args.steps)
-    value = args.steps * B * world / dt
-
-    def workload(nb):
-        return (f"DepthAnything-v2-{cfg.name} {args.precision}, {W}x{H} uint8 RGB noise frames, batch {nb} per GPU, "
+    def workload(nb, prec=None):
+        return (f"DepthAnything-v2-{cfg.name} {prec or args.precision}, {W}x{H} uint8 RGB noise frames, batch {nb} per GPU, "
                 f"Depth Resolution {args.res} (model input {h}x{w}), {args.mode} uint8 output {ow}x{oh}, "
-                f"predict_depth + make_sbs fused (d2s_pipeline), EMA off, seeded synthetic weights")
+                f"predict_depth + make_sbs fused (d2s_pipeline), EMA off, seeded synthetic weights"
+                + (", IS_CUDA-branch pre-process (bicubic + antialias)" if args.resample == "bicubic_aa" else ""))
 
-    result = {
-        "metric": "stereo frames/sec @1080p DepthAnything-v2-ViT-B", "value": value, "unit": "stereo frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": workload(B), "frames_per_step_per_gpu": B,
-                   "parallelism": f"frame-sharded dp{world}, no data-path collective"},
-    }
+    result = {"metric": "stereo frames/sec @1080p DepthAnything-v2-ViT-B", "unit": "stereo frames/s", "n_gpus": world,
+              "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": args.precision, "data": "synthetic", "rccl_ranks": rccl_ranks,
+              "config": {"workload": workload(B), "frames_per_step_per_gpu": B,
+                         "parallelism": f"frame-sharded dp{world}, no data-path collective (each rank generates its own frames)"}}
+    step = None
+    if args.ingest in ("own", "both"):
+        step = make_step(B)
+        dt = timed(step, args.warmup, args.steps)
+        result["value"] = args.steps * B * world / dt
+        result["ms_per_step"] = 1e3 * dt / args.steps
+
+    if args.ingest in ("rank0", "both") and not args.vda:
+        # SURVEY.md section 8(e), the other deployment: frames arrive on rank 0 (the capture host's GPU); every step rank 0
+        # scatters uint8 frames point-to-point (RCCL send/recv over xGMI; xGMI has no switch, a root-centric scatter is
+        # bounded by the root's egress), every rank runs the pipeline on its block, packed stereo frames are gathered back.
+        n_total = B * world
+        pool0 = [frames_for(5000 + 100 * j, n_total).to(dev) for j in range(2)] if rank == 0 else [None, None]
+        out_r = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=dev)
+
+        def ingest_step(i):
+            mine = shard.scatter_frames(pool0[i & 1], n_total, (H, W, 3), dev) if world > 1 else pool0[i & 1]
+            eng.pipeline(mine, p, sp, use_ema=False, out=out_r)
+            return shard.gather_outputs(out_r, n_total) if world > 1 else out_r
+
+        steps_i = args.steps if args.ingest == "rank0" else max(5, args.steps // 4)
+        dti = timed(ingest_step, max(2, args.warmup // 4), steps_i)
+        ing = {"value": steps_i * n_total / dti, "unit": "stereo frames/s", "steps": steps_i, "ms_per_step": 1e3 * dti / steps_i,
+               "frames_per_step": n_total,
+               "exchange": (f"per step: {world - 1} x isend of {B * H * W * 3 / 1e6:.1f} MB uint8 frames from rank 0, {world - 1} x irecv of "
+                            f"{B * oh * ow * 3 / 1e6:.1f} MB packed frames to rank 0 ({backend})") if world > 1 else "single rank: no exchange"}
+        if args.ingest == "rank0":
+            result["value"], result["ms_per_step"] = ing["value"], ing["ms_per_step"]
+            result["config"]["parallelism"] = f"frame-sharded dp{world}, rank-0 ingest: point-to-point scatter / gather per step ({backend})"
+        result["ingest_rank0"] = ing
+    if step is None:
+        step = make_step(B)
+
     if args.model != "vitb" or (H, W) != (1080, 1920):
         result["metric"] = f"stereo frames/sec @{W}x{H} DepthAnything-v2-{cfg.name}"
     if args.vda:
         result["metric"] = f"stereo frames/sec @{W}x{H} VideoDepthAnything-{cfg.name} (streaming, window 32)"
         result["config"]["workload"] = result["config"]["workload"].replace("DepthAnything-v2", "VideoDepthAnything(stream, window 32)")
+        result["config"]["parallelism"] = f"{world} independent stream(s), stream s on rank s % {world} (shard.stream_owner); replicas only"
         args.no_cpu_baseline = True                      # the CPU leg times the DA-v2 oracle only
+        args.no_parity_class = True
 
     if rank == 0 and not args.no_profile:
-        result.update(profile_pass(eng, step, args.profile_steps, B, args.precision, default_wl))
+        result.update(profile_pass(eng, step, args.profile_steps, B, args.precision, sync, default_wl))
         result["model_gflop_per_frame"] = {"counted": result.pop("model_gflop_per_frame_counted"),
                                            "survey": SURVEY_GF_PER_FRAME.get((args.model, args.res))}
-        result["model_stage_tflops_at_measured_fps"] = value / world * result["model_gflop_per_frame"]["counted"] / 1e3
+        result["model_stage_tflops_at_measured_fps"] = result["value"] / world * result["model_gflop_per_frame"]["counted"] / 1e3
 
     if B2:
         step2 = make_step(B2)
@@ -253,7 +371,7 @@ def main():
         batched = {"value": steps2 * B2 / dt2, "unit": "stereo frames/s", "frames_per_step": B2, "steps": steps2,
                    "ms_per_step": 1e3 * dt2 / steps2, "workload": workload(B2)}
         if not args.no_profile:
-            pr = profile_pass(eng, step2, 3, B2, args.precision, default_wl)
+            pr = profile_pass(eng, step2, 3, B2, args.precision, sync, default_wl)
             pr.pop("model_gflop_per_frame_counted", None)
             batched.update(pr)
         result["batched"] = batched
@@ -271,7 +389,7 @@ def main():
 
         def step_mixed(i):
             for s, f in frames.items():
-                xm[groups[s]] = ops.preprocess(f, args.res)
+                xm[groups[s]] = ops.preprocess(f, args.res, resample=args.resample)
             depth = ops.post_process_depth(eng(xm), p)
             for s, f in frames.items():
                 outs[s].copy_(ops.make_sbs(f, depth[groups[s]], sp))
@@ -282,7 +400,22 @@ def main():
                            "workload": f"{NM} frames/step, sizes seed 0: " + ", ".join(f"{len(groups[s])}x{s[1]}x{s[0]}" for s in sizes)
                                        + f"; one {cfg.name} {args.precision} batch at {h}x{w}; {args.mode}"}
 
-    if rank == 0 and world == 1 and args.sink_quality > 0:
+    if rank == 0 and world == 1 and not fake and args.precision != "fp32" and not args.no_parity_class:
+        # the engine that meets north_star's 1e-3 depth tolerance against the reference's fp32 CPU path (tests/test_gpu_configs.py):
+        # same step on v_mfma_f32_16x16x4_f32 with fp32 activations.  Reported beside the headline, never as it.
+        eng32 = ops.Engine(cfg, weights, h, w, max_batch=B, precision="fp32", device=local_rank)
+        step32 = make_step(B, eng32)
+        st32 = max(10, args.steps // 10)
+        dt32 = timed(step32, 3, st32)
+        result["parity_class"] = {"value": st32 * B / dt32, "unit": "stereo frames/s", "dtype": "fp32", "steps": st32,
+                                  "ms_per_step": 1e3 * dt32 / st32, "workload": workload(B, "fp32"),
+                                  "gate": "post-processed depth <= 1e-3 of the reference's fp32 CPU path (config 2 frame); the headline "
+                                          "bf16 engine: max 0.015 / mean 0.0024 (the reference's own bf16 CPU autocast: 0.036 / 0.0029)",
+                                  "frac_of_f32_mfma_peak": (st32 * B / dt32) * result.get("model_gflop_per_frame", {}).get("counted", 0.0) / 1e3 / PEAK_TFLOPS["fp32"]
+                                  if "model_gflop_per_frame" in result else None}
+        eng32.close()
+
+    if rank == 0 and world == 1 and not fake and args.sink_quality > 0:
         # the Streamer modes' sink (cv2.imencode -> here the HIP JPEG encoder) behind the same step,
         # frame never leaving HBM.  Reported beside the headline number, not in it (the metric ends at make_sbs).
         q = args.sink_quality
@@ -336,15 +469,24 @@ def main():
         except ImportError:
             pass
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not fake and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, weights, p, H, W, args.mode)
-        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
 
-    if rank == 0:
-        print(json.dumps(result))
     eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return result if rank == 0 else None
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_as_ranks(args.gpus)                      # does not return
+    result = rank_body(args)
+    if result is not None:
+        print(json.dumps(result))
 
 
 if __name__ == "__main__":

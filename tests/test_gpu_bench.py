@@ -1,0 +1,51 @@
+"""GPU: bench.py as the driver runs it -- the JSON contract at N=1, and `--gpus 2` spawning two ranks by itself
+(gloo rehearsal: a one-GPU box cannot host two RCCL ranks, so the ranks share device 0 and the collectives go over gloo;
+on an 8-GPU node the same code path runs with backend nccl = RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=900):
+    env = dict(os.environ, **(env_extra or {}))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_contract_n1():
+    res = _run(["--steps", "6", "--warmup", "2", "--profile-steps", "2", "--also-batch", "2", "--model", "vits", "--no-cpu-baseline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "roofline_warp", "parity_class", "batched", "ingest_rank0", "rccl_ranks"):
+        assert k in res, k
+    assert res["n_gpus"] == 1 and res["steps"] == 6 and res["dtype"] == "bf16" and res["vs_baseline"] is None
+    assert abs(res["value"] - 1e3 / res["ms_per_step"]) < 1e-6 * res["value"]
+    rf = res["roofline"]
+    assert rf["bound"] in ("mfma", "hbm") and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert res["parity_class"]["dtype"] == "fp32" and 0 < res["parity_class"]["value"] < res["value"]
+
+
+def test_bench_spawns_its_own_ranks():
+    res = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--model", "vits", "--no-profile", "--no-cpu-baseline"],
+               {"D2S_DIST_BACKEND": "gloo"})
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2
+    assert res["ingest_rank0"]["frames_per_step"] == 2 and res["ingest_rank0"]["value"] > 0
+    assert abs(res["value"] - 2 * 1e3 / res["ms_per_step"]) < 1e-6 * res["value"]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=REPO,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "D2S_DIST_BACKEND")})
+    assert r.returncode != 0 and "visible" in (r.stderr + r.stdout)

@@ -62,3 +62,77 @@ def test_scatter_gather_world2(n_frames):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+# ---- bench.py's rank body under gloo, world_size 2 -------------------------------------------------------------------
+class _StandInEngine:
+    """CPU stand-in for ops.Engine, injected into bench.rank_body by this test only: a deterministic per-frame map with the
+    engine's call shape (uint8 [B,H,W,3] -> Full-SBS uint8 [B,H,2W,3]), so the RANK logic of bench.py -- WORLD_SIZE handling,
+    rank counting by all-reduce, own-frames and rank-0-ingest modes (scatter -> step -> gather), barriers, the max-over-ranks
+    clock, one JSON object from rank 0 -- runs without a GPU.  It computes nothing of the product."""
+
+    def __init__(self, max_batch):
+        self.max_batch = max_batch
+        self.calls = 0
+
+    @staticmethod
+    def sbs_params(ipd, ratio, conv, mode, fill):
+        assert mode == "Full-SBS"
+        return mode
+
+    @staticmethod
+    def sbs_shape(H, W, sp):
+        return H, 2 * W
+
+    def pipeline(self, frames, p, sp, use_ema=False, out=None):
+        assert frames.dtype == torch.uint8 and frames.shape[0] <= self.max_batch
+        self.calls += 1
+        out.copy_(torch.cat([frames, 255 - frames], dim=2))
+        return out
+
+    def close(self):
+        pass
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      D2S_DIST_BACKEND="gloo")
+    import bench
+    args = bench.parse_args(["--gpus", str(world), "--steps", "6", "--warmup", "2", "--batch", "3", "--height", "6", "--width", "8",
+                             "--no-profile", "--no-cpu-baseline", "--sink-quality", "0", "--also-batch", "0"])
+    res = bench.rank_body(args, engine_factory=_StandInEngine, device=torch.device("cpu"))
+    if rank == 0:
+        q.put(res)
+    else:
+        assert res is None
+
+
+def test_bench_rank_body_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["scaling"] == "weak"
+    assert res["steps"] == 6 and res["warmup"] == 2 and res["value"] > 0
+    assert abs(res["value"] - 6 * 3 * 2 / (res["ms_per_step"] * 6e-3)) < 1e-6 * res["value"]       # whole-job frames / max-rank time
+    ing = res["ingest_rank0"]
+    assert ing["frames_per_step"] == 6 and ing["value"] > 0 and "isend" in ing["exchange"]
+    json_line = __import__("json").dumps(res)
+    assert "\n" not in json_line
+
+
+def test_bench_refuses_mismatched_world(monkeypatch):
+    """--gpus N must mean N ranks: with WORLD_SIZE set to something else bench.py stops instead of reporting N."""
+    sys.path.insert(0, REPO)
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    args = bench.parse_args(["--gpus", "4"])
+    with pytest.raises(SystemExit):
+        bench.rank_body(args, engine_factory=_StandInEngine, device=torch.device("cpu"))
