@@ -1,0 +1,160 @@
+// Device-side helpers shared by the MFMA GEMM kernels (gemm.hip, gemm_pp.hip): fragment types, packed converts,
+// the fused epilogue (bias / GELU / LayerScale / residuals / row re-mapping / QKV split / e4m3 de-quantisation) and the
+// XCD-aware block -> tile map.
+#pragma once
+#include "gemm.h"
+#include <type_traits>
+
+namespace d2s {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers (HIP's u32x4 struct arrays went to scratch)
+
+template <typename T> struct Prec;
+template <> struct Prec<bf16_t> { static constexpr int CE = 8; };   // elements per 16-byte chunk
+template <> struct Prec<float>  { static constexpr int CE = 4; };
+template <> struct Prec<fp8_t>  { static constexpr int CE = 16; };  // e4m3: a 128-byte K tile holds 128 elements
+
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& w, const u32x4& a, bf16_t) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w, *(const bf16x8*)&a, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& w, const u32x4& a, float) {
+    const float* wf = (const float*)&w;
+    const float* af = (const float*)&a;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], af[t], acc, 0, 0, 0);
+}
+
+// e4m3 operands: a 16-byte chunk is 16 K elements = two v_mfma_f32_16x16x32_fp8_fp8 (8 bytes per lane each; the k
+// permutation is again the same for both operands).  Same MFMA count per byte as bf16, twice the K per byte moved.
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& w, const u32x4& a, fp8_t) {
+    const long* wl = (const long*)&w;
+    const long* al = (const long*)&a;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[0], al[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[1], al[1], acc, 0, 0, 0);
+}
+
+// exact-erf GELU (HF Dinov2MLP: nn.GELU()).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e. at
+// float32 round-off for this use) -- one rcp + one exp + 6 fma instead of the ~40-instruction libm erff,
+// which was ~25 % of the FC1 launch at batch 1.
+__device__ __forceinline__ float gelu_erf(float x) {
+    float z = fabsf(x) * 0.70710678118654752f;
+    float t = __frcp_rn(1.0f + 0.3275911f * z);
+    float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    float erf_abs = 1.0f - poly * __expf(-z * z);
+    float erf_x = x < 0.f ? -erf_abs : erf_abs;
+    return 0.5f * x * (1.0f + erf_x);
+}
+
+__device__ __forceinline__ void load4(const float* p, float v[4]) { float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+__device__ __forceinline__ void load4(const bf16_t* p, float v[4]) {
+    uint2 t = *(const uint2*)p;
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ void store4(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+// two floats -> packed bf16 pair (round-to-nearest-even) in one v_cvt_pk_bf16_f32
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
+    uint2 t;
+    t.x = pk_bf16(v[0], v[1]);
+    t.y = pk_bf16(v[2], v[3]);
+    *(uint2*)p = t;
+}
+
+// four floats -> four e4m3 bytes (v_cvt_pk_fp8_f32, round-to-nearest-even), saturating at +-448
+__device__ __forceinline__ uint32_t pk_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -FP8_MAX), FP8_MAX); b = fminf(fmaxf(b, -FP8_MAX), FP8_MAX);
+    c = fminf(fmaxf(c, -FP8_MAX), FP8_MAX); d = fminf(fmaxf(d, -FP8_MAX), FP8_MAX);
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+}
+__device__ __forceinline__ void load4(const fp8_t* p, float v[4]) {
+    uint32_t t = *(const uint32_t*)p;
+    v[0] = e4m32f((fp8_t)(t & 255u)); v[1] = e4m32f((fp8_t)((t >> 8) & 255u));
+    v[2] = e4m32f((fp8_t)((t >> 16) & 255u)); v[3] = e4m32f((fp8_t)(t >> 24));
+}
+__device__ __forceinline__ void store4(fp8_t* p, const float v[4]) { *(uint32_t*)p = pk_fp8x4(v[0], v[1], v[2], v[3]); }
+
+template <typename OT> __device__ __forceinline__ OT cvt_out(float v);
+template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float v) { return f2bf(v); }
+template <> __device__ __forceinline__ fp8_t cvt_out<fp8_t>(float v) { return (fp8_t)(pk_fp8x4(v, 0.f, 0.f, 0.f) & 255u); }
+
+// skip_deq: the caller (LN-folded consumer on e4m3 operands) already turned the accumulators into real units
+template <typename OT>
+__device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float v[4], bool skip_deq = false) {
+    if (e.deq && !skip_deq) { float q[4]; load4(e.deq + n0, q); v[0] *= q[0]; v[1] *= q[1]; v[2] *= q[2]; v[3] *= q[3]; }   // fp8 operands -> real units
+    if (e.bias) { float b[4]; load4(e.bias + n0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+    if (e.act == ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+    else if (e.act == ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    if (e.scale) { float s[4]; load4(e.scale + n0, s); v[0] *= s[0]; v[1] *= s[1]; v[2] *= s[2]; v[3] *= s[3]; }
+    long off;
+    if (e.map == MAP_QKV && n0 >= e.qk_cols) {
+        int b = m / e.ntok, t = m - b * e.ntok;
+        int c = n0 - e.qk_cols;                       // h*64 + d, 4 consecutive d
+        OT* p = (OT*)e.vt + ((long)b * e.heads * 64 + c) * e.npad + t;
+        p[0] = cvt_out<OT>(v[0]); p[e.npad] = cvt_out<OT>(v[1]); p[2L * e.npad] = cvt_out<OT>(v[2]); p[3L * e.npad] = cvt_out<OT>(v[3]);
+        return;
+    }
+    if (e.map == MAP_SHUFFLE) {
+        int x = m % e.gw, y = (m / e.gw) % e.gh, b = m / (e.gw * e.gh);
+        int tap = n0 / e.cout, co = n0 - tap * e.cout;
+        int ky = tap / e.ks, kx = tap - ky * e.ks;
+        off = (((long)b * e.gh * e.ks + (long)y * e.ks + ky) * ((long)e.gw * e.ks) + (long)x * e.ks + kx) * e.cout + co;
+    } else {
+        long row = m;
+        if (e.rows_per_img) row = (long)(m / e.rows_per_img) * e.img_rows + (m % e.rows_per_img) + e.row_off;
+        off = row * e.ldc + n0;
+    }
+    if (e.res1) {
+        long roff = e.res1_mod ? ((long)(m % e.res1_mod) + e.res1_off) * e.ldc + n0 : off;
+        float r[4]; load4((const OT*)e.res1 + roff, r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+    }
+    if (e.res2) { float r[4]; load4((const OT*)e.res2 + off, r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+    if constexpr (std::is_same<OT, fp8_t>::value) { v[0] *= e.out_qscale; v[1] *= e.out_qscale; v[2] *= e.out_qscale; v[3] *= e.out_qscale; }
+    store4((OT*)e.out + off, v);
+    if constexpr (std::is_same<OT, float>::value) {            // raw residual copy for the LN-folded consumer: bf16, or e4m3 * scale
+        if (e.out2) {
+            if (e.out2_qscale > 0.f) {
+                float q[4] = {v[0] * e.out2_qscale, v[1] * e.out2_qscale, v[2] * e.out2_qscale, v[3] * e.out2_qscale};
+                store4((fp8_t*)e.out2 + off, q);
+            } else store4((bf16_t*)e.out2 + off, v);
+        }
+    }
+}
+
+// out_type -> element type of the output / residuals
+template <typename T>
+__device__ __forceinline__ void epilogue_dispatch(const GemmEpi& e, int m, int n0, float v[4], bool skip_deq = false) {
+    if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v, skip_deq);
+    else if (e.out_type == OUT_BF16) epilogue4<bf16_t>(e, m, n0, v, skip_deq);
+    else epilogue4<T>(e, m, n0, v, skip_deq);
+}
+
+// XCD-aware block -> tile map.  Workgroup b is dispatched to XCD b % 8 (observed, used for speed
+// only), each XCD has a private 4 MiB L2.  The 8 XCDs form an xn x (8/xn) grid over the tile space;
+// XCD (xi, xj) owns a rectangle of tiles and walks it m-slow / n-fast, so the blocks resident on one
+// XCD share a few W tiles (L2 hits) and each A tile is fetched from far memory once per XCD.
+// xn == 0: plain row-major order.  Returns false for surplus blocks of the padded grid.
+__device__ __forceinline__ bool tile_of_block(int bid, int tiles_m, int tiles_n, int xn, int& tm, int& tn) {
+    if (xn == 0) { tm = bid / tiles_n; tn = bid - tm * tiles_n; return true; }
+    const int xm = 8 / xn;
+    const int x = bid & 7, seq = bid >> 3;
+    const int xi = x % xn, xj = x / xn;
+    const int n0 = (tiles_n * xi) / xn, n1 = (tiles_n * (xi + 1)) / xn;
+    const int m0 = (tiles_m * xj) / xm, m1 = (tiles_m * (xj + 1)) / xm;
+    const int nl = n1 - n0, ml = m1 - m0;
+    if (seq >= nl * ml) return false;
+    const int q = seq / nl;
+    tm = m0 + q; tn = n0 + (seq - q * nl);
+    return true;
+}
+
+}  // namespace d2s

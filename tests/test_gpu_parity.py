@@ -447,7 +447,9 @@ def test_full_size_predict_depth(dev, golden_dir, name, model, res):
     post = ops.post_process_depth(raw, p).cpu().numpy()[0]
     d = np.abs(post - ref_post)
     print(f"[{name}] bf16 engine post-depth vs fp32 reference: max {d.max():.4f} mean {d.mean():.5f}")
-    assert d.max() <= 0.06 and d.mean() <= 0.006, (d.max(), d.mean())
+    # measured on MI355X over the five fixtures (round 2): max 0.0157-0.0249, mean 0.0023-0.0033; bound = 1.5 x the worst
+    # (the reference's own bf16 CPU autocast sits max 0.036 / mean 0.0029 from its fp32 self, tests/golden/vits_r518_bf16)
+    assert d.max() <= 0.0375 and d.mean() <= 0.005, (d.max(), d.mean())
     eng.close()
 
 
