@@ -151,7 +151,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU (configs[1]: 1)")
-    ap.add_argument("--also-batch", type=int, default=16, help="extra batched measurement at N=1 (0 = off)")
+    ap.add_argument("--also-batch", type=int, default=32, help="extra batched measurement at N=1 (0 = off)")
     ap.add_argument("--model", default="vitb")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
                     help="fp8 = BASELINE config 3 (e4m3 encoder linears; try --model vitl --height 2160 --width 3840 --mode Full-TAB)")

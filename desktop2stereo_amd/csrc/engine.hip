@@ -439,8 +439,10 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     // e4m3 operands and de-quantise in their epilogue (deq[n] = s_act * s_w[n]); QKV still emits bf16 for the attention
     const bool f8 = e->fp8 && !e->calib;
     // measured (ViT-B @294x518): folding wins 7 % at 1 frame, 3-5 % at 2-4, 2 % at 8, is even at 16 and loses 1 % at 32
-    // (the LN kernels' launch floor is amortised there and the wider epilogues are not) -> folded up to 16 frames
-    static const int lnf_maxb = getenv("D2S_LNF_MAXB") ? atoi(getenv("D2S_LNF_MAXB")) : 16;      // tuning aid
+    // (the LN kernels' launch floor is amortised there and the wider epilogues are not); from ~9 frames the encoder linears
+    // switch to the 256 x 256 ping-pong kernel (gemm_pp.hip: +12 % frames/s at 16, +13 % at 32), which takes plain
+    // LayerNorm-ed operands -> folded up to 8 frames
+    static const int lnf_maxb = getenv("D2S_LNF_MAXB") ? atoi(getenv("D2S_LNF_MAXB")) : 8;       // tuning aid
     static const bool no_lnf = getenv("D2S_NO_LNFUSE") && atoi(getenv("D2S_NO_LNFUSE")) != 0;
     const bool lnf = ((e->lnf && !e->fp8) || (f8 && !no_lnf)) && !e->calib && prec == D2S_PREC_BF16 && B <= lnf_maxb;
     int ln_slots = 0;

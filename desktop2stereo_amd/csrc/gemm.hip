@@ -53,11 +53,6 @@ __device__ __forceinline__ u32x4 relu_frag(u32x4 v, int floor_bits, float) {
     return __builtin_bit_cast(u32x4, x);
 }
 
-template <int I, int N, typename F> __device__ __forceinline__ void static_for_impl(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_impl<I + 1, N>(f); }
-}
-template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
-
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // chunk XOR for a row of CPR chunks: conflict-free ds_read_b128 for 128-byte (CPR 8) and 256-byte (CPR 16) rows
@@ -466,25 +461,6 @@ conv3_halo_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpa
     });
 }
 
-// pick the XCD grid (xn x 8/xn) for a tiles_m x tiles_n tile space: least padding, W chunk within L2
-static int pick_xn(int tiles_m, int tiles_n, int BN, int Kpad, size_t es, unsigned& grid) {
-    static const int force = getenv("D2S_GEMM_XN") ? atoi(getenv("D2S_GEMM_XN")) : -1;
-    long total = (long)tiles_m * tiles_n;
-    if (force == 0 || total < 16) { grid = (unsigned)total; return 0; }
-    int best = 0; double best_score = 1e30; long best_grid = total;
-    for (int xn = 1; xn <= 8; xn *= 2) {
-        if (force > 0 && xn != force) continue;
-        int xm = 8 / xn;
-        long g = 8L * cdiv(tiles_n, xn) * cdiv(tiles_m, xm);
-        double score = (double)(g - total) / (double)total;
-        double wbytes = (double)cdiv(tiles_n, xn) * BN * Kpad * es;
-        if (wbytes > 2.5e6) score += 0.5 * (wbytes / 2.5e6);
-        if (score < best_score) { best_score = score; best = xn; best_grid = g; }
-    }
-    grid = (unsigned)best_grid;
-    return best;
-}
-
 // tile codes: 64 (64x64), 128 (128x128), 256128 / 256256 (8 waves), 25664 / 25632 (256 x 64|32, 4 waves); 0 = auto
 template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR = 8, int STG = 0>
 static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
@@ -540,6 +516,15 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     static const int force_tile = getenv("D2S_GEMM_TILE") ? atoi(getenv("D2S_GEMM_TILE")) : 0;
     if (tile == 0) tile = force_tile;
     if (tile == 0 && launch_conv_halo<T>(a, W, M, N, K, Kpad, e, st)) { D2S_CHECK_LAUNCH(); return D2S_OK; }
+    if constexpr (!std::is_same<T, float>::value) {
+        // batched plain linears: the 256 x 256 ping-pong kernel (gemm_pp.hip) once the launch has enough tiles to fill the chip
+        // measured (tools/pp_check.py, ViT-B shapes): from ~140 tiles of 256 x 256 the ping-pong kernel wins every encoder
+        // linear (batch 16: +14..+30 %, batch 32: +9..+48 %); at 75 tiles (batch 8, N = 768) it loses.  D2S_GEMM_PP=0: off
+        static const int pp_min_tiles = getenv("D2S_GEMM_PP") ? atoi(getenv("D2S_GEMM_PP")) : 140;
+        const int prec = std::is_same<T, bf16_t>::value ? D2S_PREC_BF16 : D2S_PREC_FP8_OPERANDS;
+        if (tile == 0 && pp_min_tiles > 0 && (long)cdiv(M, 256) * cdiv(N, 256) >= pp_min_tiles && pp_supported(prec, a, M, N, K, Kpad, e))
+            return launch_gemm_pp(prec, a, W, M, N, K, Kpad, e, 1, st);
+    }
     if (tile == 0) {
         // Measured on the ViT-B shapes at batch 1..32 (tools/gemm_bench.py, profiles/r1_05): what matters most is 16-24
         // resident waves per CU in DIFFERENT phases of the K loop (8-wave blocks, 2-5 blocks per CU), then tile intensity;
@@ -582,6 +567,8 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
 
 int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad,
                 const GemmEpi& e, hipStream_t st) {
+    if (tile == 256256 || (tile >= 2562562 && tile <= 2562568))         // ping-pong kernel, optional K split (last digit)
+        return launch_gemm_pp(precision, a, W, M, N, K, Kpad, e, tile == 256256 ? 1 : tile % 10, st);
     const int ce = 16 / (int)elem_size(precision);
     if (M <= 0 || N <= 0 || K <= 0 || (N & 3) || (K % ce) || Kpad % (2 * gemm_bk(precision))) {
         set_error("launch_gemm: bad dims (N % 4, K % chunk, Kpad % BK)"); return D2S_E_INVALID;

@@ -157,4 +157,45 @@ __device__ __forceinline__ bool tile_of_block(int bid, int tiles_m, int tiles_n,
     return true;
 }
 
+template <int I, int N, typename F> __device__ __forceinline__ void static_for_impl(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_impl<I + 1, N>(f); }
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
+
+
+// K-split partial of the in-place residual update  x += scale (.) (A W^T + bias):  linear in the accumulator, so every split
+// adds its share straight into the fp32 residual with global_atomic_add_f32 (no partial slabs, no fence, no second pass);
+// the split that holds K tile 0 carries the bias.  fp32 addition order across splits is not fixed: the result is
+// reproducible to round-off, not bit-for-bit (the deterministic path is ksplit = 1).
+__device__ __forceinline__ void epilogue_atomic(const GemmEpi& e, int m, int n0, float v[4], bool first) {
+    if (e.deq) { float q[4]; load4(e.deq + n0, q); v[0] *= q[0]; v[1] *= q[1]; v[2] *= q[2]; v[3] *= q[3]; }
+    if (first && e.bias) { float b[4]; load4(e.bias + n0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+    if (e.scale) { float s[4]; load4(e.scale + n0, s); v[0] *= s[0]; v[1] *= s[1]; v[2] *= s[2]; v[3] *= s[3]; }
+    float* p = (float*)e.out + (long)m * e.ldc + n0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) unsafeAtomicAdd(p + c, v[c]);
+}
+
+}  // namespace d2s
+
+namespace d2s {
+// pick the XCD grid (xn x 8/xn) for a tiles_m x tiles_n tile space: least padding, W chunk within L2
+static inline int pick_xn(int tiles_m, int tiles_n, int BN, int Kpad, size_t es, unsigned& grid) {
+    static const int force = getenv("D2S_GEMM_XN") ? atoi(getenv("D2S_GEMM_XN")) : -1;
+    long total = (long)tiles_m * tiles_n;
+    if (force == 0 || total < 16) { grid = (unsigned)total; return 0; }
+    int best = 0; double best_score = 1e30; long best_grid = total;
+    for (int xn = 1; xn <= 8; xn *= 2) {
+        if (force > 0 && xn != force) continue;
+        int xm = 8 / xn;
+        long g = 8L * cdiv(tiles_n, xn) * cdiv(tiles_m, xm);
+        double score = (double)(g - total) / (double)total;
+        double wbytes = (double)cdiv(tiles_n, xn) * BN * Kpad * es;
+        if (wbytes > 2.5e6) score += 0.5 * (wbytes / 2.5e6);
+        if (score < best_score) { best_score = score; best = xn; best_grid = g; }
+    }
+    grid = (unsigned)best_grid;
+    return best;
+}
+
 }  // namespace d2s

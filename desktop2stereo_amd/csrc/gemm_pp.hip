@@ -1,0 +1,467 @@
+// Ping-pong MFMA GEMM for the batched encoder linears (gfx950):  C[m,n] = epi(sum_k A[m,k] W[n,k]),  256 x 256 block tile,
+// one persistent 8-wave block per CU.
+//
+// Why a second kernel.  gemm_glds_kernel's 128 x 128 tiles pull (128 + 128) x 128 B through L2 -> LDS per 2.1 MFLOP; at the
+// ~14.6 TB/s this chip's LDS-DMA path sustains that caps the batched linears near 950 TFLOP/s and they reach 600-880
+// (profiles/r1_07).  A 256 x 256 tile halves the fill bytes per flop, but one 8- or 16-wave block per CU in lock-step
+// (every wave loading, then every wave computing) lost to the smaller tiles (r1_05).  Here the eight waves of the block are
+// two groups of four -- one wave of each group per SIMD -- that run the SAME instruction stream one barrier apart:
+//
+//     group 0:  MEM(p)   | MFMA(p)  | MEM(p+1) | MFMA(p+1) | ...
+//     group 1:  (wait)   | MEM(p)   | MFMA(p)  | MEM(p+1)  | ...          ( | = s_barrier )
+//
+// so at any moment each SIMD has one wave in a matrix segment (8 x v_mfma_f32_32x32x16, s_setprio 1) and its partner in a
+// memory segment (ds_read_b128 fragment reads + LDS-DMA issue for a later K tile): the matrix pipe and the LDS / vector-memory
+// pipes overlap by construction instead of by luck.
+//
+// Tile geometry (bf16; e4m3 is the same bytes with two MFMAs per 16-byte chunk):
+//   block 256 (M) x 256 (N), K tile = 128 bytes per row; 8 waves = 2 (M halves = the two groups) x 4 (N quarters);
+//   wave tile 128 x 64 = 4 x 2 blocks of 32 x 32 -> 128 accumulator VGPRs; a K tile is 4 phases, one 64 x 32 quadrant each:
+//   (m0,n0) (m0,n1) (m1,n1) (m1,n0) -- a quadrant switch replaces only one operand's registers.
+//   LDS: 2 stages x (256 A rows + 256 W rows) x 128 B = 128 KiB, rows XOR-swizzled as in gemm.hip (conflict-free b128 reads
+//   for 32-row fragments too: the 16-lane read groups see XOR values {0,1,6,7,2,3,4,5} / {2,3,4,5,0,1,6,7}), plus eight
+//   wave-private 4 KiB epilogue patches = the CU's 160 KiB.
+// Schedule of tile t (parity p = t & 1), per wave.  I = LDS-DMA issue (one "piece" = 128 rows of one operand = 2 x
+// buffer_load_dwordx4 ... lds per wave), R = fragment reads, C = the 8 MFMAs:
+//     P1:  I W_n1[t+1]   R fw[!p] <- W(n1)[t],     Y <- A(m0)[t].mb1       C (m0,n0): X|Y, fw[p]
+//     P2:  I A_m1[t+1]   R Z      <- A(m1)[t].mb0                            C (m0,n1): X|Y, fw[!p]
+//     P3:  I A_m0[t+2]   R Y      <- A(m1)[t].mb1                            C (m1,n1): Z|Y, fw[!p]
+//     P4:  I W_n0[t+2]   R fw[!p] <- W(n0)[t+1],   X <- A(m0)[t+1].mb0     C (m1,n0): Z|Y, fw[p]
+//   (the two W register sets swap roles every tile: the set that held n1 of tile t is free after P3 and takes n0 of tile t+1;
+//    A lives in three 4-chunk sets: X / Z hold the first 32-row block of the m0 / m1 quadrant, Y the second block of both)
+//   * W fragments and the FIRST block of an A quadrant are read ONE PHASE BEFORE the MFMAs that use them (into registers the
+//     running MFMAs do not touch); the second block is read in its own phase and consumed by the LAST four MFMAs of the
+//     segment (the first four run on the pre-read block: 128 cycles of cover).  LDS latency therefore sits under matrix
+//     work instead of in front of it (first version, all reads in the phase of use: 1.53 us per K tile = 48 % MFMA busy);
+//     a full pre-read of both blocks needs 16 more VGPRs than the 256 there are (spills inside the K loop);
+//   * every piece is requested exactly 4 phases (8 barrier slots, > 2000 cycles) before the segment that reads it, in the
+//     order it is consumed, and overwrites the piece read 4 phases earlier;
+//   * RAW: a piece read in MEM(q) is covered by s_waitcnt vmcnt(6) at the END of MEM(q-1) of every wave (6 = the three
+//     younger pieces may stay in flight) and the barrier(s) both groups pass before MEM(q) (MI355X_MICROARCH.md "Two waves
+//     per SIMD" item 7; cdna_hip_programming.md 8-phase template);  WAR: a piece is overwritten >= 3 phases after its last read.
+// The last two K tiles run the same phases without issuing (waits 4 / 2 / 0).  K tiles per block must be even (fw0 parity).
+// Persistent loop: the block walks its XCD's tile list (pp_rect: the XCDs own rectangles of the tile space, m-slow /
+// n-fast), CU c of the XCD taking tiles c, c + cpx, ...  -- at any moment an XCD's CUs work on cpx consecutive tiles, which
+// share A row panels and W column panels in that XCD's L2.  The next tile's first twelve pieces are issued INSIDE the
+// epilogue of the current one, and the tile starts on a counted vmcnt that lets the epilogue's own stores stay in flight
+// (vmcnt retires in order on gfx9).
+// (Tried and removed, measured on MI355X: (a) stream-K -- equal K-tile ranges per CU, partial tiles exchanged through fp32
+// slabs with agent-scope flags: correct and deterministic, but the slab round trip and the 2-3x wider spread of an XCD's
+// CUs over the tile walk cost more than the rounding of tiles / CUs saves on these shapes (QKV at batch 32: 848 -> 697
+// TFLOP/s; 8192^3 with every tile in one contiguous run per CU: 1417 -> 932); (b) global_atomic_add_f32 for the in-place
+// fp32 residual of proj / FC2: 19 M atomics per launch run at 0.3 TB/s, 296 us instead of 89.)
+// Epilogue: through the wave-private LDS patch so that global memory sees whole 128-byte lines (the MFMA layout leaves a
+// lane with 4 consecutive n of ONE row: 32 rows x 16-32 B per store, measured 1.8 TB/s).
+#include "gemm_epi.h"
+#include <algorithm>
+
+namespace d2s {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int PP_STAGE = 4096;                 // 16-byte chunks per stage: (256 + 256) rows x 8 chunks
+constexpr int PP_WOFF = 2048;                  // W rows start after the 256 A rows
+
+__device__ __forceinline__ void mma32(f32x16& acc, const u32x4& w, const u32x4& a, bf16_t) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w, *(const bf16x8*)&a, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16& acc, const u32x4& w, const u32x4& a, fp8_t) {
+    const long* wl = (const long*)&w;
+    const long* al = (const long*)&a;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(wl[0], al[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(wl[1], al[1], acc, 0, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// column-wise part of the epilogue on 4 consecutive n: de-quantise, bias, activation, LayerScale
+template <int ACT>
+__device__ __forceinline__ void pp_colwise(const GemmEpi& e, int n0, float v[4], bool with_bias) {
+    if (e.deq) { float q[4]; load4(e.deq + n0, q); v[0] *= q[0]; v[1] *= q[1]; v[2] *= q[2]; v[3] *= q[3]; }
+    if (e.bias && with_bias) { float b[4]; load4(e.bias + n0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+    if (ACT == ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+    else if (ACT == ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    if (e.scale) { float s[4]; load4(e.scale + n0, s); v[0] *= s[0]; v[1] *= s[1]; v[2] *= s[2]; v[3] *= s[3]; }
+}
+
+// Epilogue modes.  Every mode issues a FIXED number of vector-memory instructions per wave (rows past M are clamped to row
+// M-1, whose duplicate A rows produced identical values), because the caller counts them in vmcnt.
+enum { PP_EP_BF16 = 0, PP_EP_F32 = 1, PP_EP_VT = 3 };
+// lower bound of the vector-memory instructions every epilogue / slab write issues AFTER its hook (the point where the next
+// segment's LDS-DMA is issued): the bf16 epilogue's 16 stores (the others issue 32 or more)
+constexpr int PP_TAIL = 16;
+
+// One wave's 128 x 64 tile -> global memory.  `hook()` is called exactly once, at the point after which at least PP_TAIL
+// vector-memory instructions follow.
+//   PP_EP_BF16   32 rows x 64 columns per pass (4 passes): ds_write_b64 -> ds_read_b128 -> global_store_dwordx4 (8 rows x 128 B)
+//   PP_EP_F32    32 rows x 32 columns per pass (8 passes): ds_write_b128 -> ds_read_b128 -> (+ residuals) -> store; the
+//                residual loads (the in-place fp32 residual stream of proj / FC2) run two passes ahead of their use
+//   PP_EP_VT     the V third of a QKV launch goes transposed to vt[b, head, d, token]; the MFMA layout already has
+//                consecutive tokens in consecutive lanes, so it is stored directly (2-byte stores, 64 B per 32 lanes)
+// LDS patch rows are 128 bytes = 8 chunks, chunk index XOR (row & 7) on both sides.  Wave-private: no barrier, the LDS ops
+// of one wave execute in order.
+template <int MODE, int ACT, typename HOOK>
+__device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& e, int bm0, int bn0, int M, int grp, int wn,
+                                            int lane, u32x4* stg, HOOK&& hook) {
+#define PP_QUAD(V, I, J, Q4) float V[4] = {acc[I][J][4 * (Q4) + 0], acc[I][J][4 * (Q4) + 1], acc[I][J][4 * (Q4) + 2], acc[I][J][4 * (Q4) + 3]};
+    const int fl = lane & 31, kg = lane >> 5;
+    const int rr = lane >> 3, rc = lane & 7;
+    const int wm0 = bm0 + grp * 128, wn0 = bn0 + wn * 64;
+    hook();
+    if constexpr (MODE == PP_EP_F32) {
+        // residual prefetch ring: pass p = (i, j) reads rows i*32 + r*8 + rr, columns j*32 + rc*4
+        f32x4 res[2][4];
+        const bool has_res = e.res1 != nullptr;
+        auto res_load = [&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            constexpr int i = p >> 1, j = p & 1;
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int m = wm0 + i * 32 + r * 8 + rr; m = m < M ? m : M - 1;
+                    res[p & 1][r] = *(const f32x4*)((const float*)e.res1 + (long)m * e.ldc + wn0 + j * 32 + rc * 4);
+                }
+            }
+        };
+        static_for<2>([&](auto pc) { res_load(pc); });
+        static_for<8>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            constexpr int i = p >> 1, j = p & 1;
+            static_for<4>([&](auto qc) {
+                constexpr int q4 = decltype(qc)::value;
+                const int n0 = wn0 + j * 32 + 8 * q4 + 4 * kg;
+                PP_QUAD(v, i, j, q4)
+                pp_colwise<ACT>(e, n0, v, true);
+                stg[fl * 8 + ((2 * q4 + kg) ^ (fl & 7))] = __builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]});
+            });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r * 8 + rr, n = wn0 + j * 32 + rc * 4;
+                int m = wm0 + i * 32 + row; m = m < M ? m : M - 1;
+                f32x4 x = __builtin_bit_cast(f32x4, stg[row * 8 + (rc ^ (row & 7))]);
+                const long off = (long)m * e.ldc + n;
+                if (has_res) x += res[p & 1][r];
+                if (e.res2) { f32x4 t = *(const f32x4*)((const float*)e.res2 + off); x += t; }
+                *(f32x4*)((float*)e.out + off) = x;
+            }
+            asm volatile("" ::: "memory");                        // (keeps the ring two passes deep: no hoisting of later loads)
+            if constexpr (p + 2 < 8) res_load(std::integral_constant<int, p + 2>{});
+        });
+        return;
+    }
+    static_for<4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (MODE == PP_EP_VT) {
+            int m = wm0 + i * 32 + fl; m = m < M ? m : M - 1;
+            const int b = m / e.ntok, t = m - b * e.ntok;
+            static_for<2>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                static_for<4>([&](auto qc) {
+                    constexpr int q4 = decltype(qc)::value;
+                    const int n0 = wn0 + j * 32 + 8 * q4 + 4 * kg;
+                    PP_QUAD(v, i, j, q4)
+                    pp_colwise<ACT_NONE>(e, n0, v, true);
+                    bf16_t* p = (bf16_t*)e.vt + ((long)b * e.heads * 64 + (n0 - e.qk_cols)) * e.npad + t;
+                    p[0] = f2bf(v[0]); p[e.npad] = f2bf(v[1]); p[2L * e.npad] = f2bf(v[2]); p[3L * e.npad] = f2bf(v[3]);
+                });
+            });
+        } else {
+            static_for<2>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                static_for<4>([&](auto qc) {
+                    constexpr int q4 = decltype(qc)::value;
+                    const int n0 = wn0 + j * 32 + 8 * q4 + 4 * kg;
+                    PP_QUAD(v, i, j, q4)
+                    pp_colwise<ACT>(e, n0, v, true);
+                    uint2 t;
+                    t.x = pk_bf16(v[0], v[1]); t.y = pk_bf16(v[2], v[3]);
+                    ((uint2*)stg)[(fl * 8 + ((j * 4 + q4) ^ (fl & 7))) * 2 + kg] = t;
+                });
+            });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r * 8 + rr, n = wn0 + rc * 8;
+                int m = wm0 + i * 32 + row; m = m < M ? m : M - 1;
+                u32x4 x = stg[row * 8 + (rc ^ (row & 7))];
+                *(u32x4*)((bf16_t*)e.out + (long)m * e.ldc + n) = x;
+            }
+        }
+    });
+#undef PP_QUAD
+}
+
+// Tile order: the 8 XCDs form an xn x (8/xn) grid of rectangles over the tile space (as tile_of_block); XCD x's tiles, in
+// m-slow / n-fast order, are its list.
+// (xn is a power of two, passed as its log2: the scalar unit has no integer divide -- a runtime '/' is ~40 instructions)
+struct PPRect { int m0, ml, n0, nl; };
+__device__ __forceinline__ PPRect pp_rect(int x, int tiles_m, int tiles_n, int lxn) {
+    const int lxm = 3 - lxn, xi = x & ((1 << lxn) - 1), xj = x >> lxn;
+    PPRect r;
+    r.n0 = (tiles_n * xi) >> lxn; r.nl = ((tiles_n * (xi + 1)) >> lxn) - r.n0;
+    r.m0 = (tiles_m * xj) >> lxm; r.ml = ((tiles_m * (xj + 1)) >> lxm) - r.m0;
+    return r;
+}
+// tile j of XCD x's list
+__device__ __forceinline__ void pp_list_tile(int x, int j, int tiles_m, int tiles_n, int xn, int& tm, int& tn) {
+    const PPRect r = pp_rect(x, tiles_m, tiles_n, xn);
+    const int q = j / r.nl;
+    tm = r.m0 + q; tn = r.n0 + (j - q * r.nl);
+}
+enum { PP_K_BF16 = 0, PP_K_GELU = 1, PP_K_QKV = 2, PP_K_F32 = 3 };     // epilogue of a launch (one kernel instance each)
+
+template <typename T, int KIND>
+__global__ void __launch_bounds__(512)
+gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn /* log2 */,
+               int skew_us) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int BK = 128 / ES;                                    // K elements per tile
+    // 128 KiB of stages + 8 wave-private 4 KiB epilogue patches = the CU's 160 KiB: the ONLY __shared__ object (see gemm.hip)
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * PP_STAGE + 8 * 256];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2, wn = wid & 3;
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    const int nkt = K / BK;                                          // K tiles per output tile: even, >= 2
+    const int cpx = gridDim.x >> 3, xcd = blockIdx.x & 7;
+    const PPRect myr = pp_rect(xcd, tiles_m, tiles_n, xn);
+    const int ntl = myr.ml * myr.nl;                                 // tiles of this XCD's list
+    int tl = blockIdx.x >> 3;                                        // this block's position in it
+    if (tl >= ntl) return;
+    // Blocks that walk one tile fewer than the busiest of their XCD start late by about half a tile time: it costs nothing
+    // (they finish before the others anyway) and it takes them out of the store bursts -- a lock-step grid dumps 128 KiB
+    // per CU at the same instant, that drains in ~8 us, and every CU sits on vmcnt behind its own stores meanwhile.
+    if (skew_us > 0 && (ntl - 1 - tl) / cpx < (ntl - 1) / cpx)
+        for (int i = 0; i < skew_us; ++i) __builtin_amdgcn_s_sleep(32);        // ~1 us each (64 x 32 cycles)
+
+    // ---- loader: this wave's two LDS-DMA instructions of each piece.  lane -> (row lr of 8, physical chunk lc)
+    // per-lane byte offsets (K tile 0).  A: [quadrant][instruction] (rows are clamped per lane).  W: ONE register -- row
+    // rw0 + lr of piece (q, j) has swizzle ((rw0 + lr) >> 1) & 7 = (lr >> 1) + 4 j, so the lane part is laneW ^ (64 j) and
+    // everything else ((bn0 + rw0) * Kpad) is wave-uniform and rides in the scalar offset
+    unsigned offA[2][2], laneW;
+    int dstA[2][2], dstW[2][2];                  // wave-uniform LDS chunk index of the instruction's first slot
+    int sofW[2][2];                              // wave-uniform byte offset of W piece (q, j) of the current tile
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = wid * 2 + j;
+            dstA[q][j] = ((i >> 3) * 128 + q * 64 + (i & 7) * 8) * 8;                  // A piece q: rows {0..63 | 64..127} of both M halves
+            dstW[q][j] = PP_WOFF + ((i >> 2) * 64 + q * 32 + (i & 3) * 8) * 8;         // W piece q: rows {0..31 | 32..63} of the four N quarters
+        }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
+    constexpr int kt0 = 0;
+    // per-lane source offsets of a tile: the lane that owns LDS slot (row r, physical chunk lc) fetches chunk lc ^ ((r >> 1) & 7)
+#define PP_SET_TILE(BM0, BN0, LANE)                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                      \
+            const int lr = (LANE) >> 3, lc = (LANE) & 7;                                                                     \
+            const int ra = (dstA[q][j] >> 3) + lr, rw = ((dstW[q][j] - PP_WOFF) >> 3) + lr;                                  \
+            int m_ = (BM0) + ra; m_ = m_ < M ? m_ : M - 1;         /* rows past M duplicate the last row */                  \
+            offA[q][j] = (unsigned)((long)m_ * lda * ES) + (unsigned)((lc ^ ((ra >> 1) & 7)) * 16);                          \
+            sofW[q][j] = ((BN0) + rw - lr) * Kpad * ES;                                                                      \
+            if (q == 0 && j == 0) laneW = (unsigned)(lr * Kpad * ES) + (unsigned)((lc ^ (lr >> 1)) * 16);                    \
+        }
+
+#define PP_ISSUE_A(Q, KT)                                                                                                   \
+    {                                                                                                                        \
+        const int so_ = ((KT) + kt0) * 128;                                                                                  \
+        u32x4* st_ = lds + ((KT) & 1) * PP_STAGE;                                                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(st_ + dstA[Q][0]), 16, offA[Q][0], so_, 0, 0);           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(st_ + dstA[Q][1]), 16, offA[Q][1], so_, 0, 0);           \
+    }
+#define PP_ISSUE_W(Q, KT)                                                                                                   \
+    {                                                                                                                        \
+        const int so_ = ((KT) + kt0) * 128;                                                                                  \
+        u32x4* st_ = lds + ((KT) & 1) * PP_STAGE;                                                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(st_ + dstW[Q][0]), 16, laneW, so_ + sofW[Q][0], 0, 0);     \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(st_ + dstW[Q][1]), 16, laneW ^ 64u, so_ + sofW[Q][1], 0, 0); \
+    }
+    // what the steady state would have issued before (0, P1): tile 0 complete + A_m0 / W_n0 of tile 1, in consumption
+    // order (12 instructions per wave)
+#define PP_PROLOGUE() { PP_ISSUE_A(0, 0) PP_ISSUE_W(0, 0) PP_ISSUE_W(1, 0) PP_ISSUE_A(1, 0) PP_ISSUE_A(0, 1) PP_ISSUE_W(0, 1) }
+
+    // ---- fragment reads: lane -> (row fl of a 32-row block, K half kg); chunk (2 ks + kg) ^ swizzle(row).
+    // The four per-lane A addresses are the only address VGPRs kept across the K loop; a W read uses the same register plus
+    // a wave-uniform delta that is re-materialised (opaque to the compiler) at each use -- four more live VGPRs are what
+    // pushed the loop over 256 registers.
+    const int fl = lane & 31, kg = lane >> 5, sw = (fl >> 1) & 7;
+    const u32x4* rdA[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rdA[ks] = lds + (grp * 128 + fl) * 8 + ((2 * ks + kg) ^ sw);
+    int wdelta = PP_WOFF + (wn * 64 - grp * 128) * 8;            // chunks from this wave's A rows to its W rows
+
+    u32x4 fX[4], fY[4], fZ[4], fw[2][4];          // A: [ks] (see the table on top); W: [set][ks], n0 in set (tile parity), n1 in the other
+    f32x16 acc[4][2];                             // [M quadrant * 2 + mb][N quadrant]
+
+#define PP_READ_A(DST, Q, MB, KT)                                                                                           \
+    {                                                                                                                        \
+        const int o_ = ((KT) & 1) * PP_STAGE + (Q) * 64 * 8 + (MB) * 32 * 8;                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) DST[ks] = rdA[ks][o_];                                              \
+    }
+#define PP_READ_W(DST, Q, KT)                                                                                               \
+    {                                                                                                                        \
+        asm volatile("" : "+s"(wdelta));                                                                                     \
+        const int o_ = wdelta + ((KT) & 1) * PP_STAGE + (Q) * 32 * 8;                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) DST[ks] = rdA[ks][o_];                                              \
+    }
+    // 8 MFMAs of one quadrant: the four of the first 32-row block (pre-read operands) run first
+#define PP_MFMA(QM, QN, FA0, FA1, FW)                                                                                       \
+    {                                                                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) mma32(acc[(QM) * 2 + 0][QN], FW[ks], FA0[ks], T());                 \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) mma32(acc[(QM) * 2 + 1][QN], FW[ks], FA1[ks], T());                 \
+        __builtin_amdgcn_s_setprio(0);                                                                                       \
+    }
+    // one K tile = 4 phases (see the table on top).  P = tile parity (literal).  ISSUE: 2 = steady state, 1 = second-to-last
+    // tile (pieces of the last tile only), 0 = last tile (nothing to issue, nothing to pre-read).  X (first K tile of a
+    // segment that follows an epilogue): that many younger global stores of the epilogue may stay in flight behind the
+    // prologue pieces the first three waits are about.
+#define PP_TILE(KT, ISSUE, P, X)                                                                                            \
+    {                                                                                                                        \
+        if (ISSUE >= 1) PP_ISSUE_W(1, (KT) + 1)                                                                              \
+        PP_READ_W(fw[(P) ^ 1], 1, KT) PP_READ_A(fY, 0, 1, KT)                                                                \
+        if (ISSUE >= 1) pp_wait_vm<6 + (X)>(); else pp_wait_vm<0>();                                                         \
+        pp_barrier();                                                                                                        \
+        PP_MFMA(0, 0, fX, fY, fw[P]) pp_barrier();                                                                           \
+        if (ISSUE >= 1) PP_ISSUE_A(1, (KT) + 1)                                                                              \
+        PP_READ_A(fZ, 1, 0, KT)                                                                                              \
+        if (ISSUE >= 1) pp_wait_vm<6 + (X)>();                                                                               \
+        pp_barrier();                                                                                                        \
+        PP_MFMA(0, 1, fX, fY, fw[(P) ^ 1]) pp_barrier();                                                                     \
+        if (ISSUE >= 2) PP_ISSUE_A(0, (KT) + 2)                                                                              \
+        PP_READ_A(fY, 1, 1, KT)                                                                                              \
+        if (ISSUE >= 2) pp_wait_vm<6 + (X)>(); else if (ISSUE == 1) pp_wait_vm<4 + (X)>();                                   \
+        pp_barrier();                                                                                                        \
+        PP_MFMA(1, 1, fZ, fY, fw[(P) ^ 1]) pp_barrier();                                                                     \
+        if (ISSUE >= 2) PP_ISSUE_W(0, (KT) + 2)                                                                              \
+        if (ISSUE >= 1) { PP_READ_W(fw[(P) ^ 1], 0, (KT) + 1) PP_READ_A(fX, 0, 0, (KT) + 1) }                                \
+        if (ISSUE >= 2) pp_wait_vm<6>(); else if (ISSUE == 1) pp_wait_vm<2>();                                               \
+        pp_barrier();                                                                                                        \
+        PP_MFMA(1, 0, fZ, fY, fw[P]) pp_barrier();                                                                           \
+    }
+
+    // ---- this block's tiles
+    int tm_ = 0, tn_ = 0;
+    pp_list_tile(xcd, tl, tiles_m, tiles_n, xn, tm_, tn_);
+    PP_SET_TILE(tm_ * 256, tn_ * 256, lane)
+    PP_PROLOGUE()
+    pp_wait_vm<6>();                                // first tile: A_m0[0], W_n0[0], W_n1[0] of this wave have landed
+    while (true) {
+        const int bm0 = tm_ * 256, bn0 = tn_ * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        pp_barrier();                               // every wave's share of A_m0[0], W_n0[0], W_n1[0] is in LDS
+        PP_READ_A(fX, 0, 0, 0) PP_READ_W(fw[0], 0, 0)
+        if (grp == 1) pp_barrier();                 // group 1 runs one barrier behind group 0 from here on
+        int kt = 0;
+        for (; kt + 2 < nkt; kt += 2) { PP_TILE(kt, 2, 0, 0) PP_TILE(kt + 1, 2, 1, 0) }
+        PP_TILE(kt, 1, 0, 0)
+        PP_TILE(kt + 1, 0, 1, 0)
+        if (grp == 0) pp_barrier();                 // same barrier count for both groups; every fragment read has returned
+        // next tile of this block
+        const int ntl_next = tl + cpx;
+        const bool more = ntl_next < ntl;
+        int ntm = 0, ntn = 0;
+        if (more) pp_list_tile(xcd, ntl_next, tiles_m, tiles_n, xn, ntm, ntn);
+        // ---- epilogue.  Its operands pass through an empty asm so that nothing of it is loop-invariant to the compiler:
+        // hoisted out of the persistent loop, the epilogue's addresses and column vectors would live (and spill) across the K loop
+        GemmEpi el = e;
+        int lane_e = lane;
+        {
+            long z = 0;                              // an opaque zero: pointers stay kernel-argument (global) pointers
+            asm volatile("" : "+s"(z));
+            asm volatile("" : "+v"(lane_e));
+            el.out = (char*)e.out + z; el.bias = e.bias ? e.bias + z : nullptr; el.scale = e.scale ? e.scale + z : nullptr;
+            el.res1 = e.res1 ? (const char*)e.res1 + z : nullptr; el.res2 = e.res2 ? (const char*)e.res2 + z : nullptr;
+            el.deq = e.deq ? e.deq + z : nullptr; el.vt = e.vt ? (char*)e.vt + z : nullptr;
+        }
+        u32x4* stg = lds + 2 * PP_STAGE + wid * 256;
+        // the next segment's first twelve pieces leave from inside the epilogue (both stages are free: the last fragment
+        // read returned before the barrier above), followed by >= PP_TAIL stores of this wave
+        auto hook = [&]() { if (more) { PP_SET_TILE(ntm * 256, ntn * 256, lane_e) PP_PROLOGUE() } };
+        {
+            if constexpr (KIND == PP_K_F32) pp_epilogue<PP_EP_F32, ACT_NONE>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+            else if constexpr (KIND == PP_K_GELU) pp_epilogue<PP_EP_BF16, ACT_GELU>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+            else if constexpr (KIND == PP_K_QKV) {
+                if (bn0 >= e.qk_cols) pp_epilogue<PP_EP_VT, ACT_NONE>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+                else pp_epilogue<PP_EP_BF16, ACT_NONE>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+            } else pp_epilogue<PP_EP_BF16, ACT_NONE>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+        }
+        if (!more) break;
+        pp_wait_vm<6 + PP_TAIL>();                  // the first six pieces of the next segment have landed
+        tl = ntl_next; tm_ = ntm; tn_ = ntn;
+    }
+#undef PP_TILE
+#undef PP_MFMA
+#undef PP_READ_A
+#undef PP_READ_W
+#undef PP_ISSUE_A
+#undef PP_ISSUE_W
+#undef PP_PROLOGUE
+#undef PP_SET_TILE
+}
+
+// tile code 256256: the ping-pong kernel.  Requirements: plain row-major A, no ReLU-on-load, an even number (>= 2) of whole K
+// tiles, MAP_ROWS / MAP_QKV, bf16 or f32 output with plain row mapping (the epilogue is staged through LDS), GELU only with
+// bf16 output, no LayerNorm folding (the engine keeps the LN kernels at the batch sizes that use this tile).
+bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, const GemmEpi& e) {
+    if (precision != D2S_PREC_BF16 && precision != D2S_PREC_FP8_OPERANDS) return false;
+    const int bk = 128 / (int)elem_size(precision);
+    if (a.mode != A_PLAIN || a.relu || K % (2 * bk) || (N & 255)) return false;
+    if (e.map != MAP_ROWS && e.map != MAP_QKV) return false;
+    if (e.ln_stats || e.ln_csum || e.stats_out || e.out2) return false;
+    if (e.rows_per_img || e.res1_mod || (e.ldc & 7)) return false;
+    const bool out_bf16 = e.out_type == OUT_BF16 || (e.out_type == OUT_T && precision == D2S_PREC_BF16);
+    if (e.out_type == OUT_F32) { if (e.act != ACT_NONE || e.map != MAP_ROWS) return false; }
+    else if (!(out_bf16 && !e.res1 && !e.res2 && (e.act == ACT_NONE || (e.act == ACT_GELU && e.map == MAP_ROWS)))) return false;
+    if (e.map == MAP_QKV && (e.qk_cols & 255)) return false;            // a block tile is entirely q|k or entirely v
+    if ((long)M * a.lda * (long)elem_size(precision) >= (1L << 31) || (long)gemm_npad(N) * Kpad * (long)elem_size(precision) >= (1L << 31)) return false;
+    return true;
+}
+
+int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, int ksplit,
+                   hipStream_t st) {
+    (void)ksplit;
+    if (!pp_supported(precision, a, M, N, K, Kpad, e)) { set_error("launch_gemm_pp: unsupported problem"); return D2S_E_UNSUPPORTED; }
+    const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
+    unsigned vgrid = 0;
+    int xn = pick_xn(tiles_m, tiles_n, 256, Kpad, elem_size(precision), vgrid);
+    if (xn == 0) xn = 1;
+    // one 160-KiB block per CU, cpx blocks per XCD (blocks beyond an XCD's list exit at once)
+    static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+    const int list_max = cdiv(tiles_n, xn) * cdiv(tiles_m, 8 / xn);     // longest XCD list
+    const unsigned grid = 8u * (unsigned)std::max(1, std::min(ncu / 8, list_max));
+    const int lxn = xn <= 1 ? 0 : (xn == 2 ? 1 : (xn == 4 ? 2 : 3));
+    GemmEpi e1 = e;
+    e1.ksplit = 1;
+    // half a tile time: K tiles x ~1.5 us + ~8 us of prologue / epilogue (D2S_PP_SKEW: percent of that; 0 = off)
+    static const int skew_pct = getenv("D2S_PP_SKEW") ? atoi(getenv("D2S_PP_SKEW")) : 50;
+    const int skew_us = (int)((K / (128 / (int)elem_size(precision)) * 1.5 + 8.0) * skew_pct / 100.0);
+    const int kind = e.out_type == OUT_F32 ? PP_K_F32 : (e.map == MAP_QKV ? PP_K_QKV : (e.act == ACT_GELU ? PP_K_GELU : PP_K_BF16));
+#define PP_LAUNCH(T_, KIND_) hipLaunchKernelGGL((gemm_pp_kernel<T_, KIND_>), dim3(grid), dim3(512), 0, st, (const T_*)a.ptr, a.lda, (const T_*)W, M, N, K, Kpad, e1, lxn, skew_us)
+    if (precision == D2S_PREC_BF16) {
+        if (kind == PP_K_F32) PP_LAUNCH(bf16_t, PP_K_F32); else if (kind == PP_K_QKV) PP_LAUNCH(bf16_t, PP_K_QKV);
+        else if (kind == PP_K_GELU) PP_LAUNCH(bf16_t, PP_K_GELU); else PP_LAUNCH(bf16_t, PP_K_BF16);
+    } else {
+        if (kind == PP_K_F32) PP_LAUNCH(fp8_t, PP_K_F32); else if (kind == PP_K_QKV) PP_LAUNCH(fp8_t, PP_K_QKV);
+        else if (kind == PP_K_GELU) PP_LAUNCH(fp8_t, PP_K_GELU); else PP_LAUNCH(fp8_t, PP_K_BF16);
+    }
+#undef PP_LAUNCH
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+}  // namespace d2s
