@@ -47,7 +47,8 @@ class DibrParams(C.Structure):
     _fields_ = [("ipd_uv", C.c_double), ("depth_strength", C.c_float), ("convergence", C.c_float), ("roll", C.c_float),
                 ("search_radius", C.c_float), ("depth_tolerance", C.c_float), ("blur_radius", C.c_float),
                 ("res_w", C.c_float), ("res_h", C.c_float), ("display_mode", C.c_int32),
-                ("feather_enabled", C.c_int32), ("feather_width", C.c_float)]
+                ("feather_enabled", C.c_int32), ("feather_width", C.c_float), ("corner_radius", C.c_float),
+                ("viewport", C.c_float * 4)]
 
 
 # every symbol include/d2s.h declares: (restype, argtypes)

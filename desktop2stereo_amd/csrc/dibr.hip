@@ -23,6 +23,7 @@ struct DibrGeom {
     float half_ipd, strength, conv;
     float tol, blur, feather_w;
     int search, feather;
+    float corner_r, vpx, vpy, vpw, vph;             // u_corner_radius; u_viewport in eye-image pixels (y up)
     float w1[16], w2[16];  // exp(-i*0.15), exp(-i*0.2)
 };
 
@@ -191,11 +192,19 @@ __device__ __forceinline__ void dibr_pixel(const uint8_t* __restrict__ rgb, cons
         alpha = fminf(bx, by);
     }
     if (g.feather) {                                                                   // :587-616
-        float fu = u, fv = 1.0f - v, fw = g.feather_w;
+        // (gl_FragCoord.xy - u_viewport.xy) / u_viewport.zw; gl_FragCoord is y-up, pixel centres at +0.5
+        float fu = (((float)x + 0.5f) - g.vpx) / g.vpw, fv = (((float)g.oh - ((float)y + 0.5f)) - g.vpy) / g.vph, fw = g.feather_w;
         float fo = smoothstepf(0.f, fw, fu) * smoothstepf(0.f, fw, 1.0f - fu) * smoothstepf(0.f, fw, fv) * smoothstepf(0.f, fw, 1.0f - fv);
         float sh = powf(fo, 0.7f);
 #pragma unroll
         for (int k = 0; k < 3; ++k) col[k] *= sh;
+    }
+    if (g.corner_r > 0.f) {
+        // rounded-box SDF over the quad's own uv (the shader's inner `uv` of the feather block shadows only that block), :617-624
+        const float dx = fabsf(u - 0.5f) - 0.5f + g.corner_r, dy = fabsf(v - 0.5f) - 0.5f + g.corner_r;
+        const float mx = fmaxf(dx, 0.f), my = fmaxf(dy, 0.f);
+        const float sdf = sqrtf(mx * mx + my * my) + fminf(fmaxf(dx, dy), 0.f) - g.corner_r;
+        alpha = fminf(alpha, 1.0f - smoothstepf(0.f, 0.01f, sdf));
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) outc[k] = col[k] * alpha;
@@ -257,6 +266,12 @@ extern "C" int d2s_dibr_warp(const uint8_t* rgb, const float* depth, int batch, 
     g.strength = p->depth_strength; g.conv = p->convergence;
     g.tol = p->depth_tolerance; g.blur = p->blur_radius; g.feather_w = p->feather_width;
     g.search = (int)p->search_radius; g.feather = p->feather_enabled != 0;
+    D2S_REQUIRE(p->corner_radius >= 0.f && p->corner_radius <= 0.5f, "corner_radius must be in [0, 0.5]");
+    g.corner_r = p->corner_radius;
+    const bool vp0 = p->viewport[2] == 0.f && p->viewport[3] == 0.f;
+    D2S_REQUIRE(vp0 || (p->viewport[2] > 0.f && p->viewport[3] > 0.f), "viewport width / height must be positive (or all zero)");
+    g.vpx = vp0 ? 0.f : p->viewport[0]; g.vpy = vp0 ? 0.f : p->viewport[1];
+    g.vpw = vp0 ? (float)g.ow : p->viewport[2]; g.vph = vp0 ? (float)g.oh : p->viewport[3];
     for (int i = 0; i < 16; ++i) { g.w1[i] = expf((float)(-i * 0.15)); g.w2[i] = expf((float)(-i * 0.2)); }
     D2S_REQUIRE(2 * g.oh <= 65535 && batch <= 65535, "frame / batch too large for one launch");
     dim3 grid(cdiv(g.ow, 256), 2 * g.oh, batch), block(256);

@@ -202,13 +202,16 @@ def make_sbs(frames: torch.Tensor, depth: torch.Tensor, sp: SbsParams, out_fmt: 
 
 def dibr_params(ipd_uv=0.064, depth_ratio=1.0, convergence=0.0, display_mode="Full-SBS", roll=0.0, feather=False,
                 viewer_depth_strength=0.1, search_radius=12.0, depth_tolerance=0.012, blur_radius=2.5,
-                feather_width=0.02, resolution=(0.0, 0.0)) -> _lib.DibrParams:
-    """Uniform block of the reference's DIBR shader with the viewer's defaults (viewer.py:1333-1343, 402-404)."""
+                feather_width=0.02, resolution=(0.0, 0.0), corner_radius=0.0, viewport=(0.0, 0.0, 0.0, 0.0)) -> _lib.DibrParams:
+    """Uniform block of the reference's DIBR shader with the viewer's defaults (viewer.py:1333-1343, 402-411).
+    corner_radius: u_corner_radius (0 desktop viewer, 0.03 OpenXR screen); viewport: u_viewport (x, y, w, h) in pixels of
+    the eye image, y up -- zeros = the eye image itself."""
     if display_mode not in MODE:
         raise ValueError(f"display_mode must be one of {list(MODE)}")
     return _lib.DibrParams(float(ipd_uv), float(viewer_depth_strength * depth_ratio), float(convergence), float(roll),
                            float(search_radius), float(depth_tolerance), float(blur_radius), float(resolution[0]),
-                           float(resolution[1]), MODE[display_mode], int(bool(feather)), float(feather_width))
+                           float(resolution[1]), MODE[display_mode], int(bool(feather)), float(feather_width),
+                           float(corner_radius), (C.c_float * 4)(*[float(v) for v in viewport]))
 
 
 def dibr_warp(frames: torch.Tensor, depth: torch.Tensor, dp: "_lib.DibrParams", out_u8: bool = True) -> torch.Tensor:

@@ -122,6 +122,12 @@ typedef struct d2s_dibr_params {
     int32_t display_mode;      /* D2S_MODE_*: how the two eye viewports are packed */
     int32_t feather_enabled;   /* u_feather_enabled */
     float   feather_width;     /* u_feather_width = 0.02 (viewer.py:1343) */
+    float   corner_radius;     /* u_corner_radius (viewer.py:411, 617-624): rounded-box SDF over the quad's uv, alpha =
+                                  1 - smoothstep(0, 0.01, sdf); 0 in the desktop viewer, 0.03 in the OpenXR screen
+                                  (xr_viewer/implementation.py:293) */
+    float   viewport[4];       /* u_viewport = (x, y, w, h) of the eye's viewport in pixels of the eye image, y up like
+                                  gl_FragCoord (viewer.py:589: the feathering is relative to it); all 0: the eye image
+                                  itself, (0, 0, out_w, out_h) */
 } d2s_dibr_params;
 
 const char* d2s_last_error(void);

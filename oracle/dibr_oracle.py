@@ -94,7 +94,7 @@ def _inpaint(rgb, dep, u, v, cdi, par, sweep_sign, ps, search_radius, tol, blur)
 
 def dibr_eye(rgb_u8_hwc: np.ndarray, depth: np.ndarray, eye_offset: float, depth_strength: float, convergence: float = 0.0,
              out_h: int = 0, out_w: int = 0, roll: float = 0.0, res=None, search_radius=12.0, tol=0.012, blur=2.5,
-             feather=False, feather_width=0.02) -> np.ndarray:
+             feather=False, feather_width=0.02, corner_radius=0.0, viewport=None) -> np.ndarray:
     """One eye of FRAGMENT_SHADER.main (viewer.py:533-631) rendered into an out_h x out_w viewport -> float32
     [out_h,out_w,3] in 0..255 (colour * alpha over black).  eye_offset: -ipd_uv/2 left, +ipd_uv/2 right
     (viewer.py:2701, 2714); depth_strength = viewer.depth_strength (0.1) * depth_ratio (viewer.py:1334, 2686)."""
@@ -135,11 +135,20 @@ def dibr_eye(rgb_u8_hwc: np.ndarray, depth: np.ndarray, eye_offset: float, depth
     by = _smoothstep(-0.001, 0.001, sv) * _smoothstep(1.001, 0.999, sv)
     alpha = np.minimum(bx, by)
     if feather:                                                                      # :587-616 (viewport uv, y up)
-        fu, fv = u, F32(1) - v
+        vx, vy, vw_, vh_ = viewport if viewport is not None and viewport[2] > 0 else (0.0, 0.0, float(ow), float(oh))
+        xs = np.arange(ow, dtype=F32)[None, :] + F32(0.5)                            # gl_FragCoord: pixel centres, y up
+        ys = F32(oh) - (np.arange(oh, dtype=F32)[:, None] + F32(0.5))
+        fu = np.broadcast_to((xs - F32(vx)) / F32(vw_), (oh, ow)).astype(F32)
+        fv = np.broadcast_to((ys - F32(vy)) / F32(vh_), (oh, ow)).astype(F32)
         fw = F32(feather_width)
         fo = (_smoothstep(0.0, fw, fu) * _smoothstep(0.0, fw, F32(1) - fu) * _smoothstep(0.0, fw, fv)
               * _smoothstep(0.0, fw, F32(1) - fv))
         color = color * np.power(fo, F32(0.7))[..., None]
+    if corner_radius > 0:                                                            # :617-624 (quad uv, Inigo Quilez rounded box)
+        r = F32(corner_radius)
+        dx, dy = np.abs(u - F32(0.5)) - F32(0.5) + r, np.abs(v - F32(0.5)) - F32(0.5) + r
+        sdf = np.sqrt(np.maximum(dx, 0) ** 2 + np.maximum(dy, 0) ** 2).astype(F32) + np.minimum(np.maximum(dx, dy), 0) - r
+        alpha = np.minimum(alpha, F32(1) - _smoothstep(0.0, 0.01, sdf.astype(F32)))
     return (color * alpha[..., None]).astype(F32)
 
 

@@ -36,6 +36,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_lib.ModelDesc) == 4 * (3 + 4 + 4 + 5) + 4 + 4 + 4 + 4  # ... ln_eps, precision, temporal, max_depth
     assert C.sizeof(_lib.PostParams) == 28 and _lib.PostParams.metric.offset == 24
     assert C.sizeof(_lib.SbsParams) == 24 and _lib.SbsParams.ipd_uv.offset == 0 and _lib.SbsParams.depth_ratio.offset == 8
+    assert C.sizeof(_lib.DibrParams) == 72 and _lib.DibrParams.corner_radius.offset == 52 and _lib.DibrParams.viewport.offset == 56
     assert C.sizeof(_lib.PreParams) == 28 and _lib.PreParams.std.offset == 12 and _lib.PreParams.resample.offset == 24
 
 

@@ -58,7 +58,9 @@ def test_dibr_parameters_vs_oracle(dev):
     img, dep = _scene(150, 260, 2)
     ti, td = torch.from_numpy(img).to(dev), torch.from_numpy(dep).to(dev)
     cases = [dict(roll=0.3), dict(convergence=0.5), dict(feather=True), dict(resolution=(520.0, 300.0)),
-             dict(depth_ratio=30.0), dict(search_radius=5.0, depth_tolerance=0.3, blur_radius=1.0)]
+             dict(depth_ratio=30.0), dict(search_radius=5.0, depth_tolerance=0.3, blur_radius=1.0),
+             dict(corner_radius=0.03),                                        # the OpenXR screen's rounded corners (viewer.py:617-624)
+             dict(corner_radius=0.2, feather=True, feather_width=0.1, viewport=(10.0, 5.0, 230.0, 140.0))]   # u_viewport != the quad
     for kw in cases:
         okw = dict(kw)
         dr = okw.pop("depth_ratio", 4.0)
@@ -68,6 +70,8 @@ def test_dibr_parameters_vs_oracle(dev):
         rk = {}
         if "roll" in okw: rk["roll"] = okw["roll"]
         if "feather" in okw: rk["feather"] = True
+        for k in ("feather_width", "corner_radius", "viewport"):
+            if k in okw: rk[k] = okw[k]
         if "resolution" in okw: rk["res"] = okw["resolution"]
         if "search_radius" in okw: rk.update(search_radius=5.0, tol=0.3, blur=1.0)
         want = R.dibr_sbs(img, dep, 0.064, dr, conv, "Full-SBS", **rk)
