@@ -79,6 +79,14 @@ SYMBOLS = {
     "d2s_dibr_warp": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(DibrParams), _P, C.c_int, _P]),
     "d2s_jpeg_bound": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "d2s_jpeg_encode": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P, _P, C.c_int64, _P]),
+    "d2s_present_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
+    "d2s_present_bind": (C.c_int, [_P, C.c_int, _P, C.c_uint64]),
+    "d2s_present_bind_gl_buffer": (C.c_int, [_P, C.c_int, C.c_uint]),
+    "d2s_present_acquire": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "d2s_present_publish": (C.c_int, [_P, C.c_int, _P]),
+    "d2s_present_consume": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "d2s_present_release": (C.c_int, [_P, C.c_int, _P]),
+    "d2s_present_destroy": (C.c_int, [_P]),
     "d2s_pipeline": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(PreParams), C.POINTER(PostParams),
                                C.POINTER(SbsParams), C.c_int, _P, C.c_int, _P, _P]),
     "d2s_engine_reset_stream": (C.c_int, [_P]),

@@ -270,10 +270,9 @@ def jpeg_encode(frames: torch.Tensor, quality: int = 90, out_stride: Optional[in
             raise ValueError(f"jpeg_encode: workspace must be a uint8 device tensor of >= {ws_frame * B + 256} bytes")
         ws = workspace
     else:
-        key = (f.device.index or 0, ws_frame * B)
-        ws = _JPEG_WS.get(key)
-        if ws is None:
-            _JPEG_WS.clear()
+        key = (f.device.index or 0, torch.cuda.current_stream(f.device).cuda_stream)
+        ws = _JPEG_WS.get(key)                      # one growing scratch per (device, stream): never freed under a running encode
+        if ws is None or ws.numel() < ws_frame * B + 256:
             ws = _JPEG_WS[key] = torch.empty(ws_frame * B + 256, dtype=torch.uint8, device=f.device)
     pad = (-ws.data_ptr()) % 256
     out = torch.empty((B, stride), dtype=torch.uint8, device=f.device)

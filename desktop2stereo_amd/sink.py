@@ -65,14 +65,20 @@ class MJPEGEncoder:
         """Queue the encode of one HWC RGB frame (device tensor or numpy) behind the work already issued on the current
         stream; returns at once.  The frame's memory must stay untouched until ``wait()`` (or the next ``set_frame``)."""
         t = _to_device(frame)
-        if self._stream is None:
+        if t.dim() != 3:
+            raise ValueError("MJPEGEncoder.set_frame takes ONE HWC frame (the reference's encoder thread holds one raw_frame, "
+                             "streamer.py:230-257); use encode_jpeg_batch for a batch")
+        if self._stream is None or self._stream.device != t.device:
             self._stream = torch.cuda.Stream(device=t.device)
+            self._ws = None
         ready = torch.cuda.Event()
-        ready.record()
-        need = ops.jpeg_bound(t.shape[-3], t.shape[-2])[1] * (t.shape[0] if t.dim() == 4 else 1) + 256
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=t.device)
+        ready.record(torch.cuda.current_stream(t.device))
+        need = ops.jpeg_bound(t.shape[-3], t.shape[-2])[1] + 256
         with torch.cuda.stream(self._stream):
+            if self._ws is None or self._ws.numel() < need:
+                # (re)allocated on the ENCODER's stream: the old scratch may still be read by the encode queued there, and the
+                # caching allocator only reuses a block for work ordered behind the stream it was allocated on
+                self._ws = torch.empty(need, dtype=torch.uint8, device=t.device)
             self._stream.wait_event(ready)
             out, sizes = ops.jpeg_encode(t, self.quality, workspace=self._ws)
             done = torch.cuda.Event()

@@ -238,6 +238,24 @@ int d2s_jpeg_bound(int H, int W, int64_t* out_bytes, int64_t* workspace_bytes);
 int d2s_jpeg_encode(const void* frames, int fmt, int batch, int H, int W, int quality, uint8_t* out,
                     int64_t out_stride, int32_t* sizes, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* f4: device-resident hand-off of a produced frame to the display path -- replaces the viewer's per-frame
+ * `stream.synchronize()` + hipGraphicsMapResources + hipMemcpy(D2D into the PBO) + unmap (reference viewer.py:1584-1712,
+ * 2399-2428; CUDART_GL viewer.py:232-345).  The consumer lends a ring of its own device buffers (d2s_present_bind: any
+ * device pointer, e.g. a mapped GL PBO; d2s_present_bind_gl_buffer: a GL buffer id, registered WRITE_DISCARD like
+ * viewer.py:293 -- needs a current GL context); the producer acquires a slot, passes its pointer as `out` of d2s_pipeline /
+ * d2s_make_sbs / d2s_upsample_depth, and publishes it; the consumer picks the latest published slot.  All waits are
+ * HIP events between the two streams (consumer_stream = (void*)-1: host wait, for a GL consumer): no copy, no host
+ * synchronisation on the producer side.  Producer and consumer may be different host threads. */
+typedef struct d2s_present d2s_present;
+int d2s_present_create(int device_id, int slots, d2s_present** out);
+int d2s_present_bind(d2s_present* p, int slot, void* dev_ptr, uint64_t bytes);
+int d2s_present_bind_gl_buffer(d2s_present* p, int slot, unsigned gl_buffer);
+int d2s_present_acquire(d2s_present* p, void* producer_stream, int* slot, void** dev_ptr, uint64_t* bytes);
+int d2s_present_publish(d2s_present* p, int slot, void* producer_stream);
+int d2s_present_consume(d2s_present* p, void* consumer_stream, int* slot, void** dev_ptr, uint64_t* seq);
+int d2s_present_release(d2s_present* p, int slot, void* consumer_stream);
+int d2s_present_destroy(d2s_present* p);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused frame pipeline: predict_depth + make_sbs for a batch of frames
  * (capture -> depth -> warp of reference main.py:232-262, 1336-1341 in one stream-ordered
