@@ -17,7 +17,9 @@ int hip_fail(hipError_t err, const char* what, const char* file, int line);
         if (_e != hipSuccess) return ::d2s::hip_fail(_e, #call, __FILE__, __LINE__); \
     } while (0)
 
-#define D2S_CHECK_LAUNCH() D2S_HIP(hipGetLastError())
+// status of the launch just made.  (hipGetLastError() is sticky on ROCm 7: it reports the last error ANY earlier runtime call of
+// this host thread returned -- e.g. a probing call of the application -- and would blame it on this launch.)
+#define D2S_CHECK_LAUNCH() D2S_HIP(hipExtGetLastError())
 
 #define D2S_REQUIRE(cond, msg)                                                  \
     do {                                                                        \
@@ -34,6 +36,7 @@ struct DeviceGuard {
     bool ok = true;
     explicit DeviceGuard(int dev) {
         int cur = -1;
+        (void)hipGetLastError();                  // errors left behind by earlier calls of this thread are not ours
         if (hipGetDevice(&cur) != hipSuccess) cur = -1;
         if (cur != dev) { ok = hipSetDevice(dev) == hipSuccess; prev = cur; }
     }

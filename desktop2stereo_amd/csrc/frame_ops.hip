@@ -326,7 +326,7 @@ constexpr int SW_GROUPS = SW_LDS_PX / 4;               // 12-byte groups of 4 pi
 constexpr int SW_DN = (FP_TW + 8 + 255) / 256;         // depth-row values per thread
 
 template <int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 5)
 stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
                    int B, WarpGeom g) {
     __shared__ __attribute__((aligned(16))) uint32_t spix[2][SW_LDS_PX];
@@ -347,9 +347,10 @@ stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     const int dxa = linear_tap(xa, g.dsx, g.dw, false).i0;
     const int dn = linear_tap(xe, g.dsx, g.dw, false).i1 - dxa + 1;
     const int groups = (wx1 - wx0) >> 2;
+    // (frame, row) of an item are tracked incrementally: the scalar unit has no integer divide
 #define SW_DECODE(ITEM, b_, y_)                                                               \
-    const int b_ = (ITEM) / g.H;                                                              \
-    const int y_ = (ITEM) - b_ * g.H;
+    const int b_ = (ITEM) == item ? cur_b : nxt_b;                                            \
+    const int y_ = (ITEM) == item ? cur_y : nxt_y;
 
 #define SW_LOAD(ITEM)                                                                         \
     {                                                                                         \
@@ -391,6 +392,21 @@ stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ de
 
     int item = blockIdx.x;
     if (item >= items) return;
+    int cur_b = item / g.H, cur_y = item - cur_b * g.H, nxt_b = cur_b, nxt_y = cur_y;      // (one division per block)
+    // per-thread column constants: the depth taps of this thread's 4 pixels depend on x only, not on the row
+    const int x_base = xa + tid * FP_PX;
+    int li0[FP_PX], li1[FP_PX];
+    float lw0[FP_PX], lw1[FP_PX];
+#pragma unroll
+    for (int k = 0; k < FP_PX; ++k) {
+        int x = x_base + k; if (x > g.W - 1) x = g.W - 1;
+        Tap t = linear_tap(x, g.dsx, g.dw, false);
+        li0[k] = t.i0 - dxa; li1[k] = t.i1 - dxa; lw0[k] = t.w0; lw1[k] = t.w1;
+    }
+    // a wave whose 256 pixels stay more than the halo away from both frame edges never reflects and never leaves the staged
+    // window as long as |shift| < FP_MARGIN - 1: one vote for both eyes, no per-tap range logic (wave-uniform)
+    const int wave_x0 = xa + (tid & ~63) * FP_PX;
+    const bool interior = wave_x0 >= FP_MARGIN + 2 && wave_x0 + 64 * FP_PX - 1 <= g.W - 1 - (FP_MARGIN + 2);
     SW_LOAD(item)
     SW_STORE(item, 0)
     __syncthreads();
@@ -398,23 +414,38 @@ stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     while (true) {
         const int next = item + (int)gridDim.x;
         const bool has = next < items;
+        nxt_b = cur_b; nxt_y = cur_y + (int)gridDim.x;
+        while (nxt_y >= g.H) { nxt_y -= g.H; ++nxt_b; }
         if (has) SW_LOAD(next)
         {
             SW_DECODE(item, b, y)
             const uint8_t* src_row = rgb + ((long)b * g.H + y) * (long)g.W * 3;
-            const int x_base = xa + tid * FP_PX;
             if (x_base < g.W) {
                 float shift[FP_PX];
+                bool small = true;
 #pragma unroll
                 for (int k = 0; k < FP_PX; ++k) {
-                    int x = x_base + k; if (x > g.W - 1) x = g.W - 1;
-                    Tap t = linear_tap(x, g.dsx, g.dw, false);
-                    float d = t.w0 * drow[buf][t.i0 - dxa] + t.w1 * drow[buf][t.i1 - dxa] - g.conv;
+                    float d = lw0[k] * drow[buf][li0[k]] + lw1[k] * drow[buf][li1[k]] - g.conv;
                     shift[k] = ((-d * g.ratio) * g.max_px) * 0.05f;
+                    small = small && fabsf(shift[k]) < (float)(FP_MARGIN - 1);
                 }
+                const bool easy = interior && __all(small);
 #pragma unroll
                 for (int eye = 0; eye < 2; ++eye) {
                     float px[FP_PX][3];
+                    if (easy) {
+                        // x + s stays inside [2, W-3] and inside the staged window: no reflection, x1 = x0 + 1 (one ds_read2_b32)
+#pragma unroll
+                        for (int k = 0; k < FP_PX; ++k) {
+                            const float sx = (float)(x_base + k) + (eye ? -shift[k] : shift[k]);
+                            const int x0 = (int)sx;
+                            const float w1 = sx - (float)x0, w0 = 1.0f - w1;
+                            const uint32_t p0 = spix[buf][x0 - wx0], p1 = spix[buf][x0 - wx0 + 1];
+                            px[k][0] = w0 * (float)(p0 & 0xffu) + w1 * (float)(p1 & 0xffu);
+                            px[k][1] = w0 * (float)((p0 >> 8) & 0xffu) + w1 * (float)((p1 >> 8) & 0xffu);
+                            px[k][2] = w0 * (float)((p0 >> 16) & 0xffu) + w1 * (float)((p1 >> 16) & 0xffu);
+                        }
+                    } else {
                     // branch-free coordinates (at most one reflection per side); one wave-level test
                     // decides between the LDS taps and the rare generic path (shift beyond the staged
                     // halo, or more than one reflection)
@@ -448,6 +479,7 @@ stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ de
                             const uint8_t* q0 = src_row + (long)x0 * 3; const uint8_t* q1 = src_row + (long)x1 * 3;
                             for (int c = 0; c < 3; ++c) px[k][c] = w0 * (float)q0[c] + w1 * (float)q1[c];
                         }
+                    }
                     }
                     // values are convex combinations of bytes: already inside [0,255], round-half-even only
                     if (x_base + FP_PX <= g.W) {
@@ -493,7 +525,7 @@ stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ de
         if (has) SW_STORE(next, buf ^ 1)
         __syncthreads();
         if (!has) break;
-        item = next;
+        item = next; cur_b = nxt_b; cur_y = nxt_y;
         buf ^= 1;
     }
 #undef SW_DECODE

@@ -54,6 +54,8 @@
 // lane with 4 consecutive n of ONE row: 32 rows x 16-32 B per store, measured 1.8 TB/s).
 #include "gemm_epi.h"
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 namespace d2s {
 
@@ -81,119 +83,194 @@ __device__ __forceinline__ void pp_barrier() {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// column-wise part of the epilogue on 4 consecutive n: de-quantise, bias, activation, LayerScale
-template <int ACT>
-__device__ __forceinline__ void pp_colwise(const GemmEpi& e, int n0, float v[4], bool with_bias) {
-    if (e.deq) { float q[4]; load4(e.deq + n0, q); v[0] *= q[0]; v[1] *= q[1]; v[2] *= q[2]; v[3] *= q[3]; }
-    if (e.bias && with_bias) { float b[4]; load4(e.bias + n0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
-    if (ACT == ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
-    else if (ACT == ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-    if (e.scale) { float s[4]; load4(e.scale + n0, s); v[0] *= s[0]; v[1] *= s[1]; v[2] *= s[2]; v[3] *= s[3]; }
+// tuning aid (build with D2S_HIPCC_DEFS=-DD2S_PP_TIMING): wave 0 of every block stamps the 100 MHz wall clock at kernel entry
+// and, per tile, at main-loop start / main-loop end / epilogue end / next tile's operands landed; tools/pp_timeline.py reads them
+#ifdef D2S_PP_TIMING
+__device__ unsigned long long pp_timing[256 * 64];
+__device__ int pp_timing_kind = -1;
+#define PP_STAMP(SLOT) { if (tid == 0 && KIND == pp_timing_kind && (SLOT) < 64) pp_timing[blockIdx.x * 64 + (SLOT)] = wall_clock64(); }
+#else
+#define PP_STAMP(SLOT)
+#endif
+
+// exact-erf GELU on two values at once: the Abramowitz-Stegun 7.1.26 form of gelu_erf (gemm_epi.h) on 2-vectors, so that the
+// multiplies / fmas become v_pk_mul_f32 / v_pk_fma_f32 (one instruction per PAIR), rearranged to
+//     gelu(x) = x/2 (1 + erf(x / sqrt 2)) = max(x, 0) - (|x| P(t)/2) exp(-x^2 / 2),    t = 1 / (1 + p |x| / sqrt 2)
+// (x/2 + |x|/2 = max(x, 0); the sign of erf cancels against the sign of x): 14 vector + 4 transcendental instructions per
+// pair.  FC1's epilogue is 128 x 64 GELUs per wave with the matrix pipe idle -- about 6 us of a 24 us tile at batch 32.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2v gelu_erf2(f32x2v x) {
+    const f32x2v ax = __builtin_elementwise_abs(x);
+    const f32x2v den = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
+    const f32x2v t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};       // v_rcp_f32 (1 ulp); __frcp_rn is a full division
+    const f32x2v hp = t * (t * (t * (t * (t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f)) + (0.5f * 1.421413741f)) + (0.5f * -0.284496736f)) + (0.5f * 0.254829592f));
+    const f32x2v arg = (ax * ax) * (-0.5f * 1.4426950408889634f);                           // exp(-x^2/2) = 2^arg
+    const f32x2v ex = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+    const f32x2v relu = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    return relu - (ax * hp) * ex;
 }
 
-// Epilogue modes.  Every mode issues a FIXED number of vector-memory instructions per wave (rows past M are clamped to row
-// M-1, whose duplicate A rows produced identical values), because the caller counts them in vmcnt.
+// Epilogue modes.  Every mode issues at least PP_TAIL vector-memory instructions per wave after its hook (rows past M fall
+// outside the output buffer's num_records: the store is dropped but still issues), because the caller counts them in vmcnt.
 enum { PP_EP_BF16 = 0, PP_EP_F32 = 1, PP_EP_VT = 3 };
-// lower bound of the vector-memory instructions every epilogue / slab write issues AFTER its hook (the point where the next
-// segment's LDS-DMA is issued): the bf16 epilogue's 16 stores (the others issue 32 or more)
+// lower bound of the vector-memory instructions every epilogue issues AFTER its hook (the point where the next segment's
+// LDS-DMA is issued): the bf16 epilogue's 16 stores (the others issue 32 or more)
 constexpr int PP_TAIL = 16;
+constexpr int PP_MAXN = 16384;                 // widest N (length of the stand-in column vectors)
+constexpr int PP_RING = 1;                      // passes of fp32 residuals in flight (16 VGPRs each)
+
+// (absent bias / LayerScale / de-quantisation vectors are replaced by constant vectors of zeros / ones on the host: a null
+//  check per load would put a branch around every one of them)
+__device__ __forceinline__ f32x4 pp_col4(const float* p, int n0) { return *(const f32x4*)(p + n0); }
+template <int ACT>
+__device__ __forceinline__ f32x4 pp_act4(f32x4 v) {
+    if constexpr (ACT == ACT_GELU) {
+        const f32x2v a = gelu_erf2((f32x2v){v[0], v[1]}), b = gelu_erf2((f32x2v){v[2], v[3]});
+        return (f32x4){a[0], a[1], b[0], b[1]};
+    } else if constexpr (ACT == ACT_RELU) {
+        return (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+    } else return v;
+}
+#define PP_PIN4(X) asm volatile("" : "+v"(X))       // the value is complete (and opaque) from here on
 
 // One wave's 128 x 64 tile -> global memory.  `hook()` is called exactly once, at the point after which at least PP_TAIL
 // vector-memory instructions follow.
 //   PP_EP_BF16   32 rows x 64 columns per pass (4 passes): ds_write_b64 -> ds_read_b128 -> global_store_dwordx4 (8 rows x 128 B)
-//   PP_EP_F32    32 rows x 32 columns per pass (8 passes): ds_write_b128 -> ds_read_b128 -> (+ residuals) -> store; the
-//                residual loads (the in-place fp32 residual stream of proj / FC2) run two passes ahead of their use
+//   PP_EP_F32    32 rows x 32 columns per pass (8 passes, column half outer): ds_write_b128 -> ds_read_b128 -> (+ residuals)
+//                -> store; the residual loads (the in-place fp32 residual stream of proj / FC2) run four passes ahead
 //   PP_EP_VT     the V third of a QKV launch goes transposed to vt[b, head, d, token]; the MFMA layout already has
 //                consecutive tokens in consecutive lanes, so it is stored directly (2-byte stores, 64 B per 32 lanes)
+// Memory order is what the time goes to here, not arithmetic: vmcnt retires in order on gfx9, so a load issued after a
+// store waits for that store's round trip to HBM, and a load issued after the hook waits for the next tile's operands.
+// (Measured with the in-kernel stamps, batch 32: with the column vectors fetched inside every pass the epilogue of a tile
+// took 9 us for bf16 output, 14-19 us with GELU or the fp32 residual -- as long as the 12-K-tile main loop.)  So every
+// column vector (de-quantisation, bias, LayerScale) and the first four passes of residuals are requested BEFORE the hook
+// and pinned (one exposed L2 latency per tile); after the hook only stores and the ring's refills are issued.
 // LDS patch rows are 128 bytes = 8 chunks, chunk index XOR (row & 7) on both sides.  Wave-private: no barrier, the LDS ops
 // of one wave execute in order.
-template <int MODE, int ACT, typename HOOK>
+template <int MODE, int ACT, bool DEQ, bool RES, typename HOOK>
 __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& e, int bm0, int bn0, int M, int grp, int wn,
                                             int lane, u32x4* stg, HOOK&& hook) {
-#define PP_QUAD(V, I, J, Q4) float V[4] = {acc[I][J][4 * (Q4) + 0], acc[I][J][4 * (Q4) + 1], acc[I][J][4 * (Q4) + 2], acc[I][J][4 * (Q4) + 3]};
+#define PP_QUAD(I, J, Q4) (f32x4){acc[I][J][4 * (Q4) + 0], acc[I][J][4 * (Q4) + 1], acc[I][J][4 * (Q4) + 2], acc[I][J][4 * (Q4) + 3]}
     const int fl = lane & 31, kg = lane >> 5;
     const int rr = lane >> 3, rc = lane & 7;
     const int wm0 = bm0 + grp * 128, wn0 = bn0 + wn * 64;
-    hook();
+    // quad (j, q4) of this lane = columns wn0 + j * 32 + 8 * q4 + 4 * kg .. + 3
     if constexpr (MODE == PP_EP_F32) {
-        // residual prefetch ring: pass p = (i, j) reads rows i*32 + r*8 + rr, columns j*32 + rc*4
-        f32x4 res[2][4];
-        const bool has_res = e.res1 != nullptr;
-        auto res_load = [&](auto pc) {
-            constexpr int p = decltype(pc)::value;
-            constexpr int i = p >> 1, j = p & 1;
-            if (has_res) {
+        // out = res + scale * (deq * acc + bias) = res + ca * acc + cc  with  ca = scale * deq,  cc = scale * bias
+        f32x4 ca[2][4], cc[2][4];                    // per column half j
+        f32x4 res[PP_RING][4];                       // residual prefetch ring: pass p = j * 4 + i
+        // raw buffers over [M][ldc]: one per-lane byte offset serves every row of every pass (+ a wave-uniform term), and
+        // rows past M fall outside num_records -- their loads return 0 and their stores are dropped, yet the instruction
+        // still issues, which keeps the vmcnt accounting fixed without clamping rows
+        const unsigned ldc = (unsigned)e.ldc, nrec = (unsigned)M * ldc * 4u;
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, nrec, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)e.res1, 0, RES ? nrec : 0u, 0x00020000);
+        const unsigned vo = ((unsigned)(wm0 + rr) * ldc + (unsigned)(wn0 + rc * 4)) * 4u;
+        auto col_load = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int m = wm0 + i * 32 + r * 8 + rr; m = m < M ? m : M - 1;
-                    res[p & 1][r] = *(const f32x4*)((const float*)e.res1 + (long)m * e.ldc + wn0 + j * 32 + rc * 4);
-                }
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = wn0 + j * 32 + 8 * q + 4 * kg;
+                const f32x4 sc = pp_col4(e.scale, n0);
+                cc[j][q] = pp_col4(e.bias, n0) * sc;
+                if constexpr (DEQ) ca[j][q] = pp_col4(e.deq, n0) * sc; else ca[j][q] = sc;
             }
         };
-        static_for<2>([&](auto pc) { res_load(pc); });
+        auto res_load = [&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            constexpr int j = p >> 2, i = p & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                res[p % PP_RING][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo + ((i * 32 + r * 8) * ldc + j * 32) * 4u, 0, 0));
+        };
+        col_load(std::integral_constant<int, 0>{});
+        if constexpr (RES) static_for<PP_RING>([&](auto pc) { res_load(pc); });
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { PP_PIN4(ca[0][q]); PP_PIN4(cc[0][q]); }
+        if constexpr (RES) {
+#pragma unroll
+            for (int p = 0; p < PP_RING; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) PP_PIN4(res[p][r]);
+        }
+        hook();
         static_for<8>([&](auto pc) {
             constexpr int p = decltype(pc)::value;
-            constexpr int i = p >> 1, j = p & 1;
+            constexpr int j = p >> 2, i = p & 3;
             static_for<4>([&](auto qc) {
                 constexpr int q4 = decltype(qc)::value;
-                const int n0 = wn0 + j * 32 + 8 * q4 + 4 * kg;
-                PP_QUAD(v, i, j, q4)
-                pp_colwise<ACT>(e, n0, v, true);
-                stg[fl * 8 + ((2 * q4 + kg) ^ (fl & 7))] = __builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]});
+                const f32x4 v = PP_QUAD(i, j, q4) * ca[j][q4] + cc[j][q4];
+                stg[fl * 8 + ((2 * q4 + kg) ^ (fl & 7))] = __builtin_bit_cast(u32x4, v);
             });
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = r * 8 + rr, n = wn0 + j * 32 + rc * 4;
-                int m = wm0 + i * 32 + row; m = m < M ? m : M - 1;
+                const int row = r * 8 + rr;
                 f32x4 x = __builtin_bit_cast(f32x4, stg[row * 8 + (rc ^ (row & 7))]);
-                const long off = (long)m * e.ldc + n;
-                if (has_res) x += res[p & 1][r];
-                if (e.res2) { f32x4 t = *(const f32x4*)((const float*)e.res2 + off); x += t; }
-                *(f32x4*)((float*)e.out + off) = x;
+                if constexpr (RES) x += res[p % PP_RING][r];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rsO, vo + ((i * 32 + r * 8) * ldc + j * 32) * 4u, 0, 0);
             }
-            asm volatile("" ::: "memory");                        // (keeps the ring two passes deep: no hoisting of later loads)
-            if constexpr (p + 2 < 8) res_load(std::integral_constant<int, p + 2>{});
+            asm volatile("" ::: "memory");                        // (keeps the ring PP_RING passes deep: no hoisting of later loads)
+            if constexpr (RES && p + PP_RING < 8) res_load(std::integral_constant<int, p + PP_RING>{});
+            if constexpr (p == 1) col_load(std::integral_constant<int, 1>{});     // two more passes until the other column half
         });
         return;
-    }
-    static_for<4>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        if constexpr (MODE == PP_EP_VT) {
-            int m = wm0 + i * 32 + fl; m = m < M ? m : M - 1;
-            const int b = m / e.ntok, t = m - b * e.ntok;
-            static_for<2>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                static_for<4>([&](auto qc) {
-                    constexpr int q4 = decltype(qc)::value;
-                    const int n0 = wn0 + j * 32 + 8 * q4 + 4 * kg;
-                    PP_QUAD(v, i, j, q4)
-                    pp_colwise<ACT_NONE>(e, n0, v, true);
-                    bf16_t* p = (bf16_t*)e.vt + ((long)b * e.heads * 64 + (n0 - e.qk_cols)) * e.npad + t;
-                    p[0] = f2bf(v[0]); p[e.npad] = f2bf(v[1]); p[2L * e.npad] = f2bf(v[2]); p[3L * e.npad] = f2bf(v[3]);
-                });
-            });
-        } else {
-            static_for<2>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                static_for<4>([&](auto qc) {
-                    constexpr int q4 = decltype(qc)::value;
-                    const int n0 = wn0 + j * 32 + 8 * q4 + 4 * kg;
-                    PP_QUAD(v, i, j, q4)
-                    pp_colwise<ACT>(e, n0, v, true);
-                    uint2 t;
-                    t.x = pk_bf16(v[0], v[1]); t.y = pk_bf16(v[2], v[3]);
-                    ((uint2*)stg)[(fl * 8 + ((j * 4 + q4) ^ (fl & 7))) * 2 + kg] = t;
-                });
-            });
+    } else {
+        f32x4 cb[2][4], cd[2][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = r * 8 + rr, n = wn0 + rc * 8;
-                int m = wm0 + i * 32 + row; m = m < M ? m : M - 1;
-                u32x4 x = stg[row * 8 + (rc ^ (row & 7))];
-                *(u32x4*)((bf16_t*)e.out + (long)m * e.ldc + n) = x;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = wn0 + j * 32 + 8 * q + 4 * kg;
+                cb[j][q] = pp_col4(e.bias, n0);
+                if constexpr (DEQ) cd[j][q] = pp_col4(e.deq, n0);
             }
-        }
-    });
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { PP_PIN4(cb[j][q]); if constexpr (DEQ) PP_PIN4(cd[j][q]); }
+        const unsigned ldc = (unsigned)e.ldc;
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, (unsigned)M * ldc * 2u, 0x00020000);
+        const unsigned vo = ((unsigned)(wm0 + rr) * ldc + (unsigned)(wn0 + rc * 8)) * 2u;
+        hook();
+        static_for<4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (MODE == PP_EP_VT) {
+                int m = wm0 + i * 32 + fl; m = m < M ? m : M - 1;
+                const int b = m / e.ntok, t = m - b * e.ntok;
+                static_for<2>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    static_for<4>([&](auto qc) {
+                        constexpr int q4 = decltype(qc)::value;
+                        const int n0 = wn0 + j * 32 + 8 * q4 + 4 * kg;
+                        f32x4 v = PP_QUAD(i, j, q4);
+                        if constexpr (DEQ) v *= cd[j][q4];
+                        v += cb[j][q4];
+                        bf16_t* p = (bf16_t*)e.vt + ((long)b * e.heads * 64 + (n0 - e.qk_cols)) * e.npad + t;
+                        p[0] = f2bf(v[0]); p[e.npad] = f2bf(v[1]); p[2L * e.npad] = f2bf(v[2]); p[3L * e.npad] = f2bf(v[3]);
+                    });
+                });
+            } else {
+                static_for<2>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    static_for<4>([&](auto qc) {
+                        constexpr int q4 = decltype(qc)::value;
+                        f32x4 v = PP_QUAD(i, j, q4);
+                        if constexpr (DEQ) v *= cd[j][q4];
+                        v = pp_act4<ACT>(v + cb[j][q4]);
+                        uint2 t;
+                        t.x = pk_bf16(v[0], v[1]); t.y = pk_bf16(v[2], v[3]);
+                        ((uint2*)stg)[(fl * 8 + ((j * 4 + q4) ^ (fl & 7))) * 2 + kg] = t;
+                    });
+                });
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = r * 8 + rr;
+                    __builtin_amdgcn_raw_buffer_store_b128(stg[row * 8 + (rc ^ (row & 7))], rsO, vo + (i * 32 + r * 8) * ldc * 2u, 0, 0);
+                }
+            }
+        });
+    }
 #undef PP_QUAD
 }
 
@@ -222,6 +299,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
                int skew_us) {
     constexpr int ES = (int)sizeof(T);
     constexpr int BK = 128 / ES;                                    // K elements per tile
+    constexpr bool DEQ = ES == 1;                                   // e4m3 operands: the accumulator is de-quantised per column
     // 128 KiB of stages + 8 wave-private 4 KiB epilogue patches = the CU's 160 KiB: the ONLY __shared__ object (see gemm.hip)
     __shared__ __attribute__((aligned(16))) u32x4 lds[2 * PP_STAGE + 8 * 256];
 
@@ -235,6 +313,8 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     const int ntl = myr.ml * myr.nl;                                 // tiles of this XCD's list
     int tl = blockIdx.x >> 3;                                        // this block's position in it
     if (tl >= ntl) return;
+    PP_STAMP(0)
+    int stamp_ = 1; (void)stamp_;
     // Blocks that walk one tile fewer than the busiest of their XCD start late by about half a tile time: it costs nothing
     // (they finish before the others anyway) and it takes them out of the store bursts -- a lock-step grid dumps 128 KiB
     // per CU at the same instant, that drains in ~8 us, and every CU sits on vmcnt behind its own stores meanwhile.
@@ -355,6 +435,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     PP_SET_TILE(tm_ * 256, tn_ * 256, lane)
     PP_PROLOGUE()
     pp_wait_vm<6>();                                // first tile: A_m0[0], W_n0[0], W_n1[0] of this wave have landed
+    bool after_epi = false;
     while (true) {
         const int bm0 = tm_ * 256, bn0 = tn_ * 256;
 #pragma unroll
@@ -366,11 +447,17 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         pp_barrier();                               // every wave's share of A_m0[0], W_n0[0], W_n1[0] is in LDS
         PP_READ_A(fX, 0, 0, 0) PP_READ_W(fw[0], 0, 0)
         if (grp == 1) pp_barrier();                 // group 1 runs one barrier behind group 0 from here on
+        PP_STAMP(stamp_)
         int kt = 0;
+        // behind an epilogue the first three waits leave its (>= PP_TAIL) stores in flight: they sit between the prologue's
+        // pieces and the ones issued here, and a plain vmcnt(6) would wait for their round trip to HBM
+        asm volatile("" : "+s"(kt));                // (a literal K tile index would put sixteen hoisted LDS addresses in VGPRs)
+        if (after_epi && nkt >= 4) { PP_TILE(kt, 2, 0, PP_TAIL) PP_TILE(kt + 1, 2, 1, 0) kt += 2; }
         for (; kt + 2 < nkt; kt += 2) { PP_TILE(kt, 2, 0, 0) PP_TILE(kt + 1, 2, 1, 0) }
         PP_TILE(kt, 1, 0, 0)
         PP_TILE(kt + 1, 0, 1, 0)
         if (grp == 0) pp_barrier();                 // same barrier count for both groups; every fragment read has returned
+        PP_STAMP(stamp_ + 1)
         // next tile of this block
         const int ntl_next = tl + cpx;
         const bool more = ntl_next < ntl;
@@ -384,25 +471,31 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
             long z = 0;                              // an opaque zero: pointers stay kernel-argument (global) pointers
             asm volatile("" : "+s"(z));
             asm volatile("" : "+v"(lane_e));
-            el.out = (char*)e.out + z; el.bias = e.bias ? e.bias + z : nullptr; el.scale = e.scale ? e.scale + z : nullptr;
-            el.res1 = e.res1 ? (const char*)e.res1 + z : nullptr; el.res2 = e.res2 ? (const char*)e.res2 + z : nullptr;
-            el.deq = e.deq ? e.deq + z : nullptr; el.vt = e.vt ? (char*)e.vt + z : nullptr;
+            el.out = (char*)e.out + z; el.bias = e.bias + z; el.scale = e.scale + z; el.deq = e.deq + z;
+            el.res1 = e.res1 ? (const char*)e.res1 + z : nullptr; el.vt = e.vt ? (char*)e.vt + z : nullptr;
         }
         u32x4* stg = lds + 2 * PP_STAGE + wid * 256;
         // the next segment's first twelve pieces leave from inside the epilogue (both stages are free: the last fragment
         // read returned before the barrier above), followed by >= PP_TAIL stores of this wave
         auto hook = [&]() { if (more) { PP_SET_TILE(ntm * 256, ntn * 256, lane_e) PP_PROLOGUE() } };
         {
-            if constexpr (KIND == PP_K_F32) pp_epilogue<PP_EP_F32, ACT_NONE>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
-            else if constexpr (KIND == PP_K_GELU) pp_epilogue<PP_EP_BF16, ACT_GELU>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+            if constexpr (KIND == PP_K_F32) {
+                if (e.res1) pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+                else pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+            }
+            else if constexpr (KIND == PP_K_GELU) pp_epilogue<PP_EP_BF16, ACT_GELU, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
             else if constexpr (KIND == PP_K_QKV) {
-                if (bn0 >= e.qk_cols) pp_epilogue<PP_EP_VT, ACT_NONE>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
-                else pp_epilogue<PP_EP_BF16, ACT_NONE>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
-            } else pp_epilogue<PP_EP_BF16, ACT_NONE>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+                if (bn0 >= e.qk_cols) pp_epilogue<PP_EP_VT, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+                else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+            } else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
         }
+        PP_STAMP(stamp_ + 2)
         if (!more) break;
         pp_wait_vm<6 + PP_TAIL>();                  // the first six pieces of the next segment have landed
+        PP_STAMP(stamp_ + 3)
+        stamp_ += 4;
         tl = ntl_next; tm_ = ntm; tn_ = ntn;
+        after_epi = true;
     }
 #undef PP_TILE
 #undef PP_MFMA
@@ -423,13 +516,33 @@ bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, 
     if (a.mode != A_PLAIN || a.relu || K % (2 * bk) || (N & 255)) return false;
     if (e.map != MAP_ROWS && e.map != MAP_QKV) return false;
     if (e.ln_stats || e.ln_csum || e.stats_out || e.out2) return false;
-    if (e.rows_per_img || e.res1_mod || (e.ldc & 7)) return false;
+    if (e.rows_per_img || e.res1_mod || (e.ldc & 7) || e.res2 || N > PP_MAXN) return false;
     const bool out_bf16 = e.out_type == OUT_BF16 || (e.out_type == OUT_T && precision == D2S_PREC_BF16);
     if (e.out_type == OUT_F32) { if (e.act != ACT_NONE || e.map != MAP_ROWS) return false; }
-    else if (!(out_bf16 && !e.res1 && !e.res2 && (e.act == ACT_NONE || (e.act == ACT_GELU && e.map == MAP_ROWS)))) return false;
+    else if (!(out_bf16 && !e.res1 && !e.res2 && !e.scale && (e.act == ACT_NONE || (e.act == ACT_GELU && e.map == MAP_ROWS)))) return false;
     if (e.map == MAP_QKV && (e.qk_cols & 255)) return false;            // a block tile is entirely q|k or entirely v
+    if ((long)M * e.ldc * 4 >= (1L << 31)) return false;               // the epilogue's 32-bit buffer offsets
     if ((long)M * a.lda * (long)elem_size(precision) >= (1L << 31) || (long)gemm_npad(N) * Kpad * (long)elem_size(precision) >= (1L << 31)) return false;
     return true;
+}
+
+// constant column vectors that stand in for an absent bias (zeros) / LayerScale / de-quantisation (ones), one set per device
+static const float* pp_const_vec(bool ones) {
+    static std::mutex mu;
+    static float* buf[64] = {};
+    int d = 0;
+    (void)hipGetDevice(&d);
+    std::lock_guard<std::mutex> g(mu);
+    if (d < 0 || d >= 64) return nullptr;
+    if (!buf[d]) {
+        std::vector<float> h(2 * PP_MAXN, 0.f);
+        std::fill(h.begin() + PP_MAXN, h.end(), 1.f);
+        float* p = nullptr;
+        if (hipMalloc(&p, h.size() * sizeof(float)) != hipSuccess) return nullptr;
+        if (hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        buf[d] = p;
+    }
+    return buf[d] + (ones ? PP_MAXN : 0);
 }
 
 int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, int ksplit,
@@ -447,6 +560,10 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
     const int lxn = xn <= 1 ? 0 : (xn == 2 ? 1 : (xn == 4 ? 2 : 3));
     GemmEpi e1 = e;
     e1.ksplit = 1;
+    if (!e1.bias) e1.bias = pp_const_vec(false);
+    if (!e1.scale) e1.scale = pp_const_vec(true);
+    if (!e1.deq) e1.deq = pp_const_vec(true);
+    if (!e1.bias || !e1.scale || !e1.deq) { set_error("launch_gemm_pp: constant vectors"); return D2S_E_HIP; }
     // half a tile time: K tiles x ~1.5 us + ~8 us of prologue / epilogue (D2S_PP_SKEW: percent of that; 0 = off)
     static const int skew_pct = getenv("D2S_PP_SKEW") ? atoi(getenv("D2S_PP_SKEW")) : 50;
     const int skew_us = (int)((K / (128 / (int)elem_size(precision)) * 1.5 + 8.0) * skew_pct / 100.0);
@@ -465,3 +582,12 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
 }
 
 }  // namespace d2s
+
+#ifdef D2S_PP_TIMING
+extern "C" int d2s_pp_timing(int kind, unsigned long long* out) {      // kind >= 0: select + clear; out != null: read 256 x 64 stamps
+    if (kind >= -1) { if (hipMemcpyToSymbol(HIP_SYMBOL(d2s::pp_timing_kind), &kind, sizeof(int)) != hipSuccess) return 1; }
+    if (out) return hipMemcpyFromSymbol(out, HIP_SYMBOL(d2s::pp_timing), sizeof(unsigned long long) * 256 * 64) != hipSuccess;
+    static unsigned long long zeros[256 * 64];
+    return hipMemcpyToSymbol(HIP_SYMBOL(d2s::pp_timing), zeros, sizeof(zeros)) != hipSuccess;
+}
+#endif

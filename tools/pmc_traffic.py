@@ -32,9 +32,9 @@ def read(d, counter):
 def main():
     root = sys.argv[1]
     out = {"source": root, "calibration": {}, "traffic_bytes_per_launch": {}}
-    for B in sorted({os.path.basename(p).split("_b")[-1] for p in glob.glob(os.path.join(root, "bench_b*"))}, key=int):
+    for B in sorted({os.path.basename(p).split("_b")[-1] for p in glob.glob(os.path.join(root, "bench_b*")) if os.path.isdir(p)}, key=int):
         d = os.path.join(root, f"bench_b{B}")
-        fetch, write = read(d, "FETCH_SIZE"), read(d, "WRITE_SIZE")          # rocprofv3 reports these in KiB-free raw units: bytes / 1? -> calibrated below
+        fetch, write = read(d, "FETCH_SIZE"), read(d, "WRITE_SIZE")          # counter units are calibrated below, not assumed
         cf, cw = read(os.path.join(root, "calib"), "FETCH_SIZE"), read(os.path.join(root, "calib"), "WRITE_SIZE")
         ff, fw = [], []
         for k, (rb, wb) in KNOWN.items():
