@@ -40,8 +40,8 @@
 //     younger pieces may stay in flight) and the barrier(s) both groups pass before MEM(q) (MI355X_MICROARCH.md "Two waves
 //     per SIMD" item 7; cdna_hip_programming.md 8-phase template);  WAR: a piece is overwritten >= 3 phases after its last read.
 // The last two K tiles run the same phases without issuing (waits 4 / 2 / 0).  K tiles per block must be even (fw0 parity).
-// Persistent loop: the block walks its XCD's tile list (pp_rect: the XCDs own rectangles of the tile space, m-slow /
-// n-fast), CU c of the XCD taking tiles c, c + cpx, ...  -- at any moment an XCD's CUs work on cpx consecutive tiles, which
+// Persistent loop: the block walks its XCD's run of the tile sequence (pp_run / pp_tile_of: column group by column group,
+// m-slow / n-fast), CU c of the XCD taking tiles c, c + cpx, ...  -- at any moment an XCD's CUs work on cpx consecutive tiles, which
 // share A row panels and W column panels in that XCD's L2.  The next tile's first twelve pieces are issued INSIDE the
 // epilogue of the current one, and the tile starts on a counted vmcnt that lets the epilogue's own stores stay in flight
 // (vmcnt retires in order on gfx9).
@@ -274,22 +274,24 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
 #undef PP_QUAD
 }
 
-// Tile order: the 8 XCDs form an xn x (8/xn) grid of rectangles over the tile space (as tile_of_block); XCD x's tiles, in
-// m-slow / n-fast order, are its list.
-// (xn is a power of two, passed as its log2: the scalar unit has no integer divide -- a runtime '/' is ~40 instructions)
-struct PPRect { int m0, ml, n0, nl; };
-__device__ __forceinline__ PPRect pp_rect(int x, int tiles_m, int tiles_n, int lxn) {
-    const int lxm = 3 - lxn, xi = x & ((1 << lxn) - 1), xj = x >> lxn;
-    PPRect r;
-    r.n0 = (tiles_n * xi) >> lxn; r.nl = ((tiles_n * (xi + 1)) >> lxn) - r.n0;
-    r.m0 = (tiles_m * xj) >> lxm; r.ml = ((tiles_m * (xj + 1)) >> lxm) - r.m0;
-    return r;
+// Tile order: the tile columns are cut into xn groups (so that a group's W panel stays in one XCD's L2); the tiles are
+// ordered group by group, m-slow / n-fast inside a group, and that sequence is cut into 8 contiguous runs of equal length
+// (+-1 tile), one per XCD.  Runs rather than whole-row rectangles: 249 tiles (batch 27, N = 768) are 31-32 per XCD -- one
+// round on its 32 CUs -- where rectangles of whole tile rows gave one XCD 33; a run may straddle two column groups.
+// (xn is a power of two, passed as its log2; the one runtime division per tile is ~40 scalar instructions)
+__host__ __device__ __forceinline__ void pp_run(int x, int total, int& start, int& len) {
+    start = (int)(((long)total * x) >> 3); len = (int)(((long)total * (x + 1)) >> 3) - start;
 }
-// tile j of XCD x's list
-__device__ __forceinline__ void pp_list_tile(int x, int j, int tiles_m, int tiles_n, int xn, int& tm, int& tn) {
-    const PPRect r = pp_rect(x, tiles_m, tiles_n, xn);
-    const int q = j / r.nl;
-    tm = r.m0 + q; tn = r.n0 + (j - q * r.nl);
+__device__ __forceinline__ void pp_tile_of(int lin, int tiles_m, int tiles_n, int lxn, int& tm, int& tn) {
+    int g = 0, n0 = 0, nl = 1;
+    for (;;) {
+        const int n1 = (tiles_n * (g + 1)) >> lxn;
+        nl = n1 - n0;
+        const int T = tiles_m * nl;
+        if (lin < T) break;
+        lin -= T; n0 = n1; ++g;
+    }
+    tm = lin / nl; tn = n0 + (lin - tm * nl);
 }
 enum { PP_K_BF16 = 0, PP_K_GELU = 1, PP_K_QKV = 2, PP_K_F32 = 3 };     // epilogue of a launch (one kernel instance each)
 
@@ -309,8 +311,8 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
     const int nkt = K / BK;                                          // K tiles per output tile: even, >= 2
     const int cpx = gridDim.x >> 3, xcd = blockIdx.x & 7;
-    const PPRect myr = pp_rect(xcd, tiles_m, tiles_n, xn);
-    const int ntl = myr.ml * myr.nl;                                 // tiles of this XCD's list
+    int run0 = 0, ntl = 0;                                           // this XCD's run of the tile sequence
+    pp_run(xcd, tiles_m * tiles_n, run0, ntl);
     int tl = blockIdx.x >> 3;                                        // this block's position in it
     if (tl >= ntl) return;
     PP_STAMP(0)
@@ -431,7 +433,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
 
     // ---- this block's tiles
     int tm_ = 0, tn_ = 0;
-    pp_list_tile(xcd, tl, tiles_m, tiles_n, xn, tm_, tn_);
+    pp_tile_of(run0 + tl, tiles_m, tiles_n, xn, tm_, tn_);
     PP_SET_TILE(tm_ * 256, tn_ * 256, lane)
     PP_PROLOGUE()
     pp_wait_vm<6>();                                // first tile: A_m0[0], W_n0[0], W_n1[0] of this wave have landed
@@ -462,7 +464,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         const int ntl_next = tl + cpx;
         const bool more = ntl_next < ntl;
         int ntm = 0, ntn = 0;
-        if (more) pp_list_tile(xcd, ntl_next, tiles_m, tiles_n, xn, ntm, ntn);
+        if (more) pp_tile_of(run0 + ntl_next, tiles_m, tiles_n, xn, ntm, ntn);
         // ---- epilogue.  Its operands pass through an empty asm so that nothing of it is loop-invariant to the compiler:
         // hoisted out of the persistent loop, the epilogue's addresses and column vectors would live (and spill) across the K loop
         GemmEpi el = e;
@@ -555,9 +557,9 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
     if (xn == 0) xn = 1;
     // one 160-KiB block per CU, cpx blocks per XCD (blocks beyond an XCD's list exit at once)
     static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
-    const int list_max = cdiv(tiles_n, xn) * cdiv(tiles_m, 8 / xn);     // longest XCD list
-    const unsigned grid = 8u * (unsigned)std::max(1, std::min(ncu / 8, list_max));
     const int lxn = xn <= 1 ? 0 : (xn == 2 ? 1 : (xn == 4 ? 2 : 3));
+    const int list_max = cdiv(tiles_m * tiles_n, 8);                     // longest XCD run
+    const unsigned grid = 8u * (unsigned)std::max(1, std::min(ncu / 8, list_max));
     GemmEpi e1 = e;
     e1.ksplit = 1;
     if (!e1.bias) e1.bias = pp_const_vec(false);
