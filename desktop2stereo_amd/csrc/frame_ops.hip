@@ -533,6 +533,254 @@ stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ de
 #undef SW_STORE
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lane-strided streaming path (Full-SBS / Full-TAB, W % 64 == 0).  stereo_warp_stream above is VALU-issue bound (~680
+// instructions per thread-row of 8 output pixels: byte unpacking at every tap, unfused blends, stride-4 LDS taps).  Here
+//   * the source window is unpacked ONCE per row into three float planes (R, G, B) in LDS: a bilinear tap pair is
+//     ds_read_b32 x 2 per channel, no v_cvt_f32_ubyte / mask / shift per tap, and the 12-byte staging groups land as
+//     conflict-free ds_write_b128 (4 consecutive floats of one channel);
+//   * lane l of wave w owns pixels xa + 256 w + l + 64 k (k = 0..3): consecutive lanes tap consecutive LDS words (no
+//     bank conflicts; the 4-consecutive-pixels mapping of the older kernel strides lanes by 4 words);
+//   * the blend keeps the reference's rounding (two products, one sum, each rounded: depth.py:2164-2184 via
+//     F.grid_sample bilinear) but issues the two products as ONE v_pk_mul_f32;
+//   * results are packed to RGBX bytes, transposed through a wave-private 1 KiB LDS patch (write [l + 64 k], read
+//     [4 l .. 4 l + 3]; one wave's LDS operations execute in order, no barrier) and leave as 12-byte stores, 768
+//     contiguous bytes per wave-instruction.
+// Everything else (one item = one row of one 1024-pixel column tile, register prefetch of the next item, one barrier per
+// item, wave-uniform easy / reflecting / generic paths) is as in stereo_warp_stream.
+// ------------------------------------------------------------------------------------------------
+typedef float wl_f2 __attribute__((ext_vector_type(2)));
+constexpr int WL_PLANE = SW_LDS_PX;                    // floats per channel plane
+constexpr int WL_DN = 2;                               // depth-row values per thread (depth grid columns under a tile <= 512)
+
+typedef uint32_t wl_u3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void wl_gload3(wl_u3& d, const void* p) { asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void wl_gload1(float& d, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+// LDS-only block barrier.  __syncthreads() is a workgroup release / acquire fence over ALL address spaces: the compiler puts
+// s_waitcnt vmcnt(0) in front of it, which drains the prefetched rows and every global store of the row just written --
+// once per row.  The rows exchanged here live in LDS only.
+__device__ __forceinline__ void wl_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 4)
+stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
+                  int B, WarpGeom g) {
+    __shared__ __attribute__((aligned(16))) float splane[2][3][WL_PLANE];     // 27,648 B
+    __shared__ float drow[2][FP_TW + 8];                                        //  8,256 B
+    __shared__ __attribute__((aligned(16))) uint32_t tpose[4][256];            //  4,096 B  -> 4 blocks per CU
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int items = B * g.H;                            // rows of all frames
+    const float span = (float)(g.W - 1);
+    const long per = (long)g.out_h * g.out_w;
+
+    // two register sets: the row after the one being computed (stored to LDS at the end of the iteration) and the row after
+    // that (requested at the start of the iteration).  With one row in flight per block the kernel ran at the latency of
+    // one load + the stores queued ahead of it per row (~4 us x 27 rows per block at batch 16: 2.6 TB/s whatever the
+    // instruction count was); vmcnt retires in order, so a load also waits for the older stores of the previous row.
+    wl_u3 pre[2][2];
+    float dpre[2][WL_DN], dpre2[2][WL_DN], dw0[2] = {0.f, 0.f}, dw1[2] = {0.f, 0.f};
+
+    const int xa = blockIdx.y * FP_TW;
+    const int wx0 = xa - FP_MARGIN < 0 ? 0 : xa - FP_MARGIN;
+    const int wx1 = xa + FP_TW + FP_MARGIN > g.W ? g.W : xa + FP_TW + FP_MARGIN;
+    const int xe = xa + FP_TW - 1 > g.W - 1 ? g.W - 1 : xa + FP_TW - 1;
+    const int dxa = linear_tap(xa, g.dsx, g.dw, false).i0;
+    const int dn = linear_tap(xe, g.dsx, g.dw, false).i1 - dxa + 1;
+    const int groups = (wx1 - wx0) >> 2;
+    int gofs[2], dofs[WL_DN];                              // this thread's (clamped) byte / element offsets inside a row
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int gi = tid + 256 * j; gofs[j] = (wx0 + 4 * (gi < groups ? gi : groups - 1)) * 3; }
+#pragma unroll
+    for (int i = 0; i < WL_DN; ++i) { const int di = tid + 256 * i; dofs[i] = di < dn ? di : dn - 1; }
+
+#define WL_LOAD(S, LB, LY)                                                                    \
+    {                                                                                         \
+        const uint8_t* row_ = rgb + ((long)(LB) * g.H + (LY)) * (long)g.W * 3;                \
+        /* The prefetch loads are issued from inline asm and waited for with a hand-counted vmcnt (WL_WAIT): the compiler's    \
+           own count for a load that crosses the loop's back edge and its branches is the minimum over all paths -- vmcnt(5)   \
+           here, which also drains the row requested a moment ago and the stores just issued.  Unconditional, at clamped        \
+           indices: every path issues the same number of vector-memory instructions. */                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) wl_gload3(pre[S][j], row_ + gofs[j]);   \
+        const float* dep_ = depth + (long)(LB) * g.dh * g.dw + dxa;                           \
+        Tap ty_ = linear_tap((LY), g.dsy, g.dh, false);                                       \
+        dw0[S] = ty_.w0; dw1[S] = ty_.w1;                                                     \
+        _Pragma("unroll") for (int i = 0; i < WL_DN; ++i) {                                   \
+            wl_gload1(dpre[S][i], dep_ + ty_.i0 * g.dw + dofs[i]); wl_gload1(dpre2[S][i], dep_ + ty_.i1 * g.dw + dofs[i]); \
+        }                                                                                     \
+    }
+    // set S has landed: N = vector-memory instructions issued after its 6 loads that may stay in flight (vmcnt retires in order)
+#define WL_WAIT(S, N)                                                                         \
+    asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(pre[S][0]), "+v"(pre[S][1]), "+v"(dpre[S][0]), "+v"(dpre[S][1]),         \
+                 "+v"(dpre2[S][0]), "+v"(dpre2[S][1]) :: "memory");
+    // bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 of a 4-pixel group -> four floats per channel plane
+#define WL_UB(WORD, N) ((float)(((WORD) >> (8 * (N))) & 0xffu))
+#define WL_STORE(S, BUF)                                                                      \
+    {                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
+            int gi = tid + 256 * j;                                                           \
+            if (gi < groups) {                                                                \
+                const uint32_t a_ = pre[S][j][0], b_ = pre[S][j][1], c_ = pre[S][j][2];       \
+                *(float4*)&splane[BUF][0][4 * gi] = make_float4(WL_UB(a_, 0), WL_UB(a_, 3), WL_UB(b_, 2), WL_UB(c_, 1)); \
+                *(float4*)&splane[BUF][1][4 * gi] = make_float4(WL_UB(a_, 1), WL_UB(b_, 0), WL_UB(b_, 3), WL_UB(c_, 2)); \
+                *(float4*)&splane[BUF][2][4 * gi] = make_float4(WL_UB(a_, 2), WL_UB(b_, 1), WL_UB(c_, 0), WL_UB(c_, 3)); \
+            }                                                                                 \
+        }                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < WL_DN; ++i) {                                   \
+            int di = tid + 256 * i;                                                           \
+            if (di < dn) drow[BUF][di] = dw0[S] * dpre[S][i] + dw1[S] * dpre2[S][i];          \
+        }                                                                                     \
+    }
+
+    int item = blockIdx.x;
+    if (item >= items) return;
+    int cur_b = item / g.H, cur_y = item - cur_b * g.H;                                     // (one division per block)
+    // per-thread column constants: pixel k of this lane, its depth taps (they depend on x only) and whether it exists
+    const int wave_x0 = xa + wid * 256;
+    int li0[FP_PX], li1[FP_PX];
+    float lw0[FP_PX], lw1[FP_PX], xf[FP_PX];
+#pragma unroll
+    for (int k = 0; k < FP_PX; ++k) {
+        int x = wave_x0 + lane + 64 * k; if (x > g.W - 1) x = g.W - 1;
+        Tap t = linear_tap(x, g.dsx, g.dw, false);
+        li0[k] = t.i0 - dxa; li1[k] = t.i1 - dxa; lw0[k] = t.w0; lw1[k] = t.w1; xf[k] = (float)x;
+    }
+    const int nk = g.W - wave_x0 >= 256 ? 4 : (g.W - wave_x0 <= 0 ? 0 : (g.W - wave_x0) >> 6);   // W % 64 == 0: wave-uniform
+    // a wave whose pixels stay more than the halo away from both frame edges never reflects and never leaves the staged
+    // window as long as |shift| < FP_MARGIN - 1 (wave-uniform vote, no per-tap range logic)
+    const bool interior = wave_x0 >= FP_MARGIN + 2 && wave_x0 + 255 <= g.W - 1 - (FP_MARGIN + 2);
+    const int xs = wave_x0 + 4 * lane;                    // first of the 4 consecutive pixels this lane stores
+    uint32_t* const tp = tpose[wid];
+    const int stride = (int)gridDim.x;
+    int n1_b = cur_b, n1_y = cur_y + stride;               // (frame, row) of the next two items, tracked incrementally
+    while (n1_y >= g.H) { n1_y -= g.H; ++n1_b; }
+    int n2_b = n1_b, n2_y = n1_y + stride;
+    while (n2_y >= g.H) { n2_y -= g.H; ++n2_b; }
+    bool has1 = item + stride < items, has2 = item + 2 * stride < items;
+    WL_LOAD(0, cur_b, cur_y)
+    WL_LOAD(1, (has1 ? n1_b : cur_b), (has1 ? n1_y : cur_y))
+    WL_WAIT(0, 6)
+    WL_STORE(0, 0)
+    wl_sync();
+    // one iteration: request item + 2 into register set SL, compute item from LDS buffer BUF, put item + 1 (set SS) into
+    // the other LDS buffer
+#define WL_ITER(BUF, SS, SL)                                                                  \
+    {                                                                                         \
+        WL_LOAD(SL, (has2 ? n2_b : cur_b), (has2 ? n2_y : cur_y))                             \
+        wl_compute(BUF, cur_b, cur_y);                                                        \
+        if (has1) {                                                                           \
+            /* younger than set SS: the 6 loads of set SL and this row's 2 stores (waves with no pixel store nothing).   \
+               (Also letting the PREVIOUS row's 2 stores stay in flight -- vmcnt(10) from the second iteration on -- measured  \
+               no faster.) */                                                                                               \
+            if (nk > 0) { WL_WAIT(SS, 8) } else { WL_WAIT(SS, 6) }                            \
+            WL_STORE(SS, (BUF) ^ 1)                                                           \
+        }                                                                                     \
+        wl_sync();                                                                      \
+        if (!has1) break;                                                                     \
+        item += stride; cur_b = n1_b; cur_y = n1_y; n1_b = n2_b; n1_y = n2_y;                 \
+        n2_y += stride; while (n2_y >= g.H) { n2_y -= g.H; ++n2_b; }                          \
+        has1 = has2; has2 = item + 2 * stride < items;                                        \
+    }
+    auto wl_compute = [&](int buf, int b, int y) {
+        if (nk > 0) {
+            const float* dr = drow[buf];
+            const float* sp = &splane[buf][0][0] - wx0;          // plane R indexed by frame x
+            float shift[FP_PX];
+            bool small = true;
+#pragma unroll
+            for (int k = 0; k < FP_PX; ++k) {
+                const wl_f2 dd = (wl_f2){dr[li0[k]], dr[li1[k]]} * (wl_f2){lw0[k], lw1[k]};
+                const float d = (dd[0] + dd[1]) - g.conv;
+                shift[k] = ((-d * g.ratio) * g.max_px) * 0.05f;
+                small = small && fabsf(shift[k]) < (float)(FP_MARGIN - 1);
+            }
+            const bool easy = interior && __all(small);
+#pragma unroll
+            for (int eye = 0; eye < 2; ++eye) {
+                uint32_t pk[FP_PX];
+                if (easy) {
+#pragma unroll
+                    for (int k = 0; k < FP_PX; ++k) {
+                        const float sx = eye ? xf[k] - shift[k] : xf[k] + shift[k];
+                        const float fl = floorf(sx);
+                        const float w1 = sx - fl, w0 = 1.0f - w1;
+                        const float* p = sp + (int)fl;
+                        const wl_f2 ww = {w0, w1};
+                        const wl_f2 vr = (wl_f2){p[0], p[1]} * ww, vg = (wl_f2){p[WL_PLANE], p[WL_PLANE + 1]} * ww,
+                                    vb = (wl_f2){p[2 * WL_PLANE], p[2 * WL_PLANE + 1]} * ww;
+                        uint32_t u = __builtin_amdgcn_cvt_pk_u8_f32(vr[0] + vr[1], 0, 0);
+                        u = __builtin_amdgcn_cvt_pk_u8_f32(vg[0] + vg[1], 1, u);
+                        pk[k] = __builtin_amdgcn_cvt_pk_u8_f32(vb[0] + vb[1], 2, u);
+                    }
+                } else {
+                    // branch-free coordinates (at most one reflection per side); one wave-level test decides between the
+                    // LDS taps and the rare generic path (shift beyond the staged halo, or more than one reflection)
+                    float sxv[FP_PX];
+                    bool fast = true;
+#pragma unroll
+                    for (int k = 0; k < FP_PX; ++k) {
+                        const float xr = fabsf(eye ? xf[k] - shift[k] : xf[k] + shift[k]);
+                        fast = fast && (xr <= 2.f * span);
+                        sxv[k] = xr <= span ? xr : span - (xr - span);
+                        const int x0 = (int)sxv[k];
+                        fast = fast && (x0 >= wx0) && (x0 + 1 < wx1 || (x0 + 1 >= g.W && x0 < wx1));
+                    }
+                    if (__all(fast)) {
+#pragma unroll
+                        for (int k = 0; k < FP_PX; ++k) {
+                            const int x0 = (int)sxv[k];
+                            const float w1 = sxv[k] - (float)x0, w0 = 1.0f - w1;
+                            const int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
+                            const float *p0 = sp + x0, *p1 = sp + x1;
+                            const wl_f2 ww = {w0, w1};
+                            const wl_f2 vr = (wl_f2){p0[0], p1[0]} * ww, vg = (wl_f2){p0[WL_PLANE], p1[WL_PLANE]} * ww,
+                                        vb = (wl_f2){p0[2 * WL_PLANE], p1[2 * WL_PLANE]} * ww;
+                            uint32_t u = __builtin_amdgcn_cvt_pk_u8_f32(vr[0] + vr[1], 0, 0);
+                            u = __builtin_amdgcn_cvt_pk_u8_f32(vg[0] + vg[1], 1, u);
+                            pk[k] = __builtin_amdgcn_cvt_pk_u8_f32(vb[0] + vb[1], 2, u);
+                        }
+                    } else {
+                        const uint8_t* src_row = rgb + ((long)b * g.H + y) * (long)g.W * 3;
+                        for (int k = 0; k < FP_PX; ++k) {
+                            const float sx = reflect_clip(eye ? xf[k] - shift[k] : xf[k] + shift[k], span);
+                            const int x0 = (int)sx;
+                            const float w1 = sx - (float)x0, w0 = 1.0f - w1;
+                            const int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
+                            const uint8_t* q0 = src_row + (long)x0 * 3; const uint8_t* q1 = src_row + (long)x1 * 3;
+                            uint32_t u = 0;
+                            u = __builtin_amdgcn_cvt_pk_u8_f32(w0 * (float)q0[0] + w1 * (float)q1[0], 0, u);
+                            u = __builtin_amdgcn_cvt_pk_u8_f32(w0 * (float)q0[1] + w1 * (float)q1[1], 1, u);
+                            pk[k] = __builtin_amdgcn_cvt_pk_u8_f32(w0 * (float)q0[2] + w1 * (float)q1[2], 2, u);
+                        }
+                    }
+                }
+                // values are convex combinations of bytes: already inside [0,255]; v_cvt_pk_u8_f32 rounds half-even
+                // wave-private transpose: [l + 64 k] -> [4 l .. 4 l + 3], then 4 x RGBX -> 12 bytes
+#pragma unroll
+                for (int k = 0; k < FP_PX; ++k) tp[lane + 64 * k] = pk[k];
+                const uint4 v = *(const uint4*)&tp[4 * lane];
+                if (xs < g.W) {
+                    const long row = (MODE == D2S_MODE_FULL_SBS) ? y : (long)eye * g.H + y;
+                    const long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + xs : xs;
+                    uint3 w3;
+                    w3.x = (v.x & 0x00ffffffu) | (v.y << 24);
+                    w3.y = ((v.y >> 8) & 0x0000ffffu) | (v.z << 16);
+                    w3.z = ((v.z >> 16) & 0x000000ffu) | (v.w << 8);
+                    *(uint3*)(out + (b * per + row * g.out_w + col) * 3) = w3;
+                }
+            }
+        }
+    };
+    while (true) {
+        WL_ITER(0, 1, 0)
+        WL_ITER(1, 0, 1)
+    }
+#undef WL_ITER
+#undef WL_WAIT
+#undef WL_LOAD
+#undef WL_STORE
+#undef WL_UB
+}
+
 // Half-TAB fast path: thread = 4 source pixels x 2 rows (y, y+1 with even y); H even.
 __global__ void __launch_bounds__(256)
 stereo_warp_fast_halftab(const uint8_t* __restrict__ rgb, const float* __restrict__ depth,
@@ -716,9 +964,17 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
             hipLaunchKernelGGL(stereo_warp_fast_halftab, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
         } else {
             long rows = (long)H * batch;
-            long rounds = (rows * tiles_x + 256 * 6 - 1) / (256 * 6);   // balanced persistent grid: every block walks `rounds` rows
+            static const bool no_lanes = getenv("D2S_WARP_LANES") && atoi(getenv("D2S_WARP_LANES")) == 0;     // (A/B switch for tests)
+            const bool lanes = !no_lanes && (W % 64 == 0) && (g.mode == D2S_MODE_FULL_SBS || g.mode == D2S_MODE_FULL_TAB) &&
+                               (long)dw * FP_TW <= 500L * W;              // <= WL_DN * 256 depth columns under a column tile
+            const int bpc = lanes ? 4 : 6;                                // resident blocks per CU (3 / 6 / 8 measured slower for lanes)
+            long rounds = (rows * tiles_x + 256 * bpc - 1) / (256 * bpc);   // balanced persistent grid: every block walks `rounds` rows
             dim3 pgrid((unsigned)((rows + rounds - 1) / rounds), tiles_x);
-            if (g.mode == D2S_MODE_FULL_SBS)
+            if (lanes && g.mode == D2S_MODE_FULL_SBS)
+                hipLaunchKernelGGL(stereo_warp_lanes<D2S_MODE_FULL_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+            else if (lanes)
+                hipLaunchKernelGGL(stereo_warp_lanes<D2S_MODE_FULL_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+            else if (g.mode == D2S_MODE_FULL_SBS)
                 hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
             else if (g.mode == D2S_MODE_FULL_TAB)
                 hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
