@@ -93,6 +93,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     // its source chunk is the same for every instruction i (rows differ by multiples of RPI*NW,
     // which the row swizzle's period divides)
     static_assert((RPI * NW) % 16 == 0, "row swizzle must be invariant across a thread's instructions");
+    static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0 && BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "tile must split evenly over the waves");
     const int lrow = wid * RPI + lane / CPR;
     const int src_chunk = (lane % CPR) ^ swz_row<CPR>(lrow);
     const T* zero = (const T*)d2s_zero_page;
@@ -547,6 +548,9 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     else if (tile == 128) launch_glds<T, 128, 128, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 64) launch_glds<T, 64, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 3264) launch_glds<T, 32, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
+    // (One-round shapes for M = 778 -- 48 x 64, 96 x 64, 48 / 96 / 80 / 112 x 128, 112 x 96: 108-240 blocks of 2-4 waves, fewer
+    //  fill bytes per CU than two rounds of a small tile -- were instantiated and swept at batch 1: 1.2-4 x SLOWER than the
+    //  32 x 64 / 64 x 64 / 64 x 128 tiles on every encoder linear.  Resident waves per CU decide the fill rate a CU reaches.)
     // LDS-DMA, 8 waves, two stages: the winners of the second sweep (profiles/r1_05), code <BM><BN>8
     else if (tile == 1281288) launch_glds<T, 128, 128, 2, 4, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);    // wave tile 64 x 32, 2 blocks / CU
     else if (tile == 641288) launch_glds<T, 64, 128, 2, 4, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);      // 3 blocks / CU
