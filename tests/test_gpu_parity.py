@@ -339,6 +339,28 @@ def test_gemm_probe(dev):
             assert np.abs(got - refb).max() <= 2e-4 * np.sqrt(K / 64) + 1e-3, (M, N, K, tile, "bf16", np.abs(got - refb).max())
 
 
+def test_gemm_pp_probe(dev):
+    """The 256 x 256 ping-pong kernel (tile code 256256; what the engine picks for the batched encoder linears) vs a float64
+    product of the rounded operands: ragged M (rows past M are dropped by the buffer range check), one and several tiles per
+    CU, bf16 and e4m3 operands; every repeat bit-identical (a race in the hand-counted vmcnt / barrier schedule shows up
+    as run-to-run differences)."""
+    from desktop2stereo_amd import ops
+    torch.manual_seed(0)
+    for prec, cast in (("bf16", torch.bfloat16), ("fp8", torch.float8_e4m3fn)):
+        for (M, N, K) in [(700, 512, 256), (3112, 768, 3072), (12448, 3072, 768), (24896, 768, 768), (513, 1024, 512)]:
+            A = torch.randn(M, K, device=dev) * 0.5
+            W = torch.randn(N, K, device=dev) * 0.5
+            A[:, 0] += torch.arange(M, device=dev) % 7 * 0.25          # asymmetric: catches transposes / row permutations
+            W[:, 1] += torch.arange(N, device=dev) % 5 * 0.25
+            b = torch.randn(N, device=dev)
+            want = (A.to(cast).double() @ W.to(cast).double().T + b.double()).float()
+            first = ops.gemm_probe(A, W, b, prec, 256256)
+            err = ((first - want).abs().max() / want.abs().max()).item()
+            assert err <= (2e-5 if prec == "bf16" else 2e-3), (prec, M, N, K, err)     # e4m3: per-tensor scales of the probe
+            for _ in range(3):
+                assert torch.equal(ops.gemm_probe(A, W, b, prec, 256256), first), (prec, M, N, K, "not reproducible")
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def tiny_fp32(dev):
