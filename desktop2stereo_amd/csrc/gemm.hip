@@ -525,6 +525,10 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
         const int prec = std::is_same<T, bf16_t>::value ? D2S_PREC_BF16 : D2S_PREC_FP8_OPERANDS;
         if (tile == 0 && pp_min_tiles > 0 && (long)cdiv(M, 256) * cdiv(N, 256) >= pp_min_tiles && pp_supported(prec, a, M, N, K, Kpad, e))
             return launch_gemm_pp(prec, a, W, M, N, K, Kpad, e, 1, st);
+        // (Tile rounding, batch 32: 294 tiles of N = 768 pay a second round for 38 tiles.  Giving the ping-pong kernel only the
+        //  tile rows that fill whole rounds and the remaining 3136 rows to the small-tile kernel -- two launches, disjoint rows --
+        //  was built and measured: FC2 156 -> 148 us, proj unchanged; the small-tile kernel needs as long for those rows as the
+        //  half-empty round.  Removed.)
     }
     if (tile == 0) {
         // Measured on the ViT-B shapes at batch 1..32 (tools/gemm_bench.py, profiles/r1_05): what matters most is 16-24
