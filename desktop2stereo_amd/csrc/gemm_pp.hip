@@ -45,6 +45,7 @@
 // share A row panels and W column panels in that XCD's L2.  The next tile's first twelve pieces are issued INSIDE the
 // epilogue of the current one, and the tile starts on a counted vmcnt that lets the epilogue's own stores stay in flight
 // (vmcnt retires in order on gfx9).
+// Tile rounding: see the unit lists in the kernel (K-split tail units + pp_tail_reduce_kernel for long-K residual launches).
 // (Tried and removed, measured on MI355X: (a) stream-K -- equal K-tile ranges per CU, partial tiles exchanged through fp32
 // slabs with agent-scope flags: correct and deterministic, but the slab round trip and the 2-3x wider spread of an XCD's
 // CUs over the tile walk cost more than the rounding of tiles / CUs saves on these shapes (QKV at batch 32: 848 -> 697
@@ -148,7 +149,7 @@ __device__ __forceinline__ f32x4 pp_act4(f32x4 v) {
 // and pinned (one exposed L2 latency per tile); after the hook only stores and the ring's refills are issued.
 // LDS patch rows are 128 bytes = 8 chunks, chunk index XOR (row & 7) on both sides.  Wave-private: no barrier, the LDS ops
 // of one wave execute in order.
-template <int MODE, int ACT, bool DEQ, bool RES, typename HOOK>
+template <int MODE, int ACT, bool DEQ, bool RES, bool IDENT = false, typename HOOK>
 __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& e, int bm0, int bn0, int M, int grp, int wn,
                                             int lane, u32x4* stg, HOOK&& hook) {
 #define PP_QUAD(I, J, Q4) (f32x4){acc[I][J][4 * (Q4) + 0], acc[I][J][4 * (Q4) + 1], acc[I][J][4 * (Q4) + 2], acc[I][J][4 * (Q4) + 3]}
@@ -184,10 +185,13 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
             for (int r = 0; r < 4; ++r)
                 res[p % PP_RING][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo + ((i * 32 + r * 8) * ldc + j * 32) * 4u, 0, 0));
         };
-        col_load(std::integral_constant<int, 0>{});
+        // IDENT: raw accumulators (the partial sums of a K split go to their slab untouched)
+        if constexpr (!IDENT) col_load(std::integral_constant<int, 0>{});
         if constexpr (RES) static_for<PP_RING>([&](auto pc) { res_load(pc); });
+        if constexpr (!IDENT) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { PP_PIN4(ca[0][q]); PP_PIN4(cc[0][q]); }
+            for (int q = 0; q < 4; ++q) { PP_PIN4(ca[0][q]); PP_PIN4(cc[0][q]); }
+        }
         if constexpr (RES) {
 #pragma unroll
             for (int p = 0; p < PP_RING; ++p)
@@ -200,7 +204,8 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
             constexpr int j = p >> 2, i = p & 3;
             static_for<4>([&](auto qc) {
                 constexpr int q4 = decltype(qc)::value;
-                const f32x4 v = PP_QUAD(i, j, q4) * ca[j][q4] + cc[j][q4];
+                f32x4 v = PP_QUAD(i, j, q4);
+                if constexpr (!IDENT) v = v * ca[j][q4] + cc[j][q4];
                 stg[fl * 8 + ((2 * q4 + kg) ^ (fl & 7))] = __builtin_bit_cast(u32x4, v);
             });
 #pragma unroll
@@ -212,7 +217,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
             }
             asm volatile("" ::: "memory");                        // (keeps the ring PP_RING passes deep: no hoisting of later loads)
             if constexpr (RES && p + PP_RING < 8) res_load(std::integral_constant<int, p + PP_RING>{});
-            if constexpr (p == 1) col_load(std::integral_constant<int, 1>{});     // two more passes until the other column half
+            if constexpr (p == 1 && !IDENT) col_load(std::integral_constant<int, 1>{});     // two more passes until the other column half
         });
         return;
     } else {
@@ -298,7 +303,7 @@ enum { PP_K_BF16 = 0, PP_K_GELU = 1, PP_K_QKV = 2, PP_K_F32 = 3 };     // epilog
 template <typename T, int KIND>
 __global__ void __launch_bounds__(512)
 gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn /* log2 */,
-               int skew_us) {
+               int skew_us, int tw /* whole tiles */, int ks /* K splits of the remaining tiles */, int kps /* K tiles per split */) {
     constexpr int ES = (int)sizeof(T);
     constexpr int BK = 128 / ES;                                    // K elements per tile
     constexpr bool DEQ = ES == 1;                                   // e4m3 operands: the accumulator is de-quantised per column
@@ -311,9 +316,15 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
     const int nkt = K / BK;                                          // K tiles per output tile: even, >= 2
     const int cpx = gridDim.x >> 3, xcd = blockIdx.x & 7;
-    int run0 = 0, ntl = 0;                                           // this XCD's run of the tile sequence
-    pp_run(xcd, tiles_m * tiles_n, run0, ntl);
-    int tl = blockIdx.x >> 3;                                        // this block's position in it
+    // This XCD's units: its run of the `tw` whole tiles, then (fp32-residual launches only) its run of the K-split units of the
+    // remaining tiles.  Tile rounding: one tile per CU per round, so 294 tiles (batch 32, N = 768) would pay a whole second
+    // round for 38 tiles; instead those 38 are cut into ks K ranges each (228 units, one short round) whose raw partial sums
+    // go to fp32 slabs [unit][256][256] and are summed + finished by pp_tail_reduce_kernel.
+    int runA = 0, nA = 0, runB = 0, nB = 0;
+    pp_run(xcd, tw, runA, nA);
+    if constexpr (KIND == PP_K_F32) pp_run(xcd, (tiles_m * tiles_n - tw) * ks, runB, nB);
+    const int ntl = nA + nB;
+    int tl = blockIdx.x >> 3;                                        // this block's position in its XCD's unit list
     if (tl >= ntl) return;
     PP_STAMP(0)
     int stamp_ = 1; (void)stamp_;
@@ -340,7 +351,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         }
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
-    constexpr int kt0 = 0;
+    int kt0 = 0;                                  // first K tile of the unit whose operands are being requested
     // per-lane source offsets of a tile: the lane that owns LDS slot (row r, physical chunk lc) fetches chunk lc ^ ((r >> 1) & 7)
 #define PP_SET_TILE(BM0, BN0, LANE)                                                                                         \
     _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                            \
@@ -431,9 +442,17 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         PP_MFMA(1, 0, fZ, fY, fw[P]) pp_barrier();                                                                           \
     }
 
-    // ---- this block's tiles
-    int tm_ = 0, tn_ = 0;
-    pp_tile_of(run0 + tl, tiles_m, tiles_n, xn, tm_, tn_);
+    // ---- this block's units.  unit j of the list -> (tile, first K tile, K tiles, slab index or -1)
+    auto unit_of = [&](int j, int& tm, int& tn, int& k0, int& nk, int& slab) {
+        if (KIND != PP_K_F32 || j < nA) { pp_tile_of(runA + j, tiles_m, tiles_n, xn, tm, tn); k0 = 0; nk = nkt; slab = -1; }
+        else {
+            const int u = runB + (j - nA), tt = u / ks;
+            pp_tile_of(tw + tt, tiles_m, tiles_n, xn, tm, tn);
+            k0 = (u - tt * ks) * kps; nk = kps; slab = u;
+        }
+    };
+    int tm_ = 0, tn_ = 0, nkt_u = nkt, slab_u = -1;
+    unit_of(tl, tm_, tn_, kt0, nkt_u, slab_u);
     PP_SET_TILE(tm_ * 256, tn_ * 256, lane)
     PP_PROLOGUE()
     pp_wait_vm<6>();                                // first tile: A_m0[0], W_n0[0], W_n1[0] of this wave have landed
@@ -454,8 +473,8 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         // behind an epilogue the first three waits leave its (>= PP_TAIL) stores in flight: they sit between the prologue's
         // pieces and the ones issued here, and a plain vmcnt(6) would wait for their round trip to HBM
         asm volatile("" : "+s"(kt));                // (a literal K tile index would put sixteen hoisted LDS addresses in VGPRs)
-        if (after_epi && nkt >= 4) { PP_TILE(kt, 2, 0, PP_TAIL) PP_TILE(kt + 1, 2, 1, 0) kt += 2; }
-        for (; kt + 2 < nkt; kt += 2) { PP_TILE(kt, 2, 0, 0) PP_TILE(kt + 1, 2, 1, 0) }
+        if (after_epi && nkt_u >= 4) { PP_TILE(kt, 2, 0, PP_TAIL) PP_TILE(kt + 1, 2, 1, 0) kt += 2; }
+        for (; kt + 2 < nkt_u; kt += 2) { PP_TILE(kt, 2, 0, 0) PP_TILE(kt + 1, 2, 1, 0) }
         PP_TILE(kt, 1, 0, 0)
         PP_TILE(kt + 1, 0, 1, 0)
         if (grp == 0) pp_barrier();                 // same barrier count for both groups; every fragment read has returned
@@ -463,8 +482,9 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         // next tile of this block
         const int ntl_next = tl + cpx;
         const bool more = ntl_next < ntl;
-        int ntm = 0, ntn = 0;
-        if (more) pp_tile_of(run0 + ntl_next, tiles_m, tiles_n, xn, ntm, ntn);
+        int ntm = 0, ntn = 0, nk0 = 0, nnk = nkt, nslab = -1;
+        if (more) unit_of(ntl_next, ntm, ntn, nk0, nnk, nslab);
+        kt0 = nk0;                                  // (the K loop of this unit is over: from here on kt0 serves the hook's prologue)
         // ---- epilogue.  Its operands pass through an empty asm so that nothing of it is loop-invariant to the compiler:
         // hoisted out of the persistent loop, the epilogue's addresses and column vectors would live (and spill) across the K loop
         GemmEpi el = e;
@@ -482,7 +502,12 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         auto hook = [&]() { if (more) { PP_SET_TILE(ntm * 256, ntn * 256, lane_e) PP_PROLOGUE() } };
         {
             if constexpr (KIND == PP_K_F32) {
-                if (e.res1) pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+                if (slab_u >= 0) {                  // a K split of a tail tile: raw partial sums to the unit's slab
+                    GemmEpi es = el;
+                    es.out = (char*)e.part + (size_t)slab_u * (65536 * 4);
+                    es.ldc = 256;
+                    pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, false, true>(acc, es, 0, 0, 256, grp, wn, lane_e, stg, hook);
+                } else if (e.res1) pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
                 else pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
             }
             else if constexpr (KIND == PP_K_GELU) pp_epilogue<PP_EP_BF16, ACT_GELU, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
@@ -496,7 +521,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         pp_wait_vm<6 + PP_TAIL>();                  // the first six pieces of the next segment have landed
         PP_STAMP(stamp_ + 3)
         stamp_ += 4;
-        tl = ntl_next; tm_ = ntm; tn_ = ntn;
+        tl = ntl_next; tm_ = ntm; tn_ = ntn; nkt_u = nnk; slab_u = nslab;
         after_epi = true;
     }
 #undef PP_TILE
@@ -507,6 +532,23 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
 #undef PP_ISSUE_W
 #undef PP_PROLOGUE
 #undef PP_SET_TILE
+}
+
+// second pass of a launch with K-split tail tiles: sum the ks slabs of each tail tile and run the fused epilogue once
+template <typename T>
+__global__ void __launch_bounds__(256)
+pp_tail_reduce_kernel(GemmEpi e, int M, int N, int tw, int ks, int lxn) {
+    const int tt = blockIdx.x >> 6;                                 // 64 blocks of 256 threads per 256 x 256 tile, 4 columns per thread
+    const int q = (blockIdx.x & 63) * 256 + threadIdx.x;
+    const int r = q >> 6, c = (q & 63) * 4;
+    int tm = 0, tn = 0;
+    pp_tile_of(tw + tt, (M + 255) / 256, (N + 255) / 256, lxn, tm, tn);
+    const int m = tm * 256 + r, n0 = tn * 256 + c;
+    if (m >= M) return;
+    const float* p = e.part + (size_t)tt * ks * 65536 + r * 256 + c;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ks; ++s) { float t[4]; load4(p + (size_t)s * 65536, t); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+    epilogue_dispatch<T>(e, m, n0, v);
 }
 
 // tile code 256256: the ping-pong kernel.  Requirements: plain row-major A, no ReLU-on-load, an even number (>= 2) of whole K
@@ -558,7 +600,20 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
     // one 160-KiB block per CU, cpx blocks per XCD (blocks beyond an XCD's list exit at once)
     static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
     const int lxn = xn <= 1 ? 0 : (xn == 2 ? 1 : (xn == 4 ? 2 : 3));
-    const int list_max = cdiv(tiles_m * tiles_n, 8);                     // longest XCD run
+    const int kind = e.out_type == OUT_F32 ? PP_K_F32 : (e.map == MAP_QKV ? PP_K_QKV : (e.act == ACT_GELU ? PP_K_GELU : PP_K_BF16));
+    // K-split tail (see the kernel): when the last round would be less than 45 % full and the launch is a residual update
+    const int tiles = tiles_m * tiles_n, nkt = K / (128 / (int)elem_size(precision));
+    int tw = tiles, ks = 1, kps = nkt;
+    static const int split_pct = getenv("D2S_PP_SPLIT") ? atoi(getenv("D2S_PP_SPLIT")) : 45;
+    // (only for long K loops: the slab round trip + the second launch cost ~30 us, a 12-K-tile round of proj costs 25 --
+    //  measured at batch 32: FC2 164 -> 144 us, proj 65 -> 71)
+    if (kind == PP_K_F32 && e.part && split_pct > 0 && nkt >= 24) {
+        const int rounds = tiles / ncu, rem = tiles - rounds * ncu;
+        if (rounds >= 1 && rem > 0 && rem * 100 <= split_pct * ncu)
+            for (int s = 8; s >= 2; --s)
+                if (nkt % (2 * s) == 0 && nkt / s >= 4 && rem * s <= ncu && (size_t)rem * s * 65536 <= e.part_elems) { ks = s; kps = nkt / s; tw = tiles - rem; break; }
+    }
+    const int list_max = cdiv(tw, 8) + (ks > 1 ? cdiv((tiles - tw) * ks, 8) : 0);      // longest XCD unit list
     const unsigned grid = 8u * (unsigned)std::max(1, std::min(ncu / 8, list_max));
     GemmEpi e1 = e;
     e1.ksplit = 1;
@@ -568,9 +623,9 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
     if (!e1.bias || !e1.scale || !e1.deq) { set_error("launch_gemm_pp: constant vectors"); return D2S_E_HIP; }
     // half a tile time: K tiles x ~1.5 us + ~8 us of prologue / epilogue (D2S_PP_SKEW: percent of that; 0 = off)
     static const int skew_pct = getenv("D2S_PP_SKEW") ? atoi(getenv("D2S_PP_SKEW")) : 50;
-    const int skew_us = (int)((K / (128 / (int)elem_size(precision)) * 1.5 + 8.0) * skew_pct / 100.0);
-    const int kind = e.out_type == OUT_F32 ? PP_K_F32 : (e.map == MAP_QKV ? PP_K_QKV : (e.act == ACT_GELU ? PP_K_GELU : PP_K_BF16));
-#define PP_LAUNCH(T_, KIND_) hipLaunchKernelGGL((gemm_pp_kernel<T_, KIND_>), dim3(grid), dim3(512), 0, st, (const T_*)a.ptr, a.lda, (const T_*)W, M, N, K, Kpad, e1, lxn, skew_us)
+    // (with a K-split tail the lists end in short units: a block without one is not half a tile "lighter")
+    const int skew_us = ks > 1 ? 0 : (int)((K / (128 / (int)elem_size(precision)) * 1.5 + 8.0) * skew_pct / 100.0);
+#define PP_LAUNCH(T_, KIND_) hipLaunchKernelGGL((gemm_pp_kernel<T_, KIND_>), dim3(grid), dim3(512), 0, st, (const T_*)a.ptr, a.lda, (const T_*)W, M, N, K, Kpad, e1, lxn, skew_us, tw, ks, kps)
     if (precision == D2S_PREC_BF16) {
         if (kind == PP_K_F32) PP_LAUNCH(bf16_t, PP_K_F32); else if (kind == PP_K_QKV) PP_LAUNCH(bf16_t, PP_K_QKV);
         else if (kind == PP_K_GELU) PP_LAUNCH(bf16_t, PP_K_GELU); else PP_LAUNCH(bf16_t, PP_K_BF16);
@@ -580,6 +635,14 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
     }
 #undef PP_LAUNCH
     D2S_CHECK_LAUNCH();
+    if (ks > 1) {
+        GemmEpi e2 = e;
+        e2.ksplit = 1;
+        const unsigned rgrid = (unsigned)(tiles - tw) * 64u;
+        if (precision == D2S_PREC_BF16) hipLaunchKernelGGL((pp_tail_reduce_kernel<bf16_t>), dim3(rgrid), dim3(256), 0, st, e2, M, N, tw, ks, lxn);
+        else hipLaunchKernelGGL((pp_tail_reduce_kernel<fp8_t>), dim3(rgrid), dim3(256), 0, st, e2, M, N, tw, ks, lxn);
+        D2S_CHECK_LAUNCH();
+    }
     return D2S_OK;
 }
 
