@@ -331,6 +331,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     // Blocks that walk one tile fewer than the busiest of their XCD start late by about half a tile time: it costs nothing
     // (they finish before the others anyway) and it takes them out of the store bursts -- a lock-step grid dumps 128 KiB
     // per CU at the same instant, that drains in ~8 us, and every CU sits on vmcnt behind its own stores meanwhile.
+    // (A further phase shift of x us per XCD, to spread the store bursts of the epilogues: x = 1 -> -2 us per launch, x = 2..3 -> worse.)
     if (skew_us > 0 && (ntl - 1 - tl) / cpx < (ntl - 1) / cpx)
         for (int i = 0; i < skew_us; ++i) __builtin_amdgcn_s_sleep(32);        // ~1 us each (64 x 32 cycles)
 
