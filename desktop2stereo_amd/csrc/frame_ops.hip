@@ -534,7 +534,7 @@ stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ de
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lane-strided streaming path (Full-SBS / Full-TAB, W % 64 == 0).  stereo_warp_stream above is VALU-issue bound (~680
+// Lane-strided streaming path (Full-SBS / Full-TAB / Half-TAB, W % 64 == 0).  stereo_warp_stream above is VALU-issue bound (~680
 // instructions per thread-row of 8 output pixels: byte unpacking at every tap, unfused blends, stride-4 LDS taps).  Here
 //   * the source window is unpacked ONCE per row into three float planes (R, G, B) in LDS: a bilinear tap pair is
 //     ds_read_b32 x 2 per channel, no v_cvt_f32_ubyte / mask / shift per tap, and the 12-byte staging groups land as
@@ -569,7 +569,7 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
     __shared__ float drow[2][FP_TW + 8];                                        //  8,256 B
     __shared__ __attribute__((aligned(16))) uint32_t tpose[4][256];            //  4,096 B  -> 4 blocks per CU
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int items = B * g.H;                            // rows of all frames
+    const int items = MODE == D2S_MODE_HALF_TAB ? B * (g.H / 2) : B * g.H;      // rows (row pairs) of all frames
     const float span = (float)(g.W - 1);
     const long per = (long)g.out_h * g.out_w;
 
@@ -631,9 +631,19 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
         }                                                                                     \
     }
 
-    int item = blockIdx.x;
-    if (item >= items) return;
-    int cur_b = item / g.H, cur_y = item - cur_b * g.H;                                     // (one division per block)
+    // Items are rows (Full modes) or row PAIRS (Half-TAB: output row yp = mean of rows 2 yp, 2 yp + 1); a block walks items
+    // it0, it0 + stride, ...; a "step" is one source row, so a pair is two consecutive steps.
+    constexpr bool HALF = MODE == D2S_MODE_HALF_TAB;
+    const int ipf = HALF ? g.H / 2 : g.H;                  // items per frame
+    const int it0 = blockIdx.x;
+    if (it0 >= items) return;
+    const int stride = (int)gridDim.x;
+    const int nsteps = ((items - 1 - it0) / stride + 1) * (HALF ? 2 : 1);
+    int cur_b = it0 / ipf, cur_y = (it0 - cur_b * ipf) * (HALF ? 2 : 1);                     // (one division per block)
+    auto advance = [&](int& rb, int& ry) {                 // (frame, row) of the next step, tracked incrementally
+        if (HALF) ry += (ry & 1) ? 2 * stride - 1 : 1; else ry += stride;
+        while (ry >= g.H) { ry -= g.H; ++rb; }
+    };
     // per-thread column constants: pixel k of this lane, its depth taps (they depend on x only) and whether it exists
     const int wave_x0 = xa + wid * 256;
     int li0[FP_PX], li1[FP_PX];
@@ -650,12 +660,11 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
     const bool interior = wave_x0 >= FP_MARGIN + 2 && wave_x0 + 255 <= g.W - 1 - (FP_MARGIN + 2);
     const int xs = wave_x0 + 4 * lane;                    // first of the 4 consecutive pixels this lane stores
     uint32_t* const tp = tpose[wid];
-    const int stride = (int)gridDim.x;
-    int n1_b = cur_b, n1_y = cur_y + stride;               // (frame, row) of the next two items, tracked incrementally
-    while (n1_y >= g.H) { n1_y -= g.H; ++n1_b; }
-    int n2_b = n1_b, n2_y = n1_y + stride;
-    while (n2_y >= g.H) { n2_y -= g.H; ++n2_b; }
-    bool has1 = item + stride < items, has2 = item + 2 * stride < items;
+    int n1_b = cur_b, n1_y = cur_y; advance(n1_b, n1_y);
+    int n2_b = n1_b, n2_y = n1_y; advance(n2_b, n2_y);
+    int step = 0;
+    bool has1 = 1 < nsteps, has2 = 2 < nsteps;
+    float hold[2][FP_PX][3];                               // Half-TAB: the even row's blended values wait for the odd row
     WL_LOAD(0, cur_b, cur_y)
     WL_LOAD(1, (has1 ? n1_b : cur_b), (has1 ? n1_y : cur_y))
     WL_WAIT(0, 6)
@@ -668,17 +677,18 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
         WL_LOAD(SL, (has2 ? n2_b : cur_b), (has2 ? n2_y : cur_y))                             \
         wl_compute(BUF, cur_b, cur_y);                                                        \
         if (has1) {                                                                           \
-            /* younger than set SS: the 6 loads of set SL and this row's 2 stores (waves with no pixel store nothing).   \
+            /* younger than set SS: the 6 loads of set SL and this row's 2 stores (waves with no pixel, and the even rows of    \
+               Half-TAB, store nothing).                                                                                    \
                (Also letting the PREVIOUS row's 2 stores stay in flight -- vmcnt(10) from the second iteration on -- measured  \
                no faster.) */                                                                                               \
-            if (nk > 0) { WL_WAIT(SS, 8) } else { WL_WAIT(SS, 6) }                            \
+            if (nk > 0 && (!HALF || (cur_y & 1))) { WL_WAIT(SS, 8) } else { WL_WAIT(SS, 6) }  \
             WL_STORE(SS, (BUF) ^ 1)                                                           \
         }                                                                                     \
         wl_sync();                                                                      \
         if (!has1) break;                                                                     \
-        item += stride; cur_b = n1_b; cur_y = n1_y; n1_b = n2_b; n1_y = n2_y;                 \
-        n2_y += stride; while (n2_y >= g.H) { n2_y -= g.H; ++n2_b; }                          \
-        has1 = has2; has2 = item + 2 * stride < items;                                        \
+        ++step; cur_b = n1_b; cur_y = n1_y; n1_b = n2_b; n1_y = n2_y;                         \
+        advance(n2_b, n2_y);                                                                  \
+        has1 = has2; has2 = step + 2 < nsteps;                                                \
     }
     auto wl_compute = [&](int buf, int b, int y) {
         if (nk > 0) {
@@ -696,7 +706,7 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
             const bool easy = interior && __all(small);
 #pragma unroll
             for (int eye = 0; eye < 2; ++eye) {
-                uint32_t pk[FP_PX];
+                float px[FP_PX][3];
                 if (easy) {
 #pragma unroll
                     for (int k = 0; k < FP_PX; ++k) {
@@ -707,9 +717,7 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
                         const wl_f2 ww = {w0, w1};
                         const wl_f2 vr = (wl_f2){p[0], p[1]} * ww, vg = (wl_f2){p[WL_PLANE], p[WL_PLANE + 1]} * ww,
                                     vb = (wl_f2){p[2 * WL_PLANE], p[2 * WL_PLANE + 1]} * ww;
-                        uint32_t u = __builtin_amdgcn_cvt_pk_u8_f32(vr[0] + vr[1], 0, 0);
-                        u = __builtin_amdgcn_cvt_pk_u8_f32(vg[0] + vg[1], 1, u);
-                        pk[k] = __builtin_amdgcn_cvt_pk_u8_f32(vb[0] + vb[1], 2, u);
+                        px[k][0] = vr[0] + vr[1]; px[k][1] = vg[0] + vg[1]; px[k][2] = vb[0] + vb[1];
                     }
                 } else {
                     // branch-free coordinates (at most one reflection per side); one wave-level test decides between the
@@ -734,9 +742,7 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
                             const wl_f2 ww = {w0, w1};
                             const wl_f2 vr = (wl_f2){p0[0], p1[0]} * ww, vg = (wl_f2){p0[WL_PLANE], p1[WL_PLANE]} * ww,
                                         vb = (wl_f2){p0[2 * WL_PLANE], p1[2 * WL_PLANE]} * ww;
-                            uint32_t u = __builtin_amdgcn_cvt_pk_u8_f32(vr[0] + vr[1], 0, 0);
-                            u = __builtin_amdgcn_cvt_pk_u8_f32(vg[0] + vg[1], 1, u);
-                            pk[k] = __builtin_amdgcn_cvt_pk_u8_f32(vb[0] + vb[1], 2, u);
+                            px[k][0] = vr[0] + vr[1]; px[k][1] = vg[0] + vg[1]; px[k][2] = vb[0] + vb[1];
                         }
                     } else {
                         const uint8_t* src_row = rgb + ((long)b * g.H + y) * (long)g.W * 3;
@@ -746,20 +752,35 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
                             const float w1 = sx - (float)x0, w0 = 1.0f - w1;
                             const int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
                             const uint8_t* q0 = src_row + (long)x0 * 3; const uint8_t* q1 = src_row + (long)x1 * 3;
-                            uint32_t u = 0;
-                            u = __builtin_amdgcn_cvt_pk_u8_f32(w0 * (float)q0[0] + w1 * (float)q1[0], 0, u);
-                            u = __builtin_amdgcn_cvt_pk_u8_f32(w0 * (float)q0[1] + w1 * (float)q1[1], 1, u);
-                            pk[k] = __builtin_amdgcn_cvt_pk_u8_f32(w0 * (float)q0[2] + w1 * (float)q1[2], 2, u);
+                            for (int c = 0; c < 3; ++c) px[k][c] = w0 * (float)q0[c] + w1 * (float)q1[c];
                         }
                     }
                 }
+                if (HALF && !(y & 1)) {                   // even row of a pair: keep the blended values (F.interpolate(mode='area') averages floats)
+#pragma unroll
+                    for (int k = 0; k < FP_PX; ++k)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) hold[eye][k][c] = px[k][c];
+                    continue;
+                }
                 // values are convex combinations of bytes: already inside [0,255]; v_cvt_pk_u8_f32 rounds half-even
+                uint32_t pk[FP_PX];
+#pragma unroll
+                for (int k = 0; k < FP_PX; ++k) {
+                    if (HALF) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) px[k][c] = (hold[eye][k][c] + px[k][c]) * 0.5f;
+                    }
+                    uint32_t u = __builtin_amdgcn_cvt_pk_u8_f32(px[k][0], 0, 0);
+                    u = __builtin_amdgcn_cvt_pk_u8_f32(px[k][1], 1, u);
+                    pk[k] = __builtin_amdgcn_cvt_pk_u8_f32(px[k][2], 2, u);
+                }
                 // wave-private transpose: [l + 64 k] -> [4 l .. 4 l + 3], then 4 x RGBX -> 12 bytes
 #pragma unroll
                 for (int k = 0; k < FP_PX; ++k) tp[lane + 64 * k] = pk[k];
                 const uint4 v = *(const uint4*)&tp[4 * lane];
                 if (xs < g.W) {
-                    const long row = (MODE == D2S_MODE_FULL_SBS) ? y : (long)eye * g.H + y;
+                    const long row = MODE == D2S_MODE_FULL_SBS ? y : (MODE == D2S_MODE_FULL_TAB ? (long)eye * g.H + y : (long)eye * (g.H / 2) + (y >> 1));
                     const long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + xs : xs;
                     uint3 w3;
                     w3.x = (v.x & 0x00ffffffu) | (v.y << 24);
@@ -959,14 +980,21 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
     if (fast_ok && g.mode == D2S_MODE_HALF_TAB && (H % 2 != 0)) fast_ok = false;
     if (fast_ok) {
         int tiles_x = cdiv(W, FP_TW);
-        if (g.mode == D2S_MODE_HALF_TAB) {
+        static const bool no_lanes = getenv("D2S_WARP_LANES") && atoi(getenv("D2S_WARP_LANES")) == 0;     // (A/B switch for tests)
+        const bool lanes_ok = !no_lanes && (W % 64 == 0) && (long)dw * FP_TW <= 500L * W;      // <= WL_DN * 256 depth columns under a column tile
+        if (g.mode == D2S_MODE_HALF_TAB && lanes_ok) {
+            long pairs = (long)(H / 2) * batch;
+            long rounds = (pairs * tiles_x + 256 * 4 - 1) / (256 * 4);
+            dim3 pgrid((unsigned)((pairs + rounds - 1) / rounds), tiles_x);
+            hipLaunchKernelGGL(stereo_warp_lanes<D2S_MODE_HALF_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+        } else if (g.mode == D2S_MODE_HALF_TAB) {
             dim3 grid((unsigned)((long)tiles_x * (H / 2) * batch));
             hipLaunchKernelGGL(stereo_warp_fast_halftab, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
         } else {
             long rows = (long)H * batch;
-            static const bool no_lanes = getenv("D2S_WARP_LANES") && atoi(getenv("D2S_WARP_LANES")) == 0;     // (A/B switch for tests)
-            const bool lanes = !no_lanes && (W % 64 == 0) && (g.mode == D2S_MODE_FULL_SBS || g.mode == D2S_MODE_FULL_TAB) &&
-                               (long)dw * FP_TW <= 500L * W;              // <= WL_DN * 256 depth columns under a column tile
+            // (Half-SBS stays on stereo_warp_stream: the lane-strided kernel needs the neighbour lane's values for the 2:1 column
+            //  mean -- 24 cross-lane moves per row -- and measured 117 vs 101 us at batch 16)
+            const bool lanes = lanes_ok && (g.mode == D2S_MODE_FULL_SBS || g.mode == D2S_MODE_FULL_TAB);
             const int bpc = lanes ? 4 : 6;                                // resident blocks per CU (3 / 6 / 8 measured slower for lanes)
             long rounds = (rows * tiles_x + 256 * bpc - 1) / (256 * bpc);   // balanced persistent grid: every block walks `rounds` rows
             dim3 pgrid((unsigned)((rows + rounds - 1) / rounds), tiles_x);
