@@ -62,6 +62,12 @@ namespace d2s {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 (mma64 below; D2S_HIPCC_DEFS=-DPP_FP8_K64=1).  Off: as written it pairs the
+// 16-byte fragment registers into 8-register operand tuples, the allocator cannot keep those pairs adjacent across the
+// pre-read schedule at 256 registers and spills 114-136 dwords inside the K loop.  Needs the fragment arrays declared as tuples.
+#ifndef PP_FP8_K64
+#define PP_FP8_K64 0
+#endif
 constexpr int PP_STAGE = 4096;                 // 16-byte chunks per stage: (256 + 256) rows x 8 chunks
 constexpr int PP_WOFF = 2048;                  // W rows start after the 256 A rows
 
@@ -73,6 +79,15 @@ __device__ __forceinline__ void mma32(f32x16& acc, const u32x4& w, const u32x4& 
     const long* al = (const long*)&a;
     acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(wl[0], al[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(wl[1], al[1], acc, 0, 0, 0);
+}
+// e4m3: two 16-byte chunks of each operand (32 K elements per lane, 64 per instruction) on the scaled K=64 MFMA with unit
+// block scales (E8M0 127 = 2^0) -- twice the rate of v_mfma_f32_32x32x16_fp8_fp8: 4 instructions x 64 cycles per quadrant
+// instead of 16 x 32.  Which K elements a lane holds does not matter as long as both operands hold the same ones.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mma64(f32x16& acc, const u32x4& w0, const u32x4& w1, const u32x4& a0, const u32x4& a1) {
+    const i32x8 w = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
+    const i32x8 a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, a, acc, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
 template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -411,8 +426,13 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
 #define PP_MFMA(QM, QN, FA0, FA1, FW)                                                                                       \
     {                                                                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                                       \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) mma32(acc[(QM) * 2 + 0][QN], FW[ks], FA0[ks], T());                 \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) mma32(acc[(QM) * 2 + 1][QN], FW[ks], FA1[ks], T());                 \
+        if constexpr (ES == 1 && PP_FP8_K64) {                                                                               \
+            _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) mma64(acc[(QM) * 2 + 0][QN], FW[2 * s_], FW[2 * s_ + 1], FA0[2 * s_], FA0[2 * s_ + 1]); \
+            _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) mma64(acc[(QM) * 2 + 1][QN], FW[2 * s_], FW[2 * s_ + 1], FA1[2 * s_], FA1[2 * s_ + 1]); \
+        } else {                                                                                                             \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) mma32(acc[(QM) * 2 + 0][QN], FW[ks], FA0[ks], T());             \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) mma32(acc[(QM) * 2 + 1][QN], FW[ks], FA1[ks], T());             \
+        }                                                                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                                                       \
     }
     // one K tile = 4 phases (see the table on top).  P = tile parity (literal).  ISSUE: 2 = steady state, 1 = second-to-last
