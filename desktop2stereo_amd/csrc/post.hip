@@ -35,7 +35,7 @@ percentile_bounds_kernel(const float* __restrict__ depth, int n, int step, int m
                          float* __restrict__ bounds) {
     constexpr int PER = SORT_N / SORT_THREADS;
     __shared__ unsigned hist[2][256];
-    __shared__ unsigned sel_prefix[2], sel_rank[2];
+    __shared__ unsigned sel_rank[2];
     const float* d = depth + (long)blockIdx.x * n;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     uint32_t key[PER];
@@ -74,23 +74,45 @@ percentile_bounds_kernel(const float* __restrict__ depth, int n, int step, int m
 #pragma unroll
         for (int i = 0; i < PER; ++i) { int idx = tid + i * SORT_THREADS; key[i] = idx < m ? f2key(d[(long)idx * step]) : 0u; }
     }
-    if (tid == 0) {
-        bool all = tail >= m;                                   // depth.py:790-791: (min, max)
-        sel_rank[0] = all ? 0 : tail - 1; sel_rank[1] = all ? m - 1 : m - tail;
-        sel_prefix[0] = sel_prefix[1] = 0;
+    // Range-adaptive radix select.  A fixed 8-bits-from-the-top radix puts all of a depth map's keys (same sign, one or two
+    // exponents) into one or two bins of the first passes -- 6144 LDS atomics on the same address, serialised: 20 us for a
+    // 24 KB problem.  Here a pass bins (key - lo) >> shift with [lo, lo + (256 << shift)) the range that still holds the
+    // target, starting from the block's [min key, max key]: the first pass spreads over all 256 bins, later passes see only
+    // the few keys of the chosen bin.  Exact: the binning is monotone in the key.
+    __shared__ unsigned red_min[SORT_THREADS / 64], red_max[SORT_THREADS / 64];
+    __shared__ unsigned sel_lo[2], sel_shift;
+    {
+        unsigned kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if (tid + i * SORT_THREADS < m) { kmin = min(kmin, key[i]); kmax = max(kmax, key[i]); }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o)); kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o)); }
+        if (lane == 0) { red_min[wid] = kmin; red_max[wid] = kmax; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < SORT_THREADS / 64; ++w) { kmin = min(kmin, red_min[w]); kmax = max(kmax, red_max[w]); }
+            if (m <= 0) { kmin = kmax = 0u; }
+            const unsigned span = kmax - kmin;
+            const int bits = span ? 32 - __clz((int)span) : 0;              // span < 2^bits
+            sel_shift = bits > 8 ? bits - 8 : 0;
+            sel_lo[0] = sel_lo[1] = kmin;
+            bool all = tail >= m;                                   // depth.py:790-791: (min, max)
+            sel_rank[0] = all ? 0 : tail - 1; sel_rank[1] = all ? m - 1 : m - tail;
+        }
+        __syncthreads();
     }
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
+    while (true) {
+        const unsigned shift = sel_shift;
         if (tid < 512) hist[tid >> 8][tid & 255] = 0;
         __syncthreads();
-        const unsigned p0 = sel_prefix[0], p1 = sel_prefix[1];
+        const unsigned l0 = sel_lo[0], l1 = sel_lo[1];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             if (tid + i * SORT_THREADS < m) {
-                unsigned hi = pass == 0 ? 0u : key[i] >> (shift + 8);
-                unsigned bin = (key[i] >> shift) & 255u;
-                if (hi == p0) atomicAdd(&hist[0][bin], 1u);
-                if (hi == p1) atomicAdd(&hist[1][bin], 1u);
+                const unsigned d0 = key[i] - l0, d1 = key[i] - l1;           // (unsigned: keys below lo wrap to huge values)
+                if (key[i] >= l0 && (d0 >> shift) < 256u) atomicAdd(&hist[0][d0 >> shift], 1u);
+                if (key[i] >= l1 && (d1 >> shift) < 256u) atomicAdd(&hist[1][d1 >> shift], 1u);
             }
         }
         __syncthreads();
@@ -103,14 +125,17 @@ percentile_bounds_kernel(const float* __restrict__ depth, int n, int step, int m
             if (target >= excl && target < incl) {
                 unsigned r = target - excl, bin;
                 if (r < c0) bin = 0; else if ((r -= c0) < c1) bin = 1; else if ((r -= c1) < c2) bin = 2; else { r -= c2; bin = 3; }
-                sel_prefix[wid] = (sel_prefix[wid] << 8) | (4 * lane + bin);
+                sel_lo[wid] += (4 * lane + bin) << shift;
                 sel_rank[wid] = r;
             }
         }
         __syncthreads();
+        if (shift == 0) break;
+        if (tid == 0) sel_shift = shift > 8 ? shift - 8 : 0;
+        __syncthreads();
     }
     if (tid == 0) {
-        float lo = key2f(sel_prefix[0]), hi = key2f(sel_prefix[1]);
+        float lo = key2f(sel_lo[0]), hi = key2f(sel_lo[1]);
         if (nvalid <= 10) { lo = 0.f; hi = 0.f; }                // depth.py:852-854
         bounds[2 * blockIdx.x] = lo;
         bounds[2 * blockIdx.x + 1] = hi;
