@@ -913,6 +913,9 @@ extern "C" int d2s_engine_calibrate(d2s_engine* e, const float* x, int batch, vo
     e->calib = false;
     e->prof_on = prof;
     if (rc != D2S_OK) return rc;
+    // headroom over the calibration frames' maxima (D2S_FP8_HEADROOM, default 1: later frames with larger activations
+    // saturate at +-448 instead of wrapping; 1.25-1.5 trades a fraction of a bit of resolution for that margin)
+    static const float headroom = getenv("D2S_FP8_HEADROOM") ? std::max(1.0f, (float)atof(getenv("D2S_FP8_HEADROOM"))) : 1.0f;
     std::vector<float> am((size_t)L * NSITE);
     D2S_HIP(hipMemcpyAsync(am.data(), e->amax, am.size() * sizeof(float), hipMemcpyDeviceToHost, st));
     D2S_HIP(hipStreamSynchronize(st));
@@ -921,7 +924,7 @@ extern "C" int d2s_engine_calibrate(d2s_engine* e, const float* x, int batch, vo
         for (int s = 0; s < NSITE; ++s) {
             float a = am[(size_t)l * NSITE + s];
             if (!(a > 0.f) || !std::isfinite(a)) { set_error("d2s_engine_calibrate: degenerate activation range"); return D2S_E_INVALID; }
-            e->act_scale[(size_t)l * NSITE + s] = a / FP8_MAX;
+            e->act_scale[(size_t)l * NSITE + s] = a * headroom / FP8_MAX;
         }
         for (int i = 0; i < 4; ++i) {                         // linear i reads site i (qkv <- LN1, proj <- attention, fc1 <- LN2, fc2 <- GELU)
             std::vector<float> dq(ly.sw[i].size());

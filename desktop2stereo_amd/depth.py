@@ -112,6 +112,23 @@ def _ensure_engine_built(engine_h: int, engine_w: int, first_x: Optional[torch.T
     return _state["engine"]
 
 
+def calibrate(frames) -> None:
+    """fp8 engines: (re)set the static e4m3 activation scales from REPRESENTATIVE frames (uint8 HWC / [B,H,W,3], numpy or
+    tensor, all of one size; up to max_batch of them are used) instead of whatever frame happened to arrive first -- a black
+    or splash first desktop frame gives ranges later frames saturate.  Builds the engine for that frame size if needed.
+    D2S_FP8_HEADROOM (>= 1) widens every range.  No reference counterpart (the reference has FP16 only)."""
+    if _state["precision"] != "fp8":
+        raise _lib.D2SError("calibrate(): the engine is not configured with precision='fp8'")
+    t = torch.from_numpy(np.ascontiguousarray(frames)) if isinstance(frames, np.ndarray) else frames
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    t = t.to(device=_device())
+    p = _state["params"]
+    x = ops.preprocess(t, p.depth_resolution, _state["cfg"].patch, p.mean, p.std, p.resample)
+    eng = _ensure_engine_built(int(x.shape[2]), int(x.shape[3]), x)
+    eng.calibrate(x[: _state["max_batch"]])
+
+
 def _fp8_first_inputs(frames_u8: torch.Tensor, key) -> Optional[torch.Tensor]:
     """Model inputs of the first batch, only when an fp8 engine is about to be built (calibration data)."""
     if _state["precision"] != "fp8" or (_state["engine"] is not None and _state["engine_key"] == key):

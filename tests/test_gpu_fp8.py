@@ -91,5 +91,11 @@ def test_fp8_through_the_call_surface(dev):
         D.configure("tiny", params=PipelineParams(depth_resolution=140), precision="fp8", max_batch=2)
         out = D.pipeline(np.stack([f, synth.structured_frame(270, 480, 6)]), display_mode="Half-TAB")
         assert tuple(out.shape) == (2, 270, 480, 3) and out.dtype == torch.uint8
+        # explicit calibration on representative frames instead of "whatever arrived first": a black first frame would have
+        # left ranges that real frames saturate; after calibrate() on two structured frames the result is the same class
+        D.configure("tiny", params=PipelineParams(depth_resolution=140), precision="fp8", max_batch=2)
+        D.calibrate(np.stack([f, synth.structured_frame(270, 480, 6)]))
+        d2 = D.predict_depth(f, use_temporal_smooth=False).cpu().numpy()
+        assert np.abs(d2 - ref).mean() <= 0.05
     finally:
         D.configure("tiny", params=PipelineParams(depth_resolution=140), precision="fp32", max_batch=4)
