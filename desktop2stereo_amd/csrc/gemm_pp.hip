@@ -102,11 +102,13 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // tuning aid (build with D2S_HIPCC_DEFS=-DD2S_PP_TIMING): wave 0 of every block stamps the 100 MHz wall clock at kernel entry
 // and, per tile, at main-loop start / main-loop end / epilogue end / next tile's operands landed; tools/pp_timeline.py reads them
 #ifdef D2S_PP_TIMING
-__device__ unsigned long long pp_timing[256 * 64];
+__device__ unsigned long long pp_timing[(256 + 8) * 64];              // rows 256..263: the eight waves of block 8
 __device__ int pp_timing_kind = -1;
 #define PP_STAMP(SLOT) { if (tid == 0 && KIND == pp_timing_kind && (SLOT) < 64) pp_timing[blockIdx.x * 64 + (SLOT)] = wall_clock64(); }
+#define PP_WSTAMP(SLOT) { if (lane == 0 && blockIdx.x == 8 && KIND == pp_timing_kind && (SLOT) < 64) pp_timing[(256 + wid) * 64 + (SLOT)] = wall_clock64(); }
 #else
 #define PP_STAMP(SLOT)
+#define PP_WSTAMP(SLOT)
 #endif
 
 // exact-erf GELU on two values at once: the Abramowitz-Stegun 7.1.26 form of gelu_erf (gemm_epi.h) on 2-vectors, so that the
@@ -500,6 +502,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         PP_TILE(kt + 1, 0, 1, 0)
         if (grp == 0) pp_barrier();                 // same barrier count for both groups; every fragment read has returned
         PP_STAMP(stamp_ + 1)
+        PP_WSTAMP(stamp_ + 1)
         // next tile of this block
         const int ntl_next = tl + cpx;
         const bool more = ntl_next < ntl;
@@ -538,6 +541,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
             } else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
         }
         PP_STAMP(stamp_ + 2)
+        PP_WSTAMP(stamp_ + 2)
         if (!more) break;
         pp_wait_vm<6 + PP_TAIL>();                  // the first six pieces of the next segment have landed
         PP_STAMP(stamp_ + 3)
@@ -670,10 +674,10 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
 }  // namespace d2s
 
 #ifdef D2S_PP_TIMING
-extern "C" int d2s_pp_timing(int kind, unsigned long long* out) {      // kind >= 0: select + clear; out != null: read 256 x 64 stamps
+extern "C" int d2s_pp_timing(int kind, unsigned long long* out) {      // kind >= 0: select + clear; out != null: read 264 x 64 stamps
     if (kind >= -1) { if (hipMemcpyToSymbol(HIP_SYMBOL(d2s::pp_timing_kind), &kind, sizeof(int)) != hipSuccess) return 1; }
-    if (out) return hipMemcpyFromSymbol(out, HIP_SYMBOL(d2s::pp_timing), sizeof(unsigned long long) * 256 * 64) != hipSuccess;
-    static unsigned long long zeros[256 * 64];
+    if (out) return hipMemcpyFromSymbol(out, HIP_SYMBOL(d2s::pp_timing), sizeof(unsigned long long) * 264 * 64) != hipSuccess;
+    static unsigned long long zeros[264 * 64];
     return hipMemcpyToSymbol(HIP_SYMBOL(d2s::pp_timing), zeros, sizeof(zeros)) != hipSuccess;
 }
 #endif

@@ -36,9 +36,10 @@ for kind in (2, 1, 3):
     assert lib.d2s_pp_timing(kind, None) == 0
     eng.pipeline(frames, p, sp, use_ema=False, out=out)
     torch.cuda.synchronize()
-    buf = np.zeros(256 * 64, dtype=np.uint64)
+    buf = np.zeros(264 * 64, dtype=np.uint64)
     assert lib.d2s_pp_timing(-2, buf.ctypes.data_as(C.c_void_p)) == 0
-    t = buf.reshape(256, 64).astype(np.float64) * 0.01            # us (100 MHz)
+    tw = buf.reshape(264, 64).astype(np.float64)[256:] * 0.01     # per-wave stamps of block 8
+    t = buf.reshape(264, 64).astype(np.float64)[:256] * 0.01      # us (100 MHz)
     live = t[:, 0] > 0
     t0 = t[live, 0].min()
     print(f"== kind {kind}: {names[kind]}  (last such launch of the frame; {int(live.sum())} blocks)")
@@ -57,6 +58,12 @@ for kind in (2, 1, 3):
         print(line)
     end = np.where(t[:, 1:] > 0, t[:, 1:], 0).max(axis=1)
     print(f"   block end: mean {end[live].mean() - t0:7.2f}  max {end[live].max() - t0:7.2f} us after the first block started")
+    if live[8]:                                    # per-wave stamps of block 8
+        print("   block 8, per wave: main-loop end / epilogue end relative to wave 0's main-loop end, per tile")
+        for k in range(ntile):
+            base = t[8, 2 + 4 * k]
+            if base <= 0: break
+            print(f"     tile {k}: " + "  ".join(f"w{w}: {tw[w, 2 + 4 * k] - base:+5.2f} / {tw[w, 3 + 4 * k] - base:+5.2f}" for w in range(8)))
     for b in a.blocks:
         if b < 256 and live[b]:
             print(f"   block {b:3d}: " + " ".join(f"{x - t0:6.1f}" for x in t[b] if x > 0))
