@@ -84,11 +84,26 @@ __device__ __forceinline__ void mma32(f32x16& acc, const u32x4& w, const u32x4& 
 // block scales (E8M0 127 = 2^0) -- twice the rate of v_mfma_f32_32x32x16_fp8_fp8: 4 instructions x 64 cycles per quadrant
 // instead of 16 x 32.  Which K elements a lane holds does not matter as long as both operands hold the same ones.
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void mma64(f32x16& acc, const u32x4& w0, const u32x4& w1, const u32x4& a0, const u32x4& a1) {
-    const i32x8 w = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
-    const i32x8 a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+__device__ __forceinline__ void mma64(f32x16& acc, const i32x8& w, const i32x8& a) {
     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, a, acc, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
+// The four 16-byte fragment chunks of one operand block: four separate registers quads, or (K = 64 MFMA) two 8-register
+// operand tuples whose halves the ds_read_b128s write directly.
+template <bool K64> struct PPFrag;
+template <> struct PPFrag<false> {
+    u32x4 c[4];
+    __device__ __forceinline__ void set(int ks, const u32x4& x) { c[ks] = x; }
+};
+template <> struct PPFrag<true> {
+    i32x8 t[2];
+    __device__ __forceinline__ void set(int ks, const u32x4& x) {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 xi = __builtin_bit_cast(i32x4, x);
+        const i32x8 w = __builtin_shufflevector(xi, xi, 0, 1, 2, 3, 0, 1, 2, 3);
+        if (ks & 1) t[ks >> 1] = __builtin_shufflevector(t[ks >> 1], w, 0, 1, 2, 3, 12, 13, 14, 15);
+        else t[ks >> 1] = __builtin_shufflevector(t[ks >> 1], w, 8, 9, 10, 11, 4, 5, 6, 7);
+    }
+};
 
 template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void pp_barrier() {
@@ -410,30 +425,31 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     for (int ks = 0; ks < 4; ++ks) rdA[ks] = lds + (grp * 128 + fl) * 8 + ((2 * ks + kg) ^ sw);
     int wdelta = PP_WOFF + (wn * 64 - grp * 128) * 8;            // chunks from this wave's A rows to its W rows
 
-    u32x4 fX[4], fY[4], fZ[4], fw[2][4];          // A: [ks] (see the table on top); W: [set][ks], n0 in set (tile parity), n1 in the other
+    constexpr bool K64 = ES == 1 && PP_FP8_K64 != 0;
+    PPFrag<K64> fX, fY, fZ, fw[2];                // A: [ks] (see the table on top); W: [set][ks], n0 in set (tile parity), n1 in the other
     f32x16 acc[4][2];                             // [M quadrant * 2 + mb][N quadrant]
 
 #define PP_READ_A(DST, Q, MB, KT)                                                                                           \
     {                                                                                                                        \
         const int o_ = ((KT) & 1) * PP_STAGE + (Q) * 64 * 8 + (MB) * 32 * 8;                                                 \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) DST[ks] = rdA[ks][o_];                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) DST.set(ks, rdA[ks][o_]);                                           \
     }
 #define PP_READ_W(DST, Q, KT)                                                                                               \
     {                                                                                                                        \
         asm volatile("" : "+s"(wdelta));                                                                                     \
         const int o_ = wdelta + ((KT) & 1) * PP_STAGE + (Q) * 32 * 8;                                                        \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) DST[ks] = rdA[ks][o_];                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) DST.set(ks, rdA[ks][o_]);                                           \
     }
     // 8 MFMAs of one quadrant: the four of the first 32-row block (pre-read operands) run first
 #define PP_MFMA(QM, QN, FA0, FA1, FW)                                                                                       \
     {                                                                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                                       \
-        if constexpr (ES == 1 && PP_FP8_K64) {                                                                               \
-            _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) mma64(acc[(QM) * 2 + 0][QN], FW[2 * s_], FW[2 * s_ + 1], FA0[2 * s_], FA0[2 * s_ + 1]); \
-            _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) mma64(acc[(QM) * 2 + 1][QN], FW[2 * s_], FW[2 * s_ + 1], FA1[2 * s_], FA1[2 * s_ + 1]); \
+        if constexpr (K64) {                                                                                                 \
+            _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) mma64(acc[(QM) * 2 + 0][QN], FW.t[s_], FA0.t[s_]);              \
+            _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) mma64(acc[(QM) * 2 + 1][QN], FW.t[s_], FA1.t[s_]);              \
         } else {                                                                                                             \
-            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) mma32(acc[(QM) * 2 + 0][QN], FW[ks], FA0[ks], T());             \
-            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) mma32(acc[(QM) * 2 + 1][QN], FW[ks], FA1[ks], T());             \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) mma32(acc[(QM) * 2 + 0][QN], FW.c[ks], FA0.c[ks], T());         \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) mma32(acc[(QM) * 2 + 1][QN], FW.c[ks], FA1.c[ks], T());         \
         }                                                                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                                                       \
     }
@@ -482,12 +498,14 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     bool after_epi = false;
     while (true) {
         const int bm0 = tm_ * 256, bn0 = tn_ * 256;
+        float zero_ = 0.f;                           // opaque: a loop-invariant zero TUPLE gets hoisted out of the persistent loop and spilled
+        asm volatile("" : "+v"(zero_));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = zero_;
         pp_barrier();                               // every wave's share of A_m0[0], W_n0[0], W_n1[0] is in LDS
         PP_READ_A(fX, 0, 0, 0) PP_READ_W(fw[0], 0, 0)
         if (grp == 1) pp_barrier();                 // group 1 runs one barrier behind group 0 from here on

@@ -25,6 +25,7 @@ struct d2s_present {
         hipEvent_t ready = nullptr, released = nullptr;
         uint64_t seq = 0;                          // publish sequence number (0: never published)
         bool has_released = false;
+        bool held = false;                         // between consume and release: the consumer's stream may still read it
     };
     int device = 0;
     std::vector<Slot> slots;
@@ -87,8 +88,25 @@ extern "C" int d2s_present_acquire(d2s_present* p, void* producer_stream, int* s
     D2S_REQUIRE(p && slot && dev_ptr, "null pointer");
     D2S_ON_DEVICE(p->device);
     std::lock_guard<std::mutex> lk(p->mu);
-    const int i = p->next;
+    // Triple buffering: never the slot the consumer holds (its release event does not exist yet, the device cannot wait for it),
+    // and -- while another one is free -- not the latest published slot either, so the consumer always finds a frame.  With
+    // two slots and a consumer holding one, the other is re-used even if it is the latest: d2s_present_consume then reports
+    // "nothing published" until the next publish (use >= 3 slots when producer and consumer run concurrently).
+    const int n = (int)p->slots.size();
+    int latest = -1;
+    for (int k = 0; k < n; ++k)
+        if (p->slots[k].seq > 0 && (latest < 0 || p->slots[k].seq > p->slots[latest].seq)) latest = k;
+    int i = -1, fallback = -1;
+    for (int k = 0; k < n; ++k) {
+        const int c = (p->next + k) % n;
+        if (p->slots[c].held) continue;
+        if (c != latest) { i = c; break; }
+        if (fallback < 0) fallback = c;
+    }
+    if (i < 0) i = fallback;
+    if (i < 0) { set_error("d2s_present_acquire: every slot is held by the consumer"); return D2S_E_STATE; }
     auto& s = p->slots[i];
+    s.seq = 0;                                      // being rewritten: not consumable until published again
     if (s.gl_resource && !s.mapped) {              // map for the time the producer writes (unmapped again at publish)
         static map_fn mapr = sym<map_fn>("hipGraphicsMapResources");
         static ptr_fn getp = sym<ptr_fn>("hipGraphicsResourceGetMappedPointer");
@@ -136,6 +154,7 @@ extern "C" int d2s_present_consume(d2s_present* p, void* consumer_stream, int* s
     auto& s = p->slots[best];
     if (consumer_stream == (void*)-1) D2S_HIP(hipEventSynchronize(s.ready));
     else D2S_HIP(hipStreamWaitEvent((hipStream_t)consumer_stream, s.ready, 0));
+    s.held = true;                                  // until d2s_present_release: the producer skips it
     *slot = best; *dev_ptr = s.ptr;
     if (seq) *seq = s.seq;
     return D2S_OK;
@@ -149,6 +168,7 @@ extern "C" int d2s_present_release(d2s_present* p, int slot, void* consumer_stre
     auto& s = p->slots[slot];
     if (consumer_stream != (void*)-1) D2S_HIP(hipEventRecord(s.released, (hipStream_t)consumer_stream));
     s.has_released = consumer_stream != (void*)-1;
+    s.held = false;
     return D2S_OK;
 }
 

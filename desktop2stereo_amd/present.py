@@ -18,7 +18,7 @@ from ._lib import check
 
 
 class PresentRing:
-    def __init__(self, shape: Tuple[int, ...], dtype=torch.uint8, slots: int = 2, device: int = 0):
+    def __init__(self, shape: Tuple[int, ...], dtype=torch.uint8, slots: int = 3, device: int = 0):
         if not torch.cuda.is_available():
             raise _lib.D2SError("PresentRing needs a ROCm device")
         self.lib = _lib.load()

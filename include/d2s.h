@@ -245,7 +245,10 @@ int d2s_jpeg_encode(const void* frames, int fmt, int batch, int H, int W, int qu
  * viewer.py:293 -- needs a current GL context); the producer acquires a slot, passes its pointer as `out` of d2s_pipeline /
  * d2s_make_sbs / d2s_upsample_depth, and publishes it; the consumer picks the latest published slot.  All waits are
  * HIP events between the two streams (consumer_stream = (void*)-1: host wait, for a GL consumer): no copy, no host
- * synchronisation on the producer side.  Producer and consumer may be different host threads. */
+ * synchronisation on the producer side.  Producer and consumer may be different host threads.  Triple buffering: the
+ * producer never takes the slot the consumer holds (between consume and release) and, while another slot is free, not the
+ * latest published one either -- use >= 3 slots when both sides run concurrently (with 2, a consume may find nothing
+ * published while the producer rewrites the only free slot). */
 typedef struct d2s_present d2s_present;
 int d2s_present_create(int device_id, int slots, d2s_present** out);
 int d2s_present_bind(d2s_present* p, int slot, void* dev_ptr, uint64_t bytes);

@@ -31,7 +31,7 @@ def test_present_ring_producer_consumer(dev):
     eng = ops.Engine(cfg, make_weights(cfg, 0), h, w, 1, "fp32")
     frames = [torch.from_numpy(synth.structured_frame(H, W, s)[None]).to(dev) for s in range(6)]
     want = [eng.pipeline(f, p, sp).clone() for f in frames]                     # ordinary call: library-independent output tensor
-    ring = PresentRing((1, oh, ow, 3), torch.uint8, slots=2)
+    ring = PresentRing((1, oh, ow, 3), torch.uint8, slots=3)        # triple buffering: {held by the consumer, latest published, being written}
     with pytest.raises(Exception):
         ring.consume()                                                           # nothing published yet: loud
     prod, cons = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
