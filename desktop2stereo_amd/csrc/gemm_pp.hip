@@ -62,9 +62,11 @@ namespace d2s {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-// e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 (mma64 below; D2S_HIPCC_DEFS=-DPP_FP8_K64=1).  Off: as written it pairs the
-// 16-byte fragment registers into 8-register operand tuples, the allocator cannot keep those pairs adjacent across the
-// pre-read schedule at 256 registers and spills 114-136 dwords inside the K loop.  Needs the fragment arrays declared as tuples.
+// e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 (mma64 / PPFrag<true> below; D2S_HIPCC_DEFS=-DPP_FP8_K64=1): the fragment
+// chunks become 8-register operand tuples and a quadrant is 4 MFMAs of 64 cycles instead of 16 of 32.  Correct (pp_check
+// --prec fp8), and the 48-K-tile FC2 runs at 1 219 TFLOP/s (96 us at batch 32) -- but the last two K tiles of every
+// tile spill ~90 dwords around the tuples, and with 6 K tiles per tile (K = 768) that costs more than the faster MFMAs give:
+// batch 32 fp8 2 820 vs 3 000 frames/s.  Off.
 #ifndef PP_FP8_K64
 #define PP_FP8_K64 0
 #endif
