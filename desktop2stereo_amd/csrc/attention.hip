@@ -55,6 +55,19 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
     f32x2_t v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+// max over lanes l and l ^ 16 (resp. l ^ 32) with gfx950's row swaps instead of ds_bpermute_b32: no LDS round trip and no
+// lgkmcnt wait in the online softmax of every key tile.  v_permlane16_swap exchanges the odd 16-lane rows of its first
+// operand with the even rows of the second; with both = v the pair is {r0 r0 r2 r2}, {r1 r1 r3 r3}.
+__device__ __forceinline__ float xmax16(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xmax32(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 // pack the P values a lane group contributes to one V^T chunk
 __device__ __forceinline__ u32x4 pack_p(const f32x4& lo, const f32x4& hi, bf16_t) {
     u32x4 r;
@@ -206,8 +219,8 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, OT* __rest
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][j][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = xmax16(mx);                          // across the 4 lane groups (lanes l, l ^ 16, l ^ 32, l ^ 48)
+            mx = xmax32(mx);
             // p = 2^((s - m) * c) as one FMA + one raw v_exp_f32 per value (arguments are <= 0: no range handling needed)
             const float m_new = fmaxf(m_run[f], mx);
             const float mc = m_new * scale_log2e;
