@@ -128,3 +128,24 @@ def test_load_safetensors_from_hf_checkpoint(tmp_path):
         assert v.dtype == np.float32 and np.array_equal(v, sd[k].float().numpy()), k
     with pytest.raises((KeyError, ValueError)):
         load_safetensors(os.path.join(str(tmp_path), "model.safetensors"), MODELS["vits"])      # wrong architecture: loud
+
+
+def test_bench_tile_fit_batch_and_traffic_table():
+    """bench.py host logic: the tile-fitting batch (whole rounds of 256 x 256 tiles on 256 CUs) and the committed PMC
+    traffic table the roofline objects quote."""
+    import json
+    import bench
+    # ViT-B at 294 x 518: 778 tokens; 27 frames -> 83 tile rows: 249 / 747 / 996 tiles = whole rounds
+    assert bench.tile_fit_batch(778, 768, 3072, 32) == 27
+    b = bench.tile_fit_batch(778, 768, 3072, 16)
+    assert 8 < b <= 16
+    for tokens, hidden in ((778, 384), (778, 1024), (337, 768)):
+        b = bench.tile_fit_batch(tokens, hidden, 4 * hidden, 32)
+        assert 16 < b <= 32
+    t = bench.pmc_traffic("gemm_linear", 1, True)
+    assert t is not None and 5e6 < t < 5e7                      # ~15.7 MB per launch at batch 1
+    assert bench.pmc_traffic("gemm_linear", 1, False) is None   # only for the workload the profile was taken on
+    assert bench.pmc_traffic("no_such_class", 1, True) is None
+    with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+        tab = json.load(f)
+    assert {"gemm_linear", "stereo_warp"} <= set(tab["traffic_bytes_per_launch"])
