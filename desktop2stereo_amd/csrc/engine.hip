@@ -342,7 +342,6 @@ int run_temporal(d2s_engine* e, int m, const void* x, void* out, hipStream_t st,
     d2s_engine::TMod& t = e->tm[m];
     const int C = t.C, S = t.sites, prec = e->prec;
     const int Tw = e->tm_init ? 32 : 1;                 // first frame: a window of one (the frame itself at position 0)
-    const size_t es = elem_size(prec);
     PROF(PC_ELT, 0, 0, launch_groupnorm(prec, x, t.gn_g, t.gn_b, e->tm_a, S, C, 32, 1e-6f, st));
     RC(gemm(e, plainA(e->tm_a, C), t.proj_in, S, rowsE(e->tm_hs, OUT_F32, C, t.proj_in.bias), st));
     for (int a = 0; a < 2; ++a) {

@@ -312,7 +312,6 @@ stereo_warp_generic(const void* __restrict__ rgb, const float* __restrict__ dept
 constexpr int FP_PX = 4;                    // source pixels per thread
 constexpr int FP_TW = 256 * FP_PX;          // tile width in source pixels
 constexpr int FP_MARGIN = 64;               // staged halo each side (pixels); beyond it -> global fallback
-constexpr int FP_LDS_PX = FP_TW + 2 * FP_MARGIN;
 
 // ------------------------------------------------------------------------------------------------
 // Streaming fast path (Full-SBS / Full-TAB / Half-SBS): persistent blocks walk (frame, row, tile) items with a
@@ -322,7 +321,6 @@ constexpr int FP_LDS_PX = FP_TW + 2 * FP_MARGIN;
 // (+ v_cvt_f32_ubyteN) instead of six byte reads.
 // ------------------------------------------------------------------------------------------------
 constexpr int SW_LDS_PX = FP_TW + 2 * FP_MARGIN;       // 1152 pixels, multiple of 4
-constexpr int SW_GROUPS = SW_LDS_PX / 4;               // 12-byte groups of 4 pixels
 constexpr int SW_DN = (FP_TW + 8 + 255) / 256;         // depth-row values per thread
 
 template <int MODE>
