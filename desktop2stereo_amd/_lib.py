@@ -96,6 +96,7 @@ SYMBOLS = {
                                           C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "d2s_profile_class_name": (C.c_char_p, [C.c_int]),
     "d2s_gemm_probe": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "d2s_attention_probe": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
 }
 
 _lib = None

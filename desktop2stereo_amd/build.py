@@ -22,7 +22,11 @@ FLAGS += os.environ.get("D2S_HIPCC_DEFS", "").split()          # tuning aids onl
 # no FMA contraction in the frame-side / post-process kernels: keeps their float32 op sequence
 # comparable with the oracle's (the matrix kernels keep the default fast contraction)
 EXTRA = {"frame_ops.hip": ["-ffp-contract=off"], "post.hip": ["-ffp-contract=off"], "ingest.hip": ["-ffp-contract=off"],
-         "dibr.hip": ["-ffp-contract=off"]}
+         "dibr.hip": ["-ffp-contract=off"],
+         # the softmax never produces a NaN (masked scores are -1e30, exp2 of them is 0): without IEEE mode the compiler
+         # drops the canonicalising v_max_f32 x, x it otherwise puts in front of every fmaxf on an MFMA result
+         # (30 of ~200 VALU instructions per key tile of the batched kernel, which is VALU-bound)
+         "attention.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
 
 
 def _hipcc() -> str:

@@ -111,6 +111,7 @@ struct d2s_engine {
     // D2S_PREC_FP8 (BASELINE config 3): encoder linears on e4m3 operands once calibrated
     bool fp8 = false, fp8_ready = false, calib = false;
     bool lnf = false;                 // LayerNorm folded into the producing / consuming linears (bf16, not fp8)
+    bool attn_prescaled = false;      // softmax scale folded into W_q / b_q (bf16 and fp8 engines)
     float* lnstats = nullptr;         // [slots][M][2] partial row sums written by the residual-update GEMMs
     float* amax = nullptr;                         // device [layers][4]: max |.| of LN1 out, attention out, LN2 out, GELU out
     std::vector<float> act_scale;                  // host   [layers][4]: amax / 448
@@ -468,7 +469,7 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
             else RC(gemm(e, plainA(e->lnbuf, D), ln1_folded ? ly.qkv_ln : ly.qkv, M, ep, st));
         }
         PROF(PC_ATTN, 4.0 * B * d.heads * (double)N * N * 64, 0,
-             launch_attention(prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st, f8 ? 1.0f / sa[1] : 0.f));
+             launch_attention(prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st, f8 ? 1.0f / sa[1] : 0.f, e->attn_prescaled));
         if (am) RC(launch_amax(prec, e->attn, (long)M * D, am + 1, st));
         {
             if (pending_ln >= 0) { D2S_HIP(hipStreamWaitEvent(st, e->ev_ln[pending_ln], 0)); pending_ln = -1; }
@@ -600,6 +601,7 @@ extern "C" int d2s_engine_create(const d2s_model_desc* desc, int device_id, d2s_
         e->lnf = desc->precision == D2S_PREC_BF16 && !(no && atoi(no) != 0);
     }                  // bf16 engine whose encoder linears switch to e4m3 operands
     e->prec = e->fp8 ? D2S_PREC_BF16 : desc->precision;
+    e->attn_prescaled = e->prec == D2S_PREC_BF16;
     const char* t = getenv("D2S_TAPS");
     e->taps = t && atoi(t) != 0;
     *out = e;
@@ -656,7 +658,16 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
         for (const HostT* t : {wq, wk, wv}) if (t->data.size() != (size_t)D * D) { set_error("qkv weight: wrong shape"); return D2S_E_MISSING; }
         std::vector<float> bias(3 * D);
         for (int i = 0; i < D; ++i) { bias[i] = bq->data[i]; bias[D + i] = bk->data[i]; bias[2 * D + i] = bv->data[i]; }
-        const float* ws[3] = {wq->data.data(), wk->data.data(), wv->data.data()};
+        // bf16 / fp8 engines: the softmax scale 64^-0.5 log2(e) goes into the q rows of the fused QKV weight and bias (fp32
+        // product, then the ONE rounding every weight gets): the attention kernels see log2-domain scores, the batched one
+        // straight from the matrix pipe (attention.hip).  The fp32 engine (parity class) keeps the reference's order of operations.
+        std::vector<float> wq_scaled;
+        if (e->attn_prescaled) {
+            wq_scaled.resize(wq->data.size());
+            for (size_t i = 0; i < wq_scaled.size(); ++i) wq_scaled[i] = wq->data[i] * ATTN_SCALE_LOG2E;
+            for (int i = 0; i < D; ++i) bias[i] *= ATTN_SCALE_LOG2E;
+        }
+        const float* ws[3] = {e->attn_prescaled ? wq_scaled.data() : wq->data.data(), wk->data.data(), wv->data.data()};
         RC(pack_matrix(e, 3 * D, D, [&](int n, int k) { return ws[n / D][(size_t)(n % D) * D + k]; }, bias.data(), ly.qkv));
         RC(pack_linear(e, p + "attention.output.dense.weight", p + "attention.output.dense.bias", D, D, ly.proj));
         RC(pack_linear(e, p + "mlp.fc1.weight", p + "mlp.fc1.bias", d.mlp, D, ly.fc1));

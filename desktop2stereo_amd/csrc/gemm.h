@@ -63,10 +63,9 @@ struct GemmEpi {
 int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad,
                 const GemmEpi& e, hipStream_t st);
 
-// 256 x 256 ping-pong kernel (gemm_pp.hip): batched plain linears.  ksplit > 1: K splits add into the in-place fp32 residual.
+// 256 x 256 ping-pong kernel (gemm_pp.hip): batched plain linears
 bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, const GemmEpi& e);
-int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, int ksplit,
-                   hipStream_t st);
+int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st);
 
 // packed-weight geometry
 static inline size_t elem_size(int precision) { return precision == D2S_PREC_BF16 ? 2 : (precision == D2S_PREC_FP8_OPERANDS ? 1 : 4); }

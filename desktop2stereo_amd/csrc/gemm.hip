@@ -524,7 +524,7 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
         static const int pp_min_tiles = getenv("D2S_GEMM_PP") ? atoi(getenv("D2S_GEMM_PP")) : 140;
         const int prec = std::is_same<T, bf16_t>::value ? D2S_PREC_BF16 : D2S_PREC_FP8_OPERANDS;
         if (tile == 0 && pp_min_tiles > 0 && (long)cdiv(M, 256) * cdiv(N, 256) >= pp_min_tiles && pp_supported(prec, a, M, N, K, Kpad, e))
-            return launch_gemm_pp(prec, a, W, M, N, K, Kpad, e, 1, st);
+            return launch_gemm_pp(prec, a, W, M, N, K, Kpad, e, st);
         // (Tile rounding, batch 32: 294 tiles of N = 768 pay a second round for 38 tiles.  Giving the ping-pong kernel only the
         //  tile rows that fill whole rounds and the remaining 3136 rows to the small-tile kernel -- two launches, disjoint rows --
         //  was built and measured: FC2 156 -> 148 us, proj unchanged; the small-tile kernel needs as long for those rows as the
@@ -575,14 +575,13 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
 
 int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad,
                 const GemmEpi& e, hipStream_t st) {
-    if (tile == 256256 || (tile >= 2562562 && tile <= 2562568))         // ping-pong kernel, optional K split (last digit)
-        return launch_gemm_pp(precision, a, W, M, N, K, Kpad, e, tile == 256256 ? 1 : tile % 10, st);
     const int ce = 16 / (int)elem_size(precision);
     if (M <= 0 || N <= 0 || K <= 0 || (N & 3) || (K % ce) || Kpad % (2 * gemm_bk(precision))) {
         set_error("launch_gemm: bad dims (N % 4, K % chunk, Kpad % BK)"); return D2S_E_INVALID;
     }
     if (a.mode == A_PLAIN && (a.lda % ce)) { set_error("launch_gemm: lda not chunk aligned"); return D2S_E_INVALID; }
     if (a.mode == A_CONV3 && (a.C % ce)) { set_error("launch_gemm: conv channels not chunk aligned"); return D2S_E_INVALID; }
+    if (tile == 256256) return launch_gemm_pp(precision, a, W, M, N, K, Kpad, e, st);      // the ping-pong kernel, forced (tests / sweeps)
     if (precision == D2S_PREC_BF16) return launch_t<bf16_t>(tile, a, W, M, N, K, Kpad, e, st);
     if (precision == D2S_PREC_FP8_OPERANDS) {
         if (a.mode != A_PLAIN || a.relu) { set_error("launch_gemm: e4m3 operands are for plain linears"); return D2S_E_UNSUPPORTED; }

@@ -163,19 +163,6 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for_i
 template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
 
 
-// K-split partial of the in-place residual update  x += scale (.) (A W^T + bias):  linear in the accumulator, so every split
-// adds its share straight into the fp32 residual with global_atomic_add_f32 (no partial slabs, no fence, no second pass);
-// the split that holds K tile 0 carries the bias.  fp32 addition order across splits is not fixed: the result is
-// reproducible to round-off, not bit-for-bit (the deterministic path is ksplit = 1).
-__device__ __forceinline__ void epilogue_atomic(const GemmEpi& e, int m, int n0, float v[4], bool first) {
-    if (e.deq) { float q[4]; load4(e.deq + n0, q); v[0] *= q[0]; v[1] *= q[1]; v[2] *= q[2]; v[3] *= q[3]; }
-    if (first && e.bias) { float b[4]; load4(e.bias + n0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
-    if (e.scale) { float s[4]; load4(e.scale + n0, s); v[0] *= s[0]; v[1] *= s[1]; v[2] *= s[2]; v[3] *= s[3]; }
-    float* p = (float*)e.out + (long)m * e.ldc + n0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) unsafeAtomicAdd(p + c, v[c]);
-}
-
 }  // namespace d2s
 
 namespace d2s {

@@ -602,6 +602,7 @@ pp_tail_reduce_kernel(GemmEpi e, int M, int N, int tw, int ks, int lxn) {
 bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, const GemmEpi& e) {
     if (precision != D2S_PREC_BF16 && precision != D2S_PREC_FP8_OPERANDS) return false;
     const int bk = 128 / (int)elem_size(precision);
+    if (M <= 0 || N <= 0 || K < 2 * bk) return false;                   // (K = 0 would pass the parity test below and run two unloaded tiles)
     if (a.mode != A_PLAIN || a.relu || K % (2 * bk) || (N & 255)) return false;
     if (e.map != MAP_ROWS && e.map != MAP_QKV) return false;
     if (e.ln_stats || e.ln_csum || e.stats_out || e.out2) return false;
@@ -634,9 +635,7 @@ static const float* pp_const_vec(bool ones) {
     return buf[d] + (ones ? PP_MAXN : 0);
 }
 
-int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, int ksplit,
-                   hipStream_t st) {
-    (void)ksplit;
+int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
     if (!pp_supported(precision, a, M, N, K, Kpad, e)) { set_error("launch_gemm_pp: unsupported problem"); return D2S_E_UNSUPPORTED; }
     const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
     unsigned vgrid = 0;

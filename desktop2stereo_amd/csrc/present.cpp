@@ -26,6 +26,7 @@ struct d2s_present {
         uint64_t seq = 0;                          // publish sequence number (0: never published)
         bool has_released = false;
         bool held = false;                         // between consume and release: the consumer's stream may still read it
+        bool writing = false;                      // between acquire and publish: the producer's stream is (about to be) writing it
     };
     int device = 0;
     std::vector<Slot> slots;
@@ -52,8 +53,16 @@ extern "C" int d2s_present_create(int device_id, int slots, d2s_present** out) {
     p->device = device_id;
     p->slots.resize(slots);
     for (auto& s : p->slots) {
-        D2S_HIP(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
-        D2S_HIP(hipEventCreateWithFlags(&s.released, hipEventDisableTiming));
+        hipError_t err = hipEventCreateWithFlags(&s.ready, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&s.released, hipEventDisableTiming);
+        if (err != hipSuccess) {                   // give back what exists so far
+            for (auto& t : p->slots) {
+                if (t.ready) (void)hipEventDestroy(t.ready);
+                if (t.released) (void)hipEventDestroy(t.released);
+            }
+            delete p;
+            return hip_fail(err, "hipEventCreateWithFlags", __FILE__, __LINE__);
+        }
     }
     *out = p;
     return D2S_OK;
@@ -64,6 +73,7 @@ extern "C" int d2s_present_bind(d2s_present* p, int slot, void* dev_ptr, uint64_
     std::lock_guard<std::mutex> lk(p->mu);
     auto& s = p->slots[slot];
     D2S_REQUIRE(!s.gl_resource, "slot is bound to a GL buffer");
+    D2S_REQUIRE(!s.held && !s.writing, "slot is in use (acquired or consumed): release / publish it first");
     s.ptr = dev_ptr; s.bytes = bytes; s.seq = 0; s.has_released = false;
     return D2S_OK;
 }
@@ -75,6 +85,7 @@ extern "C" int d2s_present_bind_gl_buffer(d2s_present* p, int slot, unsigned gl_
     if (!reg) { set_error("hipGraphicsGLRegisterBuffer is not available in this HIP runtime"); return D2S_E_UNSUPPORTED; }
     std::lock_guard<std::mutex> lk(p->mu);
     auto& s = p->slots[slot];
+    D2S_REQUIRE(!s.held && !s.writing, "slot is in use (acquired or consumed): release / publish it first");
     void* res = nullptr;
     const unsigned WRITE_DISCARD = 2;              // hipGraphicsRegisterFlagsWriteDiscard: the producer overwrites the whole buffer (viewer.py:293)
     hipError_t err = reg(&res, gl_buffer, WRITE_DISCARD);
@@ -99,12 +110,12 @@ extern "C" int d2s_present_acquire(d2s_present* p, void* producer_stream, int* s
     int i = -1, fallback = -1;
     for (int k = 0; k < n; ++k) {
         const int c = (p->next + k) % n;
-        if (p->slots[c].held) continue;
+        if (p->slots[c].held || p->slots[c].writing) continue;     // the consumer reads it / an earlier acquire is still unpublished
         if (c != latest) { i = c; break; }
         if (fallback < 0) fallback = c;
     }
     if (i < 0) i = fallback;
-    if (i < 0) { set_error("d2s_present_acquire: every slot is held by the consumer"); return D2S_E_STATE; }
+    if (i < 0) { set_error("d2s_present_acquire: every slot is held by the consumer or acquired and not yet published"); return D2S_E_STATE; }
     auto& s = p->slots[i];
     s.seq = 0;                                      // being rewritten: not consumable until published again
     if (s.gl_resource && !s.mapped) {              // map for the time the producer writes (unmapped again at publish)
@@ -118,6 +129,7 @@ extern "C" int d2s_present_acquire(d2s_present* p, void* producer_stream, int* s
     }
     if (!s.ptr) { set_error("d2s_present_acquire: slot has no buffer bound"); return D2S_E_STATE; }
     if (s.has_released) D2S_HIP(hipStreamWaitEvent((hipStream_t)producer_stream, s.released, 0));
+    s.writing = true;
     p->next = (i + 1) % (int)p->slots.size();
     *slot = i; *dev_ptr = s.ptr;
     if (bytes) *bytes = s.bytes;
@@ -130,6 +142,7 @@ extern "C" int d2s_present_publish(d2s_present* p, int slot, void* producer_stre
     D2S_ON_DEVICE(p->device);
     std::lock_guard<std::mutex> lk(p->mu);
     auto& s = p->slots[slot];
+    if (!s.writing) { set_error("d2s_present_publish: the slot was not acquired (or was published already)"); return D2S_E_STATE; }
     if (s.gl_resource && s.mapped) {
         static map_fn unmap = sym<map_fn>("hipGraphicsUnmapResources");
         if (!unmap) { set_error("hipGraphicsUnmapResources missing"); return D2S_E_UNSUPPORTED; }
@@ -137,26 +150,39 @@ extern "C" int d2s_present_publish(d2s_present* p, int slot, void* producer_stre
         s.mapped = false;
     }
     D2S_HIP(hipEventRecord(s.ready, (hipStream_t)producer_stream));
+    s.writing = false;
     s.seq = ++p->seq;
     return D2S_OK;
 }
 
 // consumer: the most recently published slot (latest-frame semantics).  consumer_stream waits on the device for "ready";
 // consumer_stream == (void*)-1: wait on the HOST instead (what a GL consumer needs before it sources the PBO).
+// *dev_ptr: the slot's device pointer; NULL for a GL-bound slot (publish unmapped it -- the consumer sources the GL buffer
+// object itself, e.g. glTexSubImage2D from the bound PBO).
 extern "C" int d2s_present_consume(d2s_present* p, void* consumer_stream, int* slot, void** dev_ptr, uint64_t* seq) {
     D2S_REQUIRE(p && slot && dev_ptr, "null pointer");
     D2S_ON_DEVICE(p->device);
-    std::lock_guard<std::mutex> lk(p->mu);
-    int best = -1;
-    for (int i = 0; i < (int)p->slots.size(); ++i)
-        if (p->slots[i].seq > 0 && (best < 0 || p->slots[i].seq > p->slots[best].seq)) best = i;
-    if (best < 0) { set_error("d2s_present_consume: nothing published yet"); return D2S_E_STATE; }
-    auto& s = p->slots[best];
-    if (consumer_stream == (void*)-1) D2S_HIP(hipEventSynchronize(s.ready));
-    else D2S_HIP(hipStreamWaitEvent((hipStream_t)consumer_stream, s.ready, 0));
-    s.held = true;                                  // until d2s_present_release: the producer skips it
-    *slot = best; *dev_ptr = s.ptr;
-    if (seq) *seq = s.seq;
+    hipEvent_t ready = nullptr;
+    {
+        // the lock covers the slot choice only: a host wait under it would stall the producer's acquire / publish for a
+        // whole GPU frame time (they are different host threads)
+        std::lock_guard<std::mutex> lk(p->mu);
+        int best = -1;
+        for (int i = 0; i < (int)p->slots.size(); ++i)
+            if (p->slots[i].seq > 0 && (best < 0 || p->slots[i].seq > p->slots[best].seq)) best = i;
+        if (best < 0) { set_error("d2s_present_consume: nothing published yet"); return D2S_E_STATE; }
+        auto& s = p->slots[best];
+        s.held = true;                              // until d2s_present_release: the producer skips it
+        ready = s.ready;                            // (not re-recorded while the slot is held)
+        *slot = best; *dev_ptr = s.gl_resource ? nullptr : s.ptr;
+        if (seq) *seq = s.seq;
+    }
+    hipError_t err = consumer_stream == (void*)-1 ? hipEventSynchronize(ready) : hipStreamWaitEvent((hipStream_t)consumer_stream, ready, 0);
+    if (err != hipSuccess) {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->slots[*slot].held = false;
+        return hip_fail(err, "wait for the slot's ready event", __FILE__, __LINE__);
+    }
     return D2S_OK;
 }
 
@@ -166,6 +192,7 @@ extern "C" int d2s_present_release(d2s_present* p, int slot, void* consumer_stre
     D2S_ON_DEVICE(p->device);
     std::lock_guard<std::mutex> lk(p->mu);
     auto& s = p->slots[slot];
+    if (!s.held) { set_error("d2s_present_release: the slot is not held by the consumer"); return D2S_E_STATE; }
     if (consumer_stream != (void*)-1) D2S_HIP(hipEventRecord(s.released, (hipStream_t)consumer_stream));
     s.has_released = consumer_stream != (void*)-1;
     s.held = false;

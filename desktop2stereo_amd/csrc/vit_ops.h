@@ -19,8 +19,11 @@ int launch_to_f32(int prec, const void* in, float* out, long n, hipStream_t st);
 // each), head_dim 64: out[B*N, D] = softmax(q k^T / 8) v.  (HF Dinov2SelfAttention.forward)
 // vt: V transposed [B, heads, 64, Npad] (Npad = N rounded up to 64, zero beyond N), see MAP_QKV in gemm.h.
 // fp8_qscale > 0 (bf16 inputs only): out is e4m3 = sat(result * fp8_qscale), the A operand of an fp8 output projection.
+// prescaled: the q third of qkv already carries ATTN_SCALE_LOG2E (bf16 / fp8 engines fold it into W_q and b_q: one rounding, and
+// the batched kernel gets log2-domain scores straight from the matrix pipe); false: the kernel applies it (fp32 parity class).
+constexpr float ATTN_SCALE_LOG2E = 0.125f * 1.4426950408889634f;          // 64^-0.5 * log2(e)
 int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B, int N, int Npad, int heads, hipStream_t st,
-                     float fp8_qscale = 0.f);
+                     float fp8_qscale = 0.f, bool prescaled = false);
 
 // Video-Depth-Anything temporal-module kernels (temporal.hip)
 int launch_groupnorm(int prec, const void* x, const float* g, const float* b, void* out, int sites, int C, int groups, float eps, hipStream_t st);

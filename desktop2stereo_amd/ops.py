@@ -422,3 +422,18 @@ def gemm_probe(A: torch.Tensor, Wt: torch.Tensor, bias: Optional[torch.Tensor], 
                                      C.c_void_p(torch.cuda.current_stream(A.device).cuda_stream)),
           "d2s_gemm_probe")
     return out
+
+
+def attention_probe(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, precision: str = "bf16", iters: int = 1):
+    """softmax(q k^T / 8) v for float32 [B, heads, N, 64] device tensors through the engine's attention kernel
+    (test / micro-benchmark).  Returns (out [B, N, heads * 64] float32, ms per launch or 0)."""
+    B, H, N, d = q.shape
+    if d != 64 or k.shape != q.shape or v.shape != q.shape:
+        raise ValueError("attention_probe: q, k, v must be [B, heads, N, 64]")
+    out = torch.empty((B, N, H * 64), dtype=torch.float32, device=q.device)
+    ms = C.c_float(0.0)
+    with _on(q.device) as st:
+        check(_lib.load().d2s_attention_probe(_ptr(q.float().contiguous()), _ptr(k.float().contiguous()), _ptr(v.float().contiguous()),
+                                              _ptr(out), B, H, N, {"bf16": PREC_BF16, "fp32": PREC_FP32}[precision], iters,
+                                              C.byref(ms), st), "d2s_attention_probe")
+    return out, ms.value

@@ -294,6 +294,12 @@ int d2s_engine_tap(d2s_engine* e, const char* name, float* out, uint64_t out_ele
 int d2s_gemm_probe(const float* A, const float* Wt, const float* bias, float* C,
                    int M, int N, int K, int precision, int tile, int iters, void* stream);
 
+/* Stand-alone attention probe (tests, micro-benchmark): out[B, N, heads*64] = softmax(q k^T / 8) v for float32 device
+ * arrays q, k, v [B, heads, N, 64], through the engine's attention kernel for that shape (HF Dinov2SelfAttention.forward;
+ * reference call site depth.py:1778).  iters > 1: *ms_per_iter (host) = mean launch time over iters - 1 repeats. */
+int d2s_attention_probe(const float* q, const float* k, const float* v, float* out, int B, int heads, int N,
+                        int precision, int iters, float* ms_per_iter, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

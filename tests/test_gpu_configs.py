@@ -122,10 +122,11 @@ def test_config3_vitl_fp8_4k_tab(dev, golden_dir):
             print(f"[config 3, ViT-L {prec}, 4K {mode}] depth vs reference fp32: max {d.max():.4f} mean {d.mean():.5f}; "
                   f"warp (same depth) max {lsb_same} LSB, {frac_same:.2e} > 1 LSB")
             assert lsb_same <= 1, (prec, mode, lsb_same)
+            # bounds = 1.5 x measured on MI355X (round 2: bf16 max 0.0178 / mean 0.0033; fp8 mean 0.0206 -- fp8 max is reported only)
             if prec == "bf16":
-                assert d.max() <= 0.06 and d.mean() <= 0.006, (d.max(), d.mean())
+                assert d.max() <= 0.027 and d.mean() <= 0.005, (d.max(), d.mean())
             else:
-                assert d.mean() <= 0.05, d.mean()
+                assert d.mean() <= 0.031, d.mean()
         eng.close()
 
 
@@ -174,7 +175,7 @@ def test_config5_mixed_64_frames(dev):
             want = O.to_u8(orc.make_sbs(f, d, ipd_uv=p.ipd, depth_ratio=p.depth_strength, display_mode="Full-SBS", fill_16_9=p.fill_16_9))
             diff = np.abs(outs[i].astype(np.int16) - want.astype(np.int16))
             print(f"[config 5, ViT-S fp32] frame {i} {f.shape[1]}x{f.shape[0]} vs oracle: max {int(diff.max())} LSB, {(diff > 1).mean():.2e} > 1 LSB")
-            assert diff.max() <= 2 and (diff > 1).mean() <= 1e-3, (i, diff.max(), (diff > 1).mean())
+            assert diff.max() <= 1, (i, diff.max(), (diff > 1).mean())          # measured: 1 LSB, no byte beyond
             one = D.pipeline(f[None], display_mode="Full-SBS").cpu().numpy()[0]
             d1 = np.abs(one.astype(np.int16) - outs[i].astype(np.int16))
             assert d1.max() <= 1 and (d1 > 0).mean() <= 1e-3, (i, d1.max())         # fp32: batch 64 == batch 1 up to summation order

@@ -31,6 +31,7 @@ def test_present_ring_producer_consumer(dev):
     eng = ops.Engine(cfg, make_weights(cfg, 0), h, w, 1, "fp32")
     frames = [torch.from_numpy(synth.structured_frame(H, W, s)[None]).to(dev) for s in range(6)]
     want = [eng.pipeline(f, p, sp).clone() for f in frames]                     # ordinary call: library-independent output tensor
+    torch.cuda.synchronize()        # the engine is one stream at a time: its workspaces must be idle before `prod` (non-blocking) uses it
     ring = PresentRing((1, oh, ow, 3), torch.uint8, slots=3)        # triple buffering: {held by the consumer, latest published, being written}
     with pytest.raises(Exception):
         ring.consume()                                                           # nothing published yet: loud
@@ -69,6 +70,26 @@ def test_present_ring_producer_consumer(dev):
     # host-wait form (a GL consumer before it sources the PBO)
     slot, buf, seq = ring.consume(host_wait=True)
     assert seq == len(frames) and torch.equal(buf, want[-1])
+    # slot states: a held slot cannot be re-bound or published, an unacquired slot cannot be published, release needs a held slot
+    with pytest.raises(Exception):
+        ring.publish(slot)
+    with pytest.raises(Exception):
+        ring.bind(slot, torch.empty((1, oh, ow, 3), dtype=torch.uint8, device=dev))
+    ring.release(slot)
+    with pytest.raises(Exception):
+        ring.release(slot)
+    # two acquires without a publish in between hand out two different slots
+    s1, b1 = ring.acquire()
+    s2, b2 = ring.acquire()
+    assert s1 != s2 and b1.data_ptr() != b2.data_ptr()
+    ring.publish(s1); ring.publish(s2)
+    # a view over a pointer the library reports (what a GL-bound slot hands out): aliases the memory, no copy
+    from desktop2stereo_amd.present import _DevMem
+    src = torch.arange(64, dtype=torch.uint8, device=dev)
+    view = torch.as_tensor(_DevMem(src.data_ptr(), 64), device=dev)
+    view[:4] = 200
+    torch.cuda.synchronize()
+    assert src[:4].tolist() == [200] * 4 and view.data_ptr() == src.data_ptr()
     # GL registration needs a GL context: on a compute node it must fail loudly, never silently
     with pytest.raises(Exception):
         ring.bind_gl_buffer(0, 12345)

@@ -22,7 +22,7 @@ def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 0.05)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 0.036)])
 def test_vda_tiny_stream(dev, golden_dir, prec, tol):
     from desktop2stereo_amd import ops
     from desktop2stereo_amd.config import MODELS
@@ -64,7 +64,7 @@ def test_vda_longer_than_window_vs_oracle(dev):
     eng.close()
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 3e-4), ("bf16", 0.05)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 3e-4), ("bf16", 0.036)])
 def test_vda_window_wrap_vs_reference(dev, golden_dir, prec, tol):
     """40 frames of the REFERENCE's own streaming VideoDepthAnything (tests/golden/vda_tiny_long, make_golden_vda.py):
     frames 32..39 run after the 32-frame window has wrapped, so the in-place ring (oldest slot overwritten, projected
