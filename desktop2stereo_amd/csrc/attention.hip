@@ -39,6 +39,25 @@ template <> struct AT<float> {
     __device__ static int key_of(int j, int i) { return j * 16 + i; }
 };
 
+// bf16x3 (split precision, common.h): rows of 64 elements = 8 units of [8 hi | 8 lo] = 16 chunks; a K = 32 step takes, per lane
+// group, the hi and the lo chunk of ONE unit; keys are permuted like the bf16 kernel's so that a lane group's P values of two S
+// fragments are the 8 consecutive keys of one V^T unit.
+template <> struct AT<bx3_t> {
+    static constexpr int CE = 4, CPR = 16, NKS = 2;
+    __device__ static int swzK(int r) { return r & 15; }
+    __device__ static int swzV(int r) { return r & 15; }
+    __device__ static int key_of(int j, int i) { return (j >> 1) * 32 + (i >> 2) * 8 + (i & 3) + 4 * (j & 1); }
+};
+#define ATT_BX3_UNIT(fg) ((0x2130 >> (4 * (fg))) & 3)               /* lane group -> unit of a K = 32 step (gemm_epi.h BX3_UNIT) */
+// x = hi + lo per operand: three bf16 MFMAs, small terms first
+__device__ __forceinline__ void mma16x3(f32x4& acc, const u32x4& a_hi, const u32x4& a_lo, const u32x4& b_hi, const u32x4& b_lo) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a_lo, *(const bf16x8*)&b_hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a_hi, *(const bf16x8*)&b_lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a_hi, *(const bf16x8*)&b_hi, acc, 0, 0, 0);
+}
+// 8 fp32 P values -> the hi chunk and the lo chunk of their unit
+__device__ __forceinline__ void pack_p3(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo);
+
 __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b, bf16_t) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, acc, 0, 0, 0);
 }
@@ -84,6 +103,13 @@ __device__ __forceinline__ u32x4 pack_p(const f32x4& lo, const f32x4&, float) {
     return r;
 }
 
+__device__ __forceinline__ void pack_p3(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+    hi.x = pk_bf16(a[0], a[1]); hi.y = pk_bf16(a[2], a[3]); hi.z = pk_bf16(b[0], b[1]); hi.w = pk_bf16(b[2], b[3]);
+    lo.x = pk_bf16(a[0] - __uint_as_float(hi.x << 16), a[1] - __uint_as_float(hi.x & 0xffff0000u));
+    lo.y = pk_bf16(a[2] - __uint_as_float(hi.y << 16), a[3] - __uint_as_float(hi.y & 0xffff0000u));
+    lo.z = pk_bf16(b[0] - __uint_as_float(hi.z << 16), b[1] - __uint_as_float(hi.z & 0xffff0000u));
+    lo.w = pk_bf16(b[2] - __uint_as_float(hi.w << 16), b[3] - __uint_as_float(hi.w & 0xffff0000u));
+}
 __device__ __forceinline__ void store_o4(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ void store_o4(bf16_t* p, const float v[4]) {
     uint2 t;
@@ -92,6 +118,7 @@ __device__ __forceinline__ void store_o4(bf16_t* p, const float v[4]) {
     *(uint2*)p = t;
 }
 
+__device__ __forceinline__ void store_o4(bx3_t* p, const float v[4]) { bx3_store4(p, v); }      // pre-split for a bf16x3 projection
 __device__ __forceinline__ void store_o4(fp8_t* p, const float v[4]) {     // values already scaled by 1 / (activation scale)
     float a = fminf(fmaxf(v[0], -FP8_MAX), FP8_MAX), b = fminf(fmaxf(v[1], -FP8_MAX), FP8_MAX);
     float c = fminf(fmaxf(v[2], -FP8_MAX), FP8_MAX), d = fminf(fmaxf(v[3], -FP8_MAX), FP8_MAX);
@@ -147,16 +174,23 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, OT* __rest
     const T* kbase = qbase + D;
     const T* vbase = vt + ((long)b * heads + h) * 64 * Npad;
 
-    // ---- Q fragments (B operand of S^T): Q[q][chunk ks*4+fg]
-    u32x4 qf[QF][NKS];
+    // ---- Q fragments (B operand of S^T): Q[q][chunk ks*4+fg]   (bf16x3: the hi and the lo chunk of unit ks * 4 + ATT_BX3_UNIT(fg))
+    constexpr bool X3 = std::is_same<T, bx3_t>::value;
+    u32x4 qf[QF][NKS], qfl[QF][X3 ? NKS : 1];
     int qrow[QF];
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
         qrow[f] = qt * BQ + (wid * QF + f) * 16 + fr;
         bool ok = qrow[f] < N;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-            qf[f][ks] = ok ? *(const u32x4*)(qbase + (long)qrow[f] * row3 + (ks * 4 + fg) * CE) : (u32x4){0u, 0u, 0u, 0u};
+        for (int ks = 0; ks < NKS; ++ks) {
+            if constexpr (X3) {
+                const int c_ = 2 * (ks * 4 + ATT_BX3_UNIT(fg));
+                qf[f][ks] = ok ? *(const u32x4*)(qbase + (long)qrow[f] * row3 + c_ * CE) : (u32x4){0u, 0u, 0u, 0u};
+                qfl[f][ks] = ok ? *(const u32x4*)(qbase + (long)qrow[f] * row3 + (c_ + 1) * CE) : (u32x4){0u, 0u, 0u, 0u};
+            } else
+                qf[f][ks] = ok ? *(const u32x4*)(qbase + (long)qrow[f] * row3 + (ks * 4 + fg) * CE) : (u32x4){0u, 0u, 0u, 0u};
+        }
     }
 
     f32x4 o[QF][4];
@@ -216,9 +250,16 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, OT* __rest
             int kr = A::key_of(j, fr);
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                u32x4 kf = Kl[kr * CPR + ((ks * 4 + fg) ^ A::swzK(kr))];
+                if constexpr (X3) {
+                    const int c_ = 2 * (ks * 4 + ATT_BX3_UNIT(fg));
+                    const u32x4 kh = Kl[kr * CPR + (c_ ^ A::swzK(kr))], kl = Kl[kr * CPR + ((c_ + 1) ^ A::swzK(kr))];
 #pragma unroll
-                for (int f = 0; f < QF; ++f) mma16(s[f][j], kf, qf[f][ks], T());
+                    for (int f = 0; f < QF; ++f) mma16x3(s[f][j], kh, kl, qf[f][ks], qfl[f][ks]);
+                } else {
+                    u32x4 kf = Kl[kr * CPR + ((ks * 4 + fg) ^ A::swzK(kr))];
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) mma16(s[f][j], kf, qf[f][ks], T());
+                }
             }
         }
         // ---- mask the ragged last tile: key of register r in fragment j = key_of(j, fg*4 + r)
@@ -267,6 +308,19 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, OT* __rest
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int pc = 0; pc < NKS; ++pc) {
+            if constexpr (X3) {
+                // lane group fg holds keys 32 pc + 8 fg .. + 7 of the tile = unit 4 pc + fg of a V^T row (both operands agree)
+                u32x4 ph[QF], pl[QF];
+#pragma unroll
+                for (int f = 0; f < QF; ++f) pack_p3(s[f][2 * pc], s[f][2 * pc + 1], ph[f], pl[f]);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int vr = d * 16 + fr, c_ = 2 * (pc * 4 + fg);
+                    const u32x4 vh = Vl[vr * CPR + (c_ ^ A::swzV(vr))], vl = Vl[vr * CPR + ((c_ + 1) ^ A::swzV(vr))];
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) mma16x3(o[f][d], vh, vl, ph[f], pl[f]);
+                }
+            } else {
             u32x4 pf[QF];
 #pragma unroll
             for (int f = 0; f < QF; ++f)
@@ -280,6 +334,7 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, OT* __rest
                 u32x4 vf = Vl[vr * CPR + ((pc * 4 + fg) ^ A::swzV(vr))];
 #pragma unroll
                 for (int f = 0; f < QF; ++f) mma16(o[f][d], vf, pf[f], T());
+            }
             }
         }
     }
@@ -566,7 +621,7 @@ attention32_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt
 }
 
 int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B, int N, int Npad, int heads, hipStream_t st,
-                     float fp8_qscale, bool prescaled) {
+                     float fp8_qscale, bool prescaled, bool bx3_out) {
     // prescaled: the q columns already carry 64^-0.5 * log2(e) (folded into W_q / b_q, engine.hip): scores are log2-domain as they are
     const float scale_log2e = prescaled ? 1.0f : ATTN_SCALE_LOG2E;
     if (fp8_qscale > 0.f && prec != D2S_PREC_BF16) { set_error("attention: e4m3 output needs bf16 inputs"); return D2S_E_UNSUPPORTED; }
@@ -613,6 +668,21 @@ int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B
         else if (bq == 128) D2S_ATT(bf16_t, 1, 8);
         else if (bq == 64) D2S_ATT(bf16_t, 1, 4);
         else D2S_ATT(bf16_t, 1, 2);
+    } else if (prec == D2S_PREC_BF16X3) {
+        // split-precision inputs (q | k and V^T pre-split by the QKV epilogue) and output; batch-1-sized launches split the keys.
+        // (64-element rows are 256 bytes: two ring stages of K | V^T are 64 KiB -> two blocks per CU)
+#define D2S_ATT3(NW_, NS_, KS_) hipLaunchKernelGGL((attention_kernel<bx3_t, 1, NW_, NS_, bx3_t, KS_>), dim3(attn_grid(cdiv(N, NW_ * 16), pairs)), dim3(64 * NW_ * KS_), 0, st, \
+        (const bx3_t*)qkv, (const bx3_t*)vt, (bx3_t*)out, N, Npad, heads, pairs, scale_log2e, 1.0f)
+        if (bq == 128) D2S_ATT3(8, 2, 1);
+        else if (bq == 64 && ks >= 2) D2S_ATT3(4, 2, 2);
+        else if (bq == 64) D2S_ATT3(4, 2, 1);
+        else D2S_ATT3(2, 3, 1);
+#undef D2S_ATT3
+    } else if (bx3_out) {
+#define D2S_ATTX(NW_) hipLaunchKernelGGL((attention_kernel<float, 1, NW_, 3, bx3_t>), dim3(attn_grid(cdiv(N, NW_ * 16), pairs)), dim3(64 * NW_), 0, st, \
+        (const float*)qkv, (const float*)vt, (bx3_t*)out, N, Npad, heads, pairs, scale_log2e, 1.0f)
+        if (bq >= 64) D2S_ATTX(4); else D2S_ATTX(2);
+#undef D2S_ATTX
     } else {
         if (bq >= 64) D2S_ATT(float, 1, 4);
         else D2S_ATT(float, 1, 2);
@@ -640,16 +710,22 @@ __global__ void attn_probe_pack_kernel(const float* __restrict__ q, const float*
     const int h = (int)((idx / (64L * N)) % heads);
     const int b = (int)(idx / (64L * N * heads));
     const int D = heads * 64;
-    auto cv = [](float x) -> T { if constexpr (sizeof(T) == 2) return f2bf(x); else return x; };
     T* row = qkv + ((long)b * N + t) * 3 * D + h * 64 + d;
-    row[0] = cv(q[idx] * qscale); row[D] = cv(k[idx]); row[2 * D] = cv(v[idx]);       // (qscale: what the engine folds into W_q)
-    vt[(((long)b * heads + h) * 64 + d) * Npad + t] = cv(v[idx]);
+    T* vrow = vt + (((long)b * heads + h) * 64 + d) * Npad + t;
+    if constexpr (std::is_same<T, bx3_t>::value) {
+        bx3_store1(row, q[idx]); bx3_store1(row + D, k[idx]); bx3_store1(row + 2 * D, v[idx]); bx3_store1(vrow, v[idx]);
+    } else {
+        auto cv = [](float x) -> T { if constexpr (sizeof(T) == 2) return f2bf(x); else return x; };
+        row[0] = cv(q[idx] * qscale); row[D] = cv(k[idx]); row[2 * D] = cv(v[idx]);       // (qscale: what the engine folds into W_q)
+        *vrow = cv(v[idx]);
+    }
 }
 template <typename T>
 __global__ void attn_probe_unpack_kernel(const T* __restrict__ o, float* __restrict__ out, long n) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    if constexpr (sizeof(T) == 2) out[idx] = bf2f(o[idx]); else out[idx] = o[idx];
+    if constexpr (std::is_same<T, bx3_t>::value) out[idx] = bx3_load1(o + idx);
+    else if constexpr (sizeof(T) == 2) out[idx] = bf2f(o[idx]); else out[idx] = o[idx];
 }
 }  // namespace d2s
 
@@ -657,7 +733,7 @@ extern "C" int d2s_attention_probe(const float* q, const float* k, const float* 
                                    int precision, int iters, float* ms_per_iter, void* stream) {
     using namespace d2s;
     D2S_REQUIRE(q && k && v && out && B > 0 && heads > 0 && N > 0 && iters >= 1, "bad argument");
-    D2S_REQUIRE(precision == D2S_PREC_BF16 || precision == D2S_PREC_FP32, "bad precision");
+    D2S_REQUIRE(precision == D2S_PREC_BF16 || precision == D2S_PREC_FP32 || precision == D2S_PREC_BF16X3, "bad precision");
     hipStream_t st = (hipStream_t)stream;
     const int Npad = (N + 63) / 64 * 64, D = heads * 64;
     const size_t es = precision == D2S_PREC_BF16 ? 2 : 4;
@@ -669,6 +745,8 @@ extern "C" int d2s_attention_probe(const float* q, const float* k, const float* 
     const long total = (long)B * heads * N * 64;
     if (precision == D2S_PREC_BF16)
         hipLaunchKernelGGL((attn_probe_pack_kernel<bf16_t>), dim3(cdiv(total, 256)), dim3(256), 0, st, q, k, v, (bf16_t*)dqkv, (bf16_t*)dvt, B, heads, N, Npad, ATTN_SCALE_LOG2E);
+    else if (precision == D2S_PREC_BF16X3)
+        hipLaunchKernelGGL((attn_probe_pack_kernel<bx3_t>), dim3(cdiv(total, 256)), dim3(256), 0, st, q, k, v, (bx3_t*)dqkv, (bx3_t*)dvt, B, heads, N, Npad, 1.0f);
     else
         hipLaunchKernelGGL((attn_probe_pack_kernel<float>), dim3(cdiv(total, 256)), dim3(256), 0, st, q, k, v, (float*)dqkv, (float*)dvt, B, heads, N, Npad, 1.0f);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -680,6 +758,8 @@ extern "C" int d2s_attention_probe(const float* q, const float* k, const float* 
     D2S_HIP(hipEventRecord(e1, st));
     if (precision == D2S_PREC_BF16)
         hipLaunchKernelGGL((attn_probe_unpack_kernel<bf16_t>), dim3(cdiv((long)B * N * D, 256)), dim3(256), 0, st, (const bf16_t*)dout, out, (long)B * N * D);
+    else if (precision == D2S_PREC_BF16X3)
+        hipLaunchKernelGGL((attn_probe_unpack_kernel<bx3_t>), dim3(cdiv((long)B * N * D, 256)), dim3(256), 0, st, (const bx3_t*)dout, out, (long)B * N * D);
     else
         hipLaunchKernelGGL((attn_probe_unpack_kernel<float>), dim3(cdiv((long)B * N * D, 256)), dim3(256), 0, st, (const float*)dout, out, (long)B * N * D);
     hipError_t err = hipStreamSynchronize(st);

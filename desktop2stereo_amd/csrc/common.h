@@ -62,6 +62,33 @@ __host__ __device__ static inline float bf2f(bf16_t h) {
     union { float f; uint32_t u; } v; v.u = ((uint32_t)h) << 16; return v.f;
 }
 
+// ---- split precision ("bf16x3", D2S_PREC_BF16X3): an element is 4 bytes like a float, but a row is stored as 32-byte UNITS of 8
+// elements, [8 x bf16 hi | 8 x bf16 lo] with hi = bf16(x), lo = bf16(x - hi), so that a 16-byte chunk is one MFMA operand
+// (gemm_epi.h).  Pointer arithmetic on bx3_t* is the float layout's; where the halves of an element live follows from its address.
+struct bx3_t { uint32_t bits; };
+// store 4 consecutive elements (column a multiple of 4, rows 32-byte aligned): p = the float-layout address of the first one
+__device__ static inline void bx3_store4(bx3_t* p, const float v[4]) {
+    const uintptr_t a = (uintptr_t)p;
+    uint2* hi = (uint2*)((a & ~(uintptr_t)31) + ((a >> 4) & 1) * 8);
+    const bf16_t h0 = f2bf(v[0]), h1 = f2bf(v[1]), h2 = f2bf(v[2]), h3 = f2bf(v[3]);
+    const bf16_t l0 = f2bf(v[0] - bf2f(h0)), l1 = f2bf(v[1] - bf2f(h1)), l2 = f2bf(v[2] - bf2f(h2)), l3 = f2bf(v[3] - bf2f(h3));
+    hi[0] = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+    hi[2] = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));      // + 16 bytes: the lo chunk
+}
+
+// one element (any column): p = its float-layout address.  load: hi + lo.
+__host__ __device__ static inline void bx3_store1(bx3_t* p, float v) {
+    const uintptr_t a = (uintptr_t)p;
+    bf16_t* u = (bf16_t*)(a & ~(uintptr_t)31) + ((a >> 2) & 7);
+    const bf16_t h = f2bf(v);
+    u[0] = h; u[8] = f2bf(v - bf2f(h));
+}
+__host__ __device__ static inline float bx3_load1(const bx3_t* p) {
+    const uintptr_t a = (uintptr_t)p;
+    const bf16_t* u = (const bf16_t*)(a & ~(uintptr_t)31) + ((a >> 2) & 7);
+    return bf2f(u[0]) + bf2f(u[8]);
+}
+
 // ---- fp8: OCP e4m3fn (gfx950's format; bias 7, max 448, no infinities, NaN = 0x7f) ----------------------------
 typedef unsigned char fp8_t;     // raw e4m3 bits
 constexpr float FP8_MAX = 448.0f;

@@ -48,7 +48,8 @@ constexpr int NSITE = 6;   // calibration sites per layer: LN1 out, attention ou
 struct d2s_engine {
     d2s_model_desc d;
     int device = 0;
-    int prec = D2S_PREC_BF16;
+    int prec = D2S_PREC_BF16;          // activation / kernel type: fp32 or bf16
+    int wprec = D2S_PREC_BF16;         // weight packing and GEMM operand precision: = prec, or D2S_PREC_BF16X3 (on fp32 activations)
     std::map<std::string, HostT> host;
     bool finalized = false;
     int h = 0, w = 0, gh = 0, gw = 0, P = 0, N = 0, Npad = 0, maxB = 0;
@@ -173,13 +174,14 @@ int upload_f32(d2s_engine* e, const std::string& name, size_t n, float** out) {
 // pack a logical [N][K] float matrix (given by accessor) into device [Npad][Kpad] T
 template <typename F>
 int pack_matrix(d2s_engine* e, int N, int K, F at, const float* bias_host, PackedW& out) {
-    int Kp = gemm_kpad(K, e->prec), Np = gemm_npad(N);
-    size_t es = elem_size(e->prec);
+    int Kp = gemm_kpad(K, e->wprec), Np = gemm_npad(N);
+    size_t es = elem_size(e->wprec);
     std::vector<uint8_t> buf((size_t)Np * Kp * es, 0);
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k) {
             float v = at(n, k);
-            if (e->prec == D2S_PREC_BF16) ((bf16_t*)buf.data())[(size_t)n * Kp + k] = f2bf(v);
+            if (e->wprec == D2S_PREC_BF16) ((bf16_t*)buf.data())[(size_t)n * Kp + k] = f2bf(v);
+            else if (e->wprec == D2S_PREC_BF16X3) bx3_pack_elem(buf.data() + (size_t)n * Kp * 4, k, v);      // [8 hi | 8 lo] units
             else ((float*)buf.data())[(size_t)n * Kp + k] = v;
         }
     int rc = dev_alloc(e, &out.w, buf.size());
@@ -294,6 +296,7 @@ void interp_pos(const float* pos, int grid, int D, int gh, int gw, std::vector<f
 }
 
 GemmA plainA(const void* p, long lda) { GemmA a = {}; a.ptr = p; a.mode = A_PLAIN; a.lda = lda; return a; }
+GemmA splitA(const void* p, long lda, bool split) { GemmA a = plainA(p, lda); a.bx3 = split ? 1 : 0; return a; }   // bf16x3 engines: pre-split rows
 GemmA convA(const void* p, int Hi, int Wi, int C, int Ho, int Wo, int stride, int relu) {
     GemmA a = {}; a.ptr = p; a.mode = A_CONV3; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.relu = relu; return a;
 }
@@ -315,7 +318,7 @@ int gemm(d2s_engine* e, const GemmA& a, const PackedW& w, int M, const GemmEpi& 
         ep2.part = (e->side && st == e->side) ? e->splitk_ws_side : e->splitk_ws;
         ep2.part_elems = e->splitk_elems;
     }
-    PROF(a.mode == A_CONV3 ? PC_CONV : PC_GEMM, 2.0 * M * w.N * w.K, 0, launch_gemm(e->prec, 0, a, w.w, M, w.N, Kl, w.Kpad, ep2, st));
+    PROF(a.mode == A_CONV3 ? PC_CONV : PC_GEMM, 2.0 * M * w.N * w.K, 0, launch_gemm(e->wprec, 0, a, w.w, M, w.N, Kl, w.Kpad, ep2, st));
     return D2S_OK;
 }
 
@@ -438,6 +441,10 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     // D2S_PREC_FP8: the producers of the four linears' A operands write e4m3 (x / s_act, saturated); the linears run on
     // e4m3 operands and de-quantise in their epilogue (deq[n] = s_act * s_w[n]); QKV still emits bf16 for the attention
     const bool f8 = e->fp8 && !e->calib;
+    // bf16x3 engines: the A operands of the four encoder linears are written PRE-SPLIT (bf16 hi | lo units, common.h) by their
+    // producers -- LayerNorm, attention, the GELU epilogue -- so that they travel by LDS-DMA like the bf16 engine's; every other
+    // GEMM / conv reads fp32 activations and splits them between its staging registers and LDS
+    const bool x3 = e->wprec == D2S_PREC_BF16X3;
     // measured (ViT-B @294x518): folding wins 7 % at 1 frame, 3-5 % at 2-4, 2 % at 8, is even at 16 and loses 1 % at 32
     // (the LN kernels' launch floor is amortised there and the wider epilogues are not); from ~9 frames the encoder linears
     // switch to the 256 x 256 ping-pong kernel (gemm_pp.hip: +12 % frames/s at 16, +13 % at 32), which takes plain
@@ -459,17 +466,17 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         // lnf: the previous layer's FC2 epilogue left the raw bf16 residual in lnbuf and the row statistics in lnstats;
         // LN1 then happens inside the QKV linear (layer 0 has no such producer and runs the LN kernel)
         const bool ln1_folded = lnf && l > 0 && ln_slots <= 16;
-        if (!ln1_folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln1g, ly.ln1b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[0] : 0.f));
+        if (!ln1_folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln1g, ly.ln1b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[0] : 0.f, x3));
         if (am) RC(launch_amax(prec, e->lnbuf, (long)M * D, am + 0, st));
         {
-            GemmEpi ep = rowsE(e->qkv, f8 ? OUT_BF16 : OUT_T, 3 * D, ln1_folded ? (f8 ? ly.w8_ln[0].bias : ly.qkv_ln.bias) : ly.qkv.bias);
+            GemmEpi ep = rowsE(e->qkv, f8 ? OUT_BF16 : (x3 ? OUT_BX3 : OUT_T), 3 * D, ln1_folded ? (f8 ? ly.w8_ln[0].bias : ly.qkv_ln.bias) : ly.qkv.bias);
             ep.map = MAP_QKV; ep.vt = e->vt; ep.ntok = N; ep.npad = e->Npad; ep.qk_cols = 2 * D; ep.heads = d.heads;
             if (ln1_folded) { ep.ln_stats = e->lnstats; ep.ln_slots = ln_slots; ep.ln_csum = f8 ? ly.csum8[0] : ly.csum_qkv; ep.ln_eps = d.ln_eps; ep.ln_dim = D; }
             if (f8) { ep.deq = ln1_folded ? ly.deq_ln[0] : ly.deq[0]; RC(gemm8(e, plainA(e->lnbuf, D), ln1_folded ? ly.w8_ln[0] : ly.w8[0], M, ep, st)); }
-            else RC(gemm(e, plainA(e->lnbuf, D), ln1_folded ? ly.qkv_ln : ly.qkv, M, ep, st));
+            else RC(gemm(e, splitA(e->lnbuf, D, x3), ln1_folded ? ly.qkv_ln : ly.qkv, M, ep, st));
         }
         PROF(PC_ATTN, 4.0 * B * d.heads * (double)N * N * 64, 0,
-             launch_attention(prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st, f8 ? 1.0f / sa[1] : 0.f, e->attn_prescaled));
+             launch_attention(x3 ? D2S_PREC_BF16X3 : prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st, f8 ? 1.0f / sa[1] : 0.f, e->attn_prescaled));
         if (am) RC(launch_amax(prec, e->attn, (long)M * D, am + 1, st));
         {
             if (pending_ln >= 0) { D2S_HIP(hipStreamWaitEvent(st, e->ev_ln[pending_ln], 0)); pending_ln = -1; }
@@ -477,18 +484,18 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
             ep.scale = ly.ls1; ep.res1 = e->resid;
             if (lnf) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[4] : 0.f; }
             if (f8) { ep.deq = ly.deq[1]; RC(gemm8(e, plainA(e->attn, D), ly.w8[1], M, ep, st)); }
-            else RC(gemm(e, plainA(e->attn, D), ly.proj, M, ep, st));
+            else RC(gemm(e, splitA(e->attn, D, x3), ly.proj, M, ep, st));
         }
         const bool ln2_folded = lnf && ln_slots <= 16;              // (more than 16 column blocks: the LN kernel runs instead)
-        if (!ln2_folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln2g, ly.ln2b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[2] : 0.f));
+        if (!ln2_folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln2g, ly.ln2b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[2] : 0.f, x3));
         if (am) RC(launch_amax(D2S_PREC_FP32, e->resid, (long)M * D, am + 4, st));       // (raw residual: the LN-folded FC1's A operand)
         if (am) RC(launch_amax(prec, e->lnbuf, (long)M * D, am + 2, st));
         {
-            GemmEpi ep = rowsE(e->mlp, OUT_T, d.mlp, ln2_folded ? (f8 ? ly.w8_ln[1].bias : ly.fc1_ln.bias) : ly.fc1.bias);
+            GemmEpi ep = rowsE(e->mlp, x3 ? OUT_BX3 : OUT_T, d.mlp, ln2_folded ? (f8 ? ly.w8_ln[1].bias : ly.fc1_ln.bias) : ly.fc1.bias);
             ep.act = ACT_GELU;
             if (ln2_folded) { ep.ln_stats = e->lnstats; ep.ln_slots = ln_slots; ep.ln_csum = f8 ? ly.csum8[1] : ly.csum_fc1; ep.ln_eps = d.ln_eps; ep.ln_dim = D; }
             if (f8) { ep.deq = ln2_folded ? ly.deq_ln[1] : ly.deq[2]; ep.out_qscale = 1.0f / sa[3]; RC(gemm8(e, plainA(e->lnbuf, D), ln2_folded ? ly.w8_ln[1] : ly.w8[2], M, ep, st)); }
-            else RC(gemm(e, plainA(e->lnbuf, D), ln2_folded ? ly.fc1_ln : ly.fc1, M, ep, st));
+            else RC(gemm(e, splitA(e->lnbuf, D, x3), ln2_folded ? ly.fc1_ln : ly.fc1, M, ep, st));
         }
         if (am) RC(launch_amax(prec, e->mlp, (long)M * d.mlp, am + 3, st));
         {
@@ -496,7 +503,7 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
             ep.scale = ly.ls2; ep.res1 = e->resid;
             if (lnf && (l + 1 < d.layers || tap_fold)) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[5] : 0.f; }
             if (f8) { ep.deq = ly.deq[3]; RC(gemm8(e, plainA(e->mlp, d.mlp), ly.w8[3], M, ep, st)); }
-            else RC(gemm(e, plainA(e->mlp, d.mlp), ly.fc2, M, ep, st));
+            else RC(gemm(e, splitA(e->mlp, d.mlp, x3), ly.fc2, M, ep, st));
         }
         if (am) RC(launch_amax(D2S_PREC_FP32, e->resid, (long)M * D, am + 5, st));       // (raw residual: the next layer's LN-folded QKV)
         if (e->taps) D2S_HIP(hipMemcpyAsync(e->tap_hidden + (size_t)(l + 1) * N * D, e->resid, (size_t)N * D * 4, hipMemcpyDeviceToDevice, st));
@@ -566,7 +573,7 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
             GemmA a = convA(Y, e->h, e->w, F / 2, e->h, e->w, 1, 0);
             GemmEpi ep = rowsE(depth, OUT_F32, 1, e->head2.bias);
             ep.map = MAP_HEAD; ep.scale = e->w3; ep.head_b3 = e->b3; ep.head_max_depth = d.max_depth;
-            PROF(PC_CONV, 2.0 * Mh * Nh * e->head2.K, 0, launch_gemm(prec, head_tile(bn), a, e->head2.w, Mh, Nh, e->head2.K, e->head2.Kpad, ep, st));
+            PROF(PC_CONV, 2.0 * Mh * Nh * e->head2.K, 0, launch_gemm(e->wprec, head_tile(bn), a, e->head2.w, Mh, Nh, e->head2.K, e->head2.Kpad, ep, st));
         } else {
             RC(conv3(e, Y, B, e->h, e->w, F / 2, 1, 0, e->head2, Z, ACT_RELU, nullptr, nullptr, st));
             PROF(PC_ELT, 0, 0, launch_head_final(prec, Z, e->w3, e->b3, d.max_depth, depth, (long)B * e->h * e->w, d.head_hidden, st));
@@ -587,7 +594,8 @@ extern "C" int d2s_engine_create(const d2s_model_desc* desc, int device_id, d2s_
     D2S_REQUIRE(desc && out, "null pointer");
     D2S_REQUIRE(desc->hidden > 0 && desc->heads > 0 && desc->hidden == desc->heads * 64, "head_dim must be 64");
     D2S_REQUIRE(desc->layers > 0 && desc->patch > 0 && desc->pos_grid > 0 && desc->fusion % 8 == 0, "bad model desc");
-    D2S_REQUIRE(desc->precision == D2S_PREC_FP32 || desc->precision == D2S_PREC_BF16 || desc->precision == D2S_PREC_FP8, "bad precision");
+    D2S_REQUIRE(desc->precision == D2S_PREC_FP32 || desc->precision == D2S_PREC_BF16 || desc->precision == D2S_PREC_FP8 ||
+                desc->precision == D2S_PREC_BF16X3, "bad precision");
     for (int i = 0; i < 4; ++i) D2S_REQUIRE(desc->neck[i] % 8 == 0 && desc->out_indices[i] >= 1 && desc->out_indices[i] <= desc->layers, "bad neck / out_indices");
     D2S_REQUIRE(desc->head_hidden % 4 == 0 && desc->mlp % 8 == 0, "bad head_hidden / mlp");
     D2S_REQUIRE(desc->max_depth >= 0.f && !(desc->temporal && desc->max_depth > 0.f),
@@ -600,7 +608,8 @@ extern "C" int d2s_engine_create(const d2s_model_desc* desc, int device_id, d2s_
         const char* no = getenv("D2S_NO_LNFUSE");
         e->lnf = desc->precision == D2S_PREC_BF16 && !(no && atoi(no) != 0);
     }                  // bf16 engine whose encoder linears switch to e4m3 operands
-    e->prec = e->fp8 ? D2S_PREC_BF16 : desc->precision;
+    e->prec = e->fp8 ? D2S_PREC_BF16 : (desc->precision == D2S_PREC_BF16X3 ? D2S_PREC_FP32 : desc->precision);
+    e->wprec = desc->precision == D2S_PREC_BF16X3 ? D2S_PREC_BF16X3 : e->prec;      // split-precision GEMM operands on the fp32 engine
     e->attn_prescaled = e->prec == D2S_PREC_BF16;
     const char* t = getenv("D2S_TAPS");
     e->taps = t && atoi(t) != 0;

@@ -2,15 +2,19 @@
 //   C[m, n] = epilogue( sum_k A[m, k] * W[n, k] )          W packed [Npad][Kpad], K contiguous
 #pragma once
 #include "common.h"
+#include <cstring>
 
 namespace d2s {
 
 enum { A_PLAIN = 0, A_CONV3 = 1 };
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
 enum { MAP_ROWS = 0, MAP_SHUFFLE = 1, MAP_QKV = 2, MAP_HEAD = 3 };
-enum { OUT_T = 0, OUT_F32 = 1, OUT_BF16 = 2 };   // OUT_T: operand type (fp8 operands: e4m3 of v * out_qscale)
+enum { OUT_T = 0, OUT_F32 = 1, OUT_BF16 = 2, OUT_BX3 = 3 };   // OUT_T: operand type (fp8 operands: e4m3 of v * out_qscale; bf16x3: fp32)
+                                                            // OUT_BX3 (bf16x3 launches): the unit format, A operand of the next linear
 
 constexpr int D2S_PREC_FP8_OPERANDS = D2S_PREC_FP8;   // as a GEMM precision: e4m3 operands (A and W), fp32 accumulate
+// D2S_PREC_BF16X3 as a GEMM precision: A is fp32 in memory (split into bf16 hi + lo on its way into LDS), W is packed in the
+// bf16x3 unit format (gemm_epi.h), outputs / residuals of type OUT_T are fp32
 
 struct GemmA {
     const void* ptr;      // T*
@@ -19,6 +23,7 @@ struct GemmA {
     int Hi, Wi, C;        // A_CONV3: input NHWC [B,Hi,Wi,C], 3x3, pad 1
     int Ho, Wo, stride;   //          output grid, conv stride
     int relu;             // max(x,0) on load (pre-activation)
+    int bx3;              // D2S_PREC_BF16X3 launches: A is ALREADY in the split unit format (plain rows): LDS-DMA tiles; 0: fp32, split when staged
 };
 
 struct GemmEpi {
@@ -68,7 +73,13 @@ bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, 
 int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st);
 
 // packed-weight geometry
-static inline size_t elem_size(int precision) { return precision == D2S_PREC_BF16 ? 2 : (precision == D2S_PREC_FP8_OPERANDS ? 1 : 4); }
+static inline size_t elem_size(int precision) { return precision == D2S_PREC_BF16 ? 2 : (precision == D2S_PREC_FP8_OPERANDS ? 1 : 4); }   // fp32, bf16x3: 4
+// host-side packing of one bf16x3 weight row: element k of a row lives in unit k / 8
+static inline void bx3_pack_elem(uint8_t* row, int k, float v) {
+    const bf16_t hi = f2bf(v), lo = f2bf(v - bf2f(hi));
+    uint8_t* u = row + (size_t)(k >> 3) * 32 + (k & 7) * 2;
+    memcpy(u, &hi, 2); memcpy(u + 16, &lo, 2);
+}
 static inline int gemm_bk(int precision) { return 128 / (int)elem_size(precision); }   // 128-byte K tile
 static inline int gemm_kpad(int K, int precision) { int bk = 2 * gemm_bk(precision); return (K + bk - 1) / bk * bk; }   // 256-byte multiple
 static inline int gemm_npad(int N) { return (N + 255) / 256 * 256; }

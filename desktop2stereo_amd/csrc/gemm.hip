@@ -45,7 +45,8 @@ __device__ __forceinline__ u32x4 relu_frag(u32x4 v, int floor_bits, bf16_t) {
     x = __builtin_elementwise_max(x, (s16x8){f, f, f, f, f, f, f, f});
     return __builtin_bit_cast(u32x4, x);
 }
-__device__ __forceinline__ u32x4 relu_frag(u32x4 v, int, fp8_t) { return v; }   // e4m3 operands: encoder linears only, no ReLU-on-load
+__device__ __forceinline__ u32x4 relu_frag(u32x4 v, int, fp8_t) { return v; }
+__device__ __forceinline__ u32x4 relu_frag(u32x4 v, int, bx3_t) { return v; }   // bf16x3: ReLU-on-load happens on the fp32 values as they are staged   // e4m3 operands: encoder linears only, no ReLU-on-load
 __device__ __forceinline__ u32x4 relu_frag(u32x4 v, int floor_bits, float) {
     f32x4 x = __builtin_bit_cast(f32x4, v);
     float f = floor_bits == 0 ? 0.f : -3.0e38f;
@@ -72,6 +73,9 @@ template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, int STG =
 __global__ void __launch_bounds__(64 * WM * WN)
 gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
     static_assert(STG == 0 || (STG == 1 && NS == 2), "the register-staged variant uses two LDS stages");
+    constexpr bool BX3 = std::is_same<T, bx3_t>::value;   // A: fp32 in memory, split hi / lo when the staging registers are stored
+    static_assert(!BX3 || CPR == 8, "bf16x3 units are laid out for 128-byte K tiles");
+    // (bf16x3 with STG == 0: both operands already in the unit format, LDS-DMA like any other type; STG == 1: A is fp32)
     constexpr int CE = Prec<T>::CE;
     constexpr int BK = CPR * CE;                    // K tile: CPR 16-byte chunks per row (8 -> 128 B, 16 -> 256 B)
     constexpr int RPI = 64 / CPR;                   // rows covered by one 1-KiB LDS-DMA wave-instruction
@@ -147,11 +151,27 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
         _Pragma("unroll") for (int i = 0; i < BI; ++i)                                                           \
             D2S_MOVE(S, AI + i, wrow + (long)(RPI * NW * i) * Kpad + ((KT) + kt0) * BK, st_ + BM * CPR + (i * NW + wid) * 64); \
     }
-    // staging registers -> LDS, the same lane-linear slots the LDS-DMA path fills
+    // staging registers -> LDS, the same lane-linear slots the LDS-DMA path fills.  bf16x3: this lane's A chunk is 4 fp32 values
+    // (logical chunk c = src_chunk of the row's K tile): their bf16 hi / lo pieces are the (c & 1) halves of the hi / lo chunk of
+    // unit c >> 1, i.e. logical chunks 2 (c >> 1) and 2 (c >> 1) + 1, swizzled like every other chunk of the row.
+    const int bx_row = (lane / CPR) * CPR, bx_sw = swz_row<CPR>(lrow);
+    const int bx_hi = (bx_row + (((src_chunk >> 1) * 2) ^ bx_sw)) * 2 + (src_chunk & 1);           // in 8-byte units
+    const int bx_lo = (bx_row + (((src_chunk >> 1) * 2 + 1) ^ bx_sw)) * 2 + (src_chunk & 1);
 #define D2S_STORE_STG(KT, S)                                                                                     \
     {                                                                                                            \
         u32x4* st_ = lds + ((KT) % NS) * STAGE;                                                                  \
-        _Pragma("unroll") for (int i = 0; i < AI; ++i) st_[(i * NW + wid) * 64 + lane] = stg[S][i];              \
+        if constexpr (BX3) {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                     \
+                f32x4 x_ = __builtin_bit_cast(f32x4, stg[S][i]);                                                 \
+                if (a.relu) x_ = __builtin_elementwise_max(x_, (f32x4){0.f, 0.f, 0.f, 0.f});                     \
+                uint2 h_, l_;                                                                                    \
+                bx3_split4(x_, h_, l_);                                                                          \
+                uint2* s2_ = (uint2*)(st_ + (i * NW + wid) * 64);                                                \
+                s2_[bx_hi] = h_; s2_[bx_lo] = l_;                                                                \
+            }                                                                                                    \
+        } else {                                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < AI; ++i) st_[(i * NW + wid) * 64 + lane] = stg[S][i];          \
+        }                                                                                                        \
         _Pragma("unroll") for (int i = 0; i < BI; ++i) st_[BM * CPR + (i * NW + wid) * 64 + lane] = stg[S][AI + i]; \
     }
 
@@ -191,6 +211,19 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     {                                                                                                            \
         const u32x4* A_l = lds + ((KT) % NS) * STAGE + (wave_m * (BM / WM)) * CPR;                               \
         const u32x4* B_l = lds + ((KT) % NS) * STAGE + BM * CPR + (wave_n * (BN / WN)) * CPR;                    \
+        if constexpr (BX3) {                                                                                     \
+            /* one K = 32 step per 128-byte tile: lane group fg takes unit BX3_UNIT(fg) = chunks 2 u (hi), 2 u + 1 (lo) */ \
+            const int cu_ = 2 * BX3_UNIT(fg);                                                                    \
+            u32x4 fbh[FN], fbl[FN];                                                                              \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                     \
+                int r = j * 16 + fr; fbh[j] = B_l[r * CPR + (cu_ ^ swz_row<CPR>(r))]; fbl[j] = B_l[r * CPR + ((cu_ + 1) ^ swz_row<CPR>(r))]; \
+            }                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                                     \
+                int r = i * 16 + fr;                                                                             \
+                const u32x4 fah = A_l[r * CPR + (cu_ ^ swz_row<CPR>(r))], fal = A_l[r * CPR + ((cu_ + 1) ^ swz_row<CPR>(r))]; \
+                _Pragma("unroll") for (int j = 0; j < FN; ++j) mma_bx3(acc[i][j], fbh[j], fbl[j], fah, fal);     \
+            }                                                                                                    \
+        } else {                                                                                                 \
         _Pragma("unroll") for (int ks = 0; ks < CPR / 4; ++ks) {                                                 \
             /* W fragments stay live for the k-step; A fragments stream through one at a time */                 \
             /* (keeps the 8-wave 256-row tiles inside the 256-register budget) */                                \
@@ -204,6 +237,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
                 if (RELU) fa = relu_frag(fa, 0, T());                                                            \
                 _Pragma("unroll") for (int j = 0; j < FN; ++j) mma_chunk(acc[i][j], fb[j], fa, T());             \
             }                                                                                                    \
+        }                                                                                                        \
         }                                                                                                        \
     }
 #define D2S_K_LOOP(RELU)                                                                                         \
@@ -512,6 +546,51 @@ static bool launch_conv_halo(const GemmA& a, const void* W, int M, int N, int K,
     }
 }
 
+// bf16x3 operands: the register-staged tiles only (the fp32 -> hi / lo split happens between the staging registers and LDS).
+// Same rule as the other types -- resident waves first, then tile intensity -- on the staged instantiations.
+static int launch_bx3(int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
+    typedef bx3_t T;
+    static const int force_tile = getenv("D2S_GEMM_TILE_BX3") ? atoi(getenv("D2S_GEMM_TILE_BX3")) : 0;
+    if (a.bx3) {
+        // A pre-split by its producer (LayerNorm / attention / GELU epilogue): LDS-DMA rings for both operands, the bf16 tile rule
+        if (a.mode != A_PLAIN || a.relu) { set_error("launch_gemm: a pre-split bf16x3 A operand must be a plain matrix"); return D2S_E_UNSUPPORTED; }
+        static const int force_dma = getenv("D2S_GEMM_TILE_BX3D") ? atoi(getenv("D2S_GEMM_TILE_BX3D")) : 0;
+        int t = force_dma;
+        if (t == 0) {
+            const long b128 = (long)cdiv(M, 128) * cdiv(N, 128), b64128 = (long)cdiv(M, 64) * cdiv(N, 128), b64 = (long)cdiv(M, 64) * cdiv(N, 64);
+            if (b128 >= 400 && (N >= 1536 || b128 >= 900)) t = 1281288;
+            else if (b64128 >= 280) t = 641288;
+            else if (b64 >= 384) t = 64648;
+            else t = 3264;
+        }
+        if (t == 3264) launch_glds<T, 32, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
+        else if (t == 64648) launch_glds<T, 64, 64, 4, 2, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);
+        else if (t == 641288) launch_glds<T, 64, 128, 2, 4, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);
+        else if (t == 1281288) launch_glds<T, 128, 128, 2, 4, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);
+        else { set_error("launch_gemm: bad tile code for pre-split bf16x3 operands"); return D2S_E_INVALID; }
+        D2S_CHECK_LAUNCH();
+        return D2S_OK;
+    }
+    if (tile == 0 || tile == 256256) tile = force_tile;
+    if (tile == 0) {
+        const long b128 = (long)cdiv(M, 128) * cdiv(N, 128), b64128 = (long)cdiv(M, 64) * cdiv(N, 128), b64 = (long)cdiv(M, 64) * cdiv(N, 64);
+        if (N <= 64) tile = (long)cdiv(M, 256) >= 224 ? (N <= 32 ? 912832 : 9256648) : 93264;
+        else if (b128 >= 400 && (N >= 1536 || b128 >= 900)) tile = 91288;
+        else if (b64128 >= 280) tile = 964128;
+        else if (b64 >= 384) tile = 964;
+        else tile = 93264;
+    }
+    if (tile == 93264 || tile == 3264) launch_glds<T, 32, 64, 2, 2, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 964 || tile == 64) launch_glds<T, 64, 64, 2, 2, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 964128) launch_glds<T, 64, 128, 2, 4, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 91288 || tile == 128) launch_glds<T, 128, 128, 4, 2, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);
+    else if (tile == 912832) launch_glds<T, 128, 32, 4, 1, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);      // WN == 1: MAP_HEAD capable
+    else if (tile == 9256648) launch_glds<T, 256, 64, 8, 1, 2, 8, 1>(a, W, M, N, K, Kpad, e, st);     // WN == 1, 8 waves
+    else { set_error("launch_gemm: bad tile code for bf16x3 operands"); return D2S_E_INVALID; }
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
 template <typename T>
 static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
     static const int force_tile = getenv("D2S_GEMM_TILE") ? atoi(getenv("D2S_GEMM_TILE")) : 0;
@@ -581,6 +660,10 @@ int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, i
     }
     if (a.mode == A_PLAIN && (a.lda % ce)) { set_error("launch_gemm: lda not chunk aligned"); return D2S_E_INVALID; }
     if (a.mode == A_CONV3 && (a.C % ce)) { set_error("launch_gemm: conv channels not chunk aligned"); return D2S_E_INVALID; }
+    if (precision == D2S_PREC_BF16X3) {
+        if (e.ln_stats || e.ln_csum || e.stats_out || e.out2 || e.deq) { set_error("launch_gemm: bf16x3 operands take plain epilogues"); return D2S_E_UNSUPPORTED; }
+        return launch_bx3(tile, a, W, M, N, K, Kpad, e, st);
+    }
     if (tile == 256256) return launch_gemm_pp(precision, a, W, M, N, K, Kpad, e, st);      // the ping-pong kernel, forced (tests / sweeps)
     if (precision == D2S_PREC_BF16) return launch_t<bf16_t>(tile, a, W, M, N, K, Kpad, e, st);
     if (precision == D2S_PREC_FP8_OPERANDS) {
@@ -597,6 +680,11 @@ __global__ void cast_pad_kernel(const float* __restrict__ src, void* __restrict_
     if (idx >= (long)rows_pad * cols_pad) return;
     int c = (int)(idx % cols_pad), r = (int)(idx / cols_pad);
     float v = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+    if (prec == -D2S_PREC_BF16X3) {                  // a bf16x3 WEIGHT matrix: unit format (the A operand stays fp32: prec == D2S_PREC_BF16X3 below)
+        const bf16_t hi = f2bf(v), lo = f2bf(v - bf2f(hi));
+        bf16_t* u = (bf16_t*)((char*)dst + ((long)r * cols_pad + (c & ~7)) * 4) + (c & 7);
+        u[0] = hi; u[8] = lo;
+    } else
     if (prec == D2S_PREC_BF16) ((bf16_t*)dst)[idx] = f2bf(v);
     else if (prec == D2S_PREC_FP8_OPERANDS) ((fp8_t*)dst)[idx] = f2e4m3(v);      // unit scales: the caller keeps |v| <= 448
     else ((float*)dst)[idx] = v;
@@ -609,7 +697,7 @@ using namespace d2s;
 extern "C" int d2s_gemm_probe(const float* A, const float* Wt, const float* bias, float* Cout, int M, int N, int K,
                               int precision, int tile, int iters, void* stream) {
     D2S_REQUIRE(A && Wt && Cout && M > 0 && N > 0 && K > 0 && (N % 4 == 0) && iters >= 1, "bad argument");
-    D2S_REQUIRE(precision == D2S_PREC_BF16 || precision == D2S_PREC_FP32 || precision == D2S_PREC_FP8_OPERANDS, "bad precision");
+    D2S_REQUIRE(precision == D2S_PREC_BF16 || precision == D2S_PREC_FP32 || precision == D2S_PREC_FP8_OPERANDS || precision == D2S_PREC_BF16X3, "bad precision");
     hipStream_t st = (hipStream_t)stream;
     int bf = precision;
     int Kp = gemm_kpad(K, precision), Np = gemm_npad(N);
@@ -618,7 +706,7 @@ extern "C" int d2s_gemm_probe(const float* A, const float* Wt, const float* bias
     D2S_HIP(hipMalloc(&dA, (size_t)M * Kp * es));
     D2S_HIP(hipMalloc(&dW, (size_t)Np * Kp * es));
     hipLaunchKernelGGL(cast_pad_kernel, dim3(cdiv((long)M * Kp, 256)), dim3(256), 0, st, A, dA, M, K, M, Kp, bf);
-    hipLaunchKernelGGL(cast_pad_kernel, dim3(cdiv((long)Np * Kp, 256)), dim3(256), 0, st, Wt, dW, N, K, Np, Kp, bf);
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(cdiv((long)Np * Kp, 256)), dim3(256), 0, st, Wt, dW, N, K, Np, Kp, bf == D2S_PREC_BF16X3 ? -bf : bf);
     GemmA a = {};
     a.ptr = dA; a.mode = A_PLAIN; a.lda = Kp;
     GemmEpi e = {};

@@ -11,7 +11,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers (HIP's u32x4 struct arrays went to scratch)
 
+// Split-precision operand ("bf16x3"): the element is 4 bytes like a float, but a row is stored as 32-byte UNITS of 8 elements,
+// [8 x bf16 hi | 8 x bf16 lo] with hi = bf16(x), lo = bf16(x - hi) (x = hi + lo to ~16 mantissa bits).  A 16-byte chunk is thus
+// either the hi or the lo halves of 8 consecutive elements -- exactly one MFMA operand -- and the byte geometry (128-byte K tile of
+// 32 elements, 8 chunks per row, swizzle) is the float kernels'.  Weights are packed in this format at engine build; activations
+// stay fp32 in HBM and are split on their way into LDS (register-staged tiles), so nothing else in the engine knows the format.
 template <typename T> struct Prec;
+template <> struct Prec<bx3_t>  { static constexpr int CE = 4; };   // "elements" per 16-byte chunk for address arithmetic (as float)
 template <> struct Prec<bf16_t> { static constexpr int CE = 8; };   // elements per 16-byte chunk
 template <> struct Prec<float>  { static constexpr int CE = 4; };
 template <> struct Prec<fp8_t>  { static constexpr int CE = 16; };  // e4m3: a 128-byte K tile holds 128 elements
@@ -24,6 +30,17 @@ __device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& w, const u32x
     const float* af = (const float*)&a;
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], af[t], acc, 0, 0, 0);
+}
+
+// bf16x3: lane group fg of an MFMA takes unit BX3_UNIT(fg) of the K tile (the same for both operands, so the sum is unchanged).
+// Not the identity: with the row swizzle (r >> 1) & 7 the chunk pairs {0,1} {6,7} / {2,3} {4,5} of lane groups 0 / 1 and 2 / 3 keep
+// the 16-lane ds_read_b128 service groups conflict-free (XOR partners must lie in the subgroup {0, 1, 6, 7}).
+#define BX3_UNIT(fg) ((0x2130 >> (4 * (fg))) & 3)                   /* 0 -> 0, 1 -> 3, 2 -> 1, 3 -> 2 */
+// x = hi + lo (the dropped lo * lo term is 2^-16 relative): three bf16 MFMAs
+__device__ __forceinline__ void mma_bx3(f32x4& acc, const u32x4& w_hi, const u32x4& w_lo, const u32x4& a_hi, const u32x4& a_lo) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w_lo, *(const bf16x8*)&a_hi, acc, 0, 0, 0);     // small terms first
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w_hi, *(const bf16x8*)&a_lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w_hi, *(const bf16x8*)&a_hi, acc, 0, 0, 0);
 }
 
 // e4m3 operands: a 16-byte chunk is 16 K elements = two v_mfma_f32_16x16x32_fp8_fp8 (8 bytes per lane each; the k
@@ -67,6 +84,13 @@ __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
     t.y = pk_bf16(v[2], v[3]);
     *(uint2*)p = t;
 }
+// four floats -> the 8-byte hi piece and the 8-byte lo piece of their unit (hi = RNE bf16, lo = RNE bf16 of the exact remainder)
+__device__ __forceinline__ void bx3_split4(const f32x4& x, uint2& hi, uint2& lo) {
+    hi.x = pk_bf16(x[0], x[1]); hi.y = pk_bf16(x[2], x[3]);
+    const float r0 = x[0] - __uint_as_float(hi.x << 16), r1 = x[1] - __uint_as_float(hi.x & 0xffff0000u);
+    const float r2 = x[2] - __uint_as_float(hi.y << 16), r3 = x[3] - __uint_as_float(hi.y & 0xffff0000u);
+    lo.x = pk_bf16(r0, r1); lo.y = pk_bf16(r2, r3);
+}
 
 // four floats -> four e4m3 bytes (v_cvt_pk_fp8_f32, round-to-nearest-even), saturating at +-448
 __device__ __forceinline__ uint32_t pk_fp8x4(float a, float b, float c, float d) {
@@ -82,10 +106,27 @@ __device__ __forceinline__ void load4(const fp8_t* p, float v[4]) {
 }
 __device__ __forceinline__ void store4(fp8_t* p, const float v[4]) { *(uint32_t*)p = pk_fp8x4(v[0], v[1], v[2], v[3]); }
 
+// bf16x3 output (the A operand of a following bf16x3 linear, pre-split so that it can travel by LDS-DMA): hi / lo pieces of the unit
+__device__ __forceinline__ void store4(bx3_t* p, const float v[4]) {
+    const uintptr_t a = (uintptr_t)p;
+    uint2* hi = (uint2*)((a & ~(uintptr_t)31) + ((a >> 4) & 1) * 8);
+    uint2 h, l;
+    bx3_split4((f32x4){v[0], v[1], v[2], v[3]}, h, l);
+    hi[0] = h; hi[2] = l;
+}
+__device__ __forceinline__ void load4(const bx3_t* p, float v[4]) {
+    const uintptr_t a = (uintptr_t)p;
+    const uint2* hi = (const uint2*)((a & ~(uintptr_t)31) + ((a >> 4) & 1) * 8);
+    const uint2 h = hi[0], l = hi[2];
+    v[0] = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16); v[1] = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
+    v[2] = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16); v[3] = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+}
+
 template <typename OT> __device__ __forceinline__ OT cvt_out(float v);
 template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float v) { return f2bf(v); }
 template <> __device__ __forceinline__ fp8_t cvt_out<fp8_t>(float v) { return (fp8_t)(pk_fp8x4(v, 0.f, 0.f, 0.f) & 255u); }
+template <> __device__ __forceinline__ bx3_t cvt_out<bx3_t>(float v) { return bx3_t{__float_as_uint(v)}; }     // (never stored element-wise: MAP_QKV outputs stay fp32)
 
 // skip_deq: the caller (LN-folded consumer on e4m3 operands) already turned the accumulators into real units
 template <typename OT>
@@ -100,7 +141,11 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float
         int b = m / e.ntok, t = m - b * e.ntok;
         int c = n0 - e.qk_cols;                       // h*64 + d, 4 consecutive d
         OT* p = (OT*)e.vt + ((long)b * e.heads * 64 + c) * e.npad + t;
-        p[0] = cvt_out<OT>(v[0]); p[e.npad] = cvt_out<OT>(v[1]); p[2L * e.npad] = cvt_out<OT>(v[2]); p[3L * e.npad] = cvt_out<OT>(v[3]);
+        if constexpr (std::is_same<OT, bx3_t>::value) {            // V^T rows in the unit format along the keys
+            bx3_store1(p, v[0]); bx3_store1(p + e.npad, v[1]); bx3_store1(p + 2L * e.npad, v[2]); bx3_store1(p + 3L * e.npad, v[3]);
+        } else {
+            p[0] = cvt_out<OT>(v[0]); p[e.npad] = cvt_out<OT>(v[1]); p[2L * e.npad] = cvt_out<OT>(v[2]); p[3L * e.npad] = cvt_out<OT>(v[3]);
+        }
         return;
     }
     if (e.map == MAP_SHUFFLE) {
@@ -135,6 +180,10 @@ template <typename T>
 __device__ __forceinline__ void epilogue_dispatch(const GemmEpi& e, int m, int n0, float v[4], bool skip_deq = false) {
     if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v, skip_deq);
     else if (e.out_type == OUT_BF16) epilogue4<bf16_t>(e, m, n0, v, skip_deq);
+    else if constexpr (std::is_same<T, bx3_t>::value) {
+        if (e.out_type == OUT_BX3) epilogue4<bx3_t>(e, m, n0, v, skip_deq);                     // pre-split for the next bf16x3 linear
+        else epilogue4<float>(e, m, n0, v, skip_deq);                                           // bf16x3 engines keep fp32 activations
+    }
     else epilogue4<T>(e, m, n0, v, skip_deq);
 }
 

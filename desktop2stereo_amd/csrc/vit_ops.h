@@ -8,7 +8,8 @@ int launch_patchify(int prec, const float* x, void* A, int B, int h, int w, int 
                     const float* cls, const float* pos, float* resid, int N, int D, hipStream_t st);   // also writes the cls rows
 int launch_cls_rows(const float* cls, const float* pos, float* resid, int B, int N, int D, hipStream_t st);
 int launch_layernorm(int prec, const float* x, const float* g, const float* b, void* out, int rows_out, int D, float eps,
-                     int rows_per_img, int img_rows, int row_off, hipStream_t st, float fp8_qscale = 0.f);   // > 0: e4m3 output
+                     int rows_per_img, int img_rows, int row_off, hipStream_t st, float fp8_qscale = 0.f,   // > 0: e4m3 output
+                     bool bx3_out = false);                                                     // fp32 engines: the bf16x3 unit format
 int launch_amax(int prec, const void* x, long n, float* slot, hipStream_t st);       // *slot = max(*slot, max |x|); fp8 calibration
 int launch_bilinear_nhwc(int prec, const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t st,
                          const void* addend = nullptr);    // out = upsample(in) [+ addend]
@@ -22,8 +23,9 @@ int launch_to_f32(int prec, const void* in, float* out, long n, hipStream_t st);
 // prescaled: the q third of qkv already carries ATTN_SCALE_LOG2E (bf16 / fp8 engines fold it into W_q and b_q: one rounding, and
 // the batched kernel gets log2-domain scores straight from the matrix pipe); false: the kernel applies it (fp32 parity class).
 constexpr float ATTN_SCALE_LOG2E = 0.125f * 1.4426950408889634f;          // 64^-0.5 * log2(e)
+// bx3_out (fp32 inputs only): out in the bf16x3 unit format (common.h), the pre-split A operand of a bf16x3 output projection.
 int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B, int N, int Npad, int heads, hipStream_t st,
-                     float fp8_qscale = 0.f, bool prescaled = false);
+                     float fp8_qscale = 0.f, bool prescaled = false, bool bx3_out = false);
 
 // Video-Depth-Anything temporal-module kernels (temporal.hip)
 int launch_groupnorm(int prec, const void* x, const float* g, const float* b, void* out, int sites, int C, int groups, float eps, hipStream_t st);

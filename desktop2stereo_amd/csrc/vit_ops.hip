@@ -22,6 +22,7 @@ __device__ __forceinline__ void store_row4(bf16_t* o, const float r[4], float) {
     t.y = (uint32_t)f2bf(r[2]) | ((uint32_t)f2bf(r[3]) << 16);
     *(uint2*)o = t;
 }
+__device__ __forceinline__ void store_row4(bx3_t* o, const float r[4], float) { bx3_store4(o, r); }      // pre-split A operand of a bf16x3 linear
 __device__ __forceinline__ void store_row4(fp8_t* o, const float r[4], float qscale) {
     float a = fminf(fmaxf(r[0] * qscale, -FP8_MAX), FP8_MAX), b = fminf(fmaxf(r[1] * qscale, -FP8_MAX), FP8_MAX);
     float c = fminf(fmaxf(r[2] * qscale, -FP8_MAX), FP8_MAX), d = fminf(fmaxf(r[3] * qscale, -FP8_MAX), FP8_MAX);
@@ -180,10 +181,13 @@ int launch_cls_rows(const float* cls, const float* pos, float* resid, int B, int
 }
 
 int launch_layernorm(int prec, const float* x, const float* g, const float* b, void* out, int rows_out, int D, float eps,
-                     int rows_per_img, int img_rows, int row_off, hipStream_t st, float fp8_qscale) {
+                     int rows_per_img, int img_rows, int row_off, hipStream_t st, float fp8_qscale, bool bx3_out) {
     if (D > 1024 || (D & 3)) { set_error("layernorm: D must be a multiple of 4 and <= 1024"); return D2S_E_UNSUPPORTED; }
     dim3 grid(cdiv(rows_out, 4)), block(256);
-    if (fp8_qscale > 0.f)       // e4m3 output for an fp8 linear: out = sat(LN(x) * qscale)
+    if (bx3_out) {              // bf16x3 engines: the unit format, so the consuming linear's A operand can travel by LDS-DMA
+        if (prec != D2S_PREC_FP32 || (D & 7)) { set_error("layernorm: bf16x3 output needs the fp32 engine and D % 8 == 0"); return D2S_E_UNSUPPORTED; }
+        hipLaunchKernelGGL(layernorm_kernel<bx3_t>, grid, block, 0, st, x, g, b, (bx3_t*)out, rows_out, D, eps, rows_per_img, img_rows, row_off, 0.f);
+    } else if (fp8_qscale > 0.f)       // e4m3 output for an fp8 linear: out = sat(LN(x) * qscale)
         hipLaunchKernelGGL(layernorm_kernel<fp8_t>, grid, block, 0, st, x, g, b, (fp8_t*)out, rows_out, D, eps, rows_per_img, img_rows, row_off, fp8_qscale);
     else
         DISPATCH_T(prec, hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, st, x, g, b, (bf16_t*)out, rows_out, D, eps, rows_per_img, img_rows, row_off, 0.f),

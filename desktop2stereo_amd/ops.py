@@ -301,10 +301,10 @@ class Engine:
         self.device = torch.device("cuda", device)
         desc = ModelDesc(cfg.hidden, cfg.heads, cfg.layers, (C.c_int32 * 4)(*cfg.out_indices), (C.c_int32 * 4)(*cfg.neck),
                          cfg.fusion, cfg.head_hidden, cfg.mlp, cfg.patch, cfg.pos_grid, cfg.ln_eps,
-                         {"bf16": PREC_BF16, "fp32": PREC_FP32, "fp8": _lib.PREC_FP8}.get(precision, -1), int(bool(temporal)),
-                         float(max_depth))
-        if precision not in ("bf16", "fp32", "fp8"):
-            raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
+                         {"bf16": PREC_BF16, "fp32": PREC_FP32, "fp8": _lib.PREC_FP8, "bf16x3": _lib.PREC_BF16X3}.get(precision, -1),
+                         int(bool(temporal)), float(max_depth))
+        if precision not in ("bf16", "fp32", "fp8", "bf16x3"):
+            raise ValueError("precision must be 'bf16', 'fp32', 'fp8' or 'bf16x3'")
         self._h = C.c_void_p()
         with _on(self.device):
             check(self.lib.d2s_engine_create(C.byref(desc), device, C.byref(self._h)), "d2s_engine_create")
@@ -418,7 +418,7 @@ def gemm_probe(A: torch.Tensor, Wt: torch.Tensor, bias: Optional[torch.Tensor], 
     N = Wt.shape[0]
     out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     check(_lib.load().d2s_gemm_probe(_ptr(A.contiguous()), _ptr(Wt.contiguous()), _ptr(bias) if bias is not None else None,
-                                     _ptr(out), M, N, K, {"bf16": PREC_BF16, "fp32": PREC_FP32, "fp8": _lib.PREC_FP8}[precision], tile, iters,
+                                     _ptr(out), M, N, K, {"bf16": PREC_BF16, "fp32": PREC_FP32, "fp8": _lib.PREC_FP8, "bf16x3": _lib.PREC_BF16X3}[precision], tile, iters,
                                      C.c_void_p(torch.cuda.current_stream(A.device).cuda_stream)),
           "d2s_gemm_probe")
     return out
@@ -434,6 +434,6 @@ def attention_probe(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, precision
     ms = C.c_float(0.0)
     with _on(q.device) as st:
         check(_lib.load().d2s_attention_probe(_ptr(q.float().contiguous()), _ptr(k.float().contiguous()), _ptr(v.float().contiguous()),
-                                              _ptr(out), B, H, N, {"bf16": PREC_BF16, "fp32": PREC_FP32}[precision], iters,
+                                              _ptr(out), B, H, N, {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": _lib.PREC_BF16X3}[precision], iters,
                                               C.byref(ms), st), "d2s_attention_probe")
     return out, ms.value

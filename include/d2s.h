@@ -52,6 +52,11 @@ extern "C" {
 #define D2S_PREC_FP8        2   /* BASELINE config 3: the encoder's four linears per layer (75 % of the FLOPs) run on e4m3
                                    operands (OCP e4m3fn; weights per-output-channel scales, activations static per-tensor
                                    scales set by d2s_engine_calibrate), fp32 accumulate; everything else as D2S_PREC_BF16 */
+#define D2S_PREC_BF16X3     3   /* split precision (parity class on the bf16 pipe): fp32 activations everywhere as D2S_PREC_FP32, but
+                                   every GEMM / convolution operand is split x = hi + lo into two bf16 values (the activation on its way
+                                   into LDS, the weights once at engine build) and the product is three bf16 MFMAs
+                                   hi*hi + hi*lo + lo*hi with fp32 accumulation: ~16 mantissa bits per operand at 3/16 of the
+                                   fp32-MFMA cost.  Attention, LayerNorm, softmax, residual stream: exactly the fp32 engine's. */
 
 typedef struct d2s_engine d2s_engine;     /* opaque: weights + workspaces + per-stream state */
 

@@ -64,7 +64,7 @@ def test_config2_bench_step_vitb_bf16_1080p_full_sbs(dev, golden_dir):
     sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, "Full-SBS", p.fill_16_9)
     ref_full = O.upsample_depth(z["f0_post_depth"], H, W)
     stats = {}
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16x3", "bf16"):
         eng = ops.Engine(cfg, make_weights(cfg, 0), h, w, 1, prec)
         out, depth = eng.pipeline(_t(frame[None], dev), p, sp, want_depth=True)
         out2, _ = eng.pipeline(_t(frame[None], dev), p, sp, want_depth=True)          # side stream / folds: deterministic
@@ -78,9 +78,10 @@ def test_config2_bench_step_vitb_bf16_1080p_full_sbs(dev, golden_dir):
         print(f"[config 2, {prec}] depth vs reference fp32: max {d.max():.5f} mean {d.mean():.6f}; warp (same depth) max {lsb_same} LSB, "
               f"{frac_same:.2e} of bytes > 1 LSB; end to end max {lsb_e2e} LSB, {frac_e2e:.2e} of bytes > 1 LSB")
         assert lsb_same <= 1, (prec, lsb_same)
-        if prec == "fp32":
+        if prec in ("fp32", "bf16x3"):               # both parity-class engines (bf16x3: the same gate on the bf16 matrix pipe)
             assert d.max() <= 1e-3, d.max()                                            # north_star's gate
             assert frac_e2e <= 1e-4, frac_e2e        # a 1e-3 depth error is < 0.03 px of shift: isolated 2-LSB flips on sharp edges
+            assert lsb_e2e <= (1 if prec == "fp32" else 2), (prec, lsb_e2e)
         else:
             # measured on MI355X (round 2): max 0.0146 / mean 0.0024 -- the reference's own CPU path is bf16 autocast and sits
             # 0.036 / 0.0029 from its fp32 self (tests/golden/vits_r518_bf16); bound = 1.5 x measured

@@ -337,6 +337,9 @@ def test_gemm_probe(dev):
             Wb = torch.from_numpy(W).bfloat16().double().numpy()
             refb = Ab @ Wb.T + b
             assert np.abs(got - refb).max() <= 2e-4 * np.sqrt(K / 64) + 1e-3, (M, N, K, tile, "bf16", np.abs(got - refb).max())
+            # split precision (hi + lo bf16 per operand, three MFMAs): ~2^-16 per operand, i.e. ~100 x tighter than bf16
+            got = ops.gemm_probe(_t(A, dev), _t(W, dev), _t(b, dev), "bf16x3", tile).cpu().numpy()
+            assert np.abs(got - ref).max() <= 3e-5 * np.sqrt(K) + 1e-5, (M, N, K, tile, "bf16x3", np.abs(got - ref).max())
 
 
 def test_gemm_pp_probe(dev):
@@ -375,7 +378,7 @@ def test_attention_probe(dev, monkeypatch):
         v[..., 63] -= 1.0
         q[:, :, N // 2] *= 3.0
         k[:, :, N - 3] = q[:, :, N // 2] * 1.5                     # q . k / 8 ~ 100 for that pair: the max jumps in the last tile
-        for prec, cast, tol in (("bf16", torch.bfloat16, 2e-2), ("fp32", torch.float32, 2e-5)):
+        for prec, cast, tol in (("bf16", torch.bfloat16, 2e-2), ("fp32", torch.float32, 2e-5), ("bf16x3", torch.float32, 2e-4)):
             if prec == "fp32" and B * H * N > 12 * 778 * 8:
                 continue
             qd, kd, vd = (t.to(cast).double() for t in (q, k, v))
@@ -503,6 +506,15 @@ def test_full_size_predict_depth(dev, golden_dir, name, model, res):
     raw = raw.cpu().numpy()[0]
     assert np.abs(raw - ref_raw).max() <= 2e-4 * scale, ("fp32 raw", np.abs(raw - ref_raw).max() / scale)
     assert np.abs(post - ref_post).max() <= 1e-3, ("fp32 post", np.abs(post - ref_post).max())
+    eng.close()
+    # split precision: the same 1e-3 parity gate on the bf16 matrix pipe (fp32 activations, operands split hi + lo)
+    eng = ops.Engine(cfg, wts, h, w, 1, "bf16x3")
+    raw3 = eng(x)
+    post3 = ops.post_process_depth(raw3, p).cpu().numpy()[0]
+    raw3 = raw3.cpu().numpy()[0]
+    print(f"[{name}] bf16x3 engine vs fp32 reference: raw max {np.abs(raw3 - ref_raw).max() / scale:.2e} of range, post-depth max "
+          f"{np.abs(post3 - ref_post).max():.2e} mean {np.abs(post3 - ref_post).mean():.2e}")
+    assert np.abs(post3 - ref_post).max() <= 1e-3, ("bf16x3 post", np.abs(post3 - ref_post).max())
     eng.close()
     eng = ops.Engine(cfg, wts, h, w, 1, "bf16")
     raw = eng(x)

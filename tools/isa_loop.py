@@ -13,14 +13,19 @@ def main():
     lines = [l.split(';')[0].strip() for l in s[start:end].split('\n')]
     lines = [l for l in lines if l and not l.startswith(';') and not (l.startswith('.') and not l.endswith(':'))]
     labels = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(':')}
-    best = None
+    loops = []
     for i, l in enumerate(lines):
         if l.startswith('s_cbranch') or l.startswith('s_branch'):
             t = labels.get(l.split()[-1])
-            if t is not None and t < i and any('s_barrier' in x for x in lines[t:i]):
-                if best is None or (i - t) > (best[1] - best[0]):
-                    best = (t, i)
-    t, i = best
+            if t is not None and t < i and any('s_barrier' in x for x in lines[t:i]) and any('v_mfma' in x for x in lines[t:i]):
+                loops.append((t, i))
+    which = sys.argv[3] if len(sys.argv) > 3 else 'widest'          # widest | all | <index by size, 0 = smallest>
+    loops.sort(key=lambda r: r[1] - r[0])
+    if which == 'all':
+        for n, (t, i) in enumerate(loops):
+            print(n, t, i, i - t)
+        return
+    t, i = loops[-1] if which == 'widest' else loops[int(which)]
     body = [l for l in lines[t:i + 1] if not l.endswith(':')]
     c = collections.Counter(l.split()[0] for l in body)
     valu = sum(v for k, v in c.items() if k.startswith('v_') and 'mfma' not in k)
