@@ -68,3 +68,63 @@ def gather_outputs(out: torch.Tensor, n_frames: int, dst: int = 0) -> Optional[t
     if out.shape[0] > 0:
         dist.send(out.contiguous(), dst)
     return None
+
+
+# ---- EMA under frame sharding (second row) ------------------------------------------------------
+def ema_step_torch(depth: torch.Tensor, state: torch.Tensor, initialised: bool, alpha: float) -> torch.Tensor:
+    """One DepthStabilizer step (reference depth.py:1873-1887) with torch ops, any device: first frame seeds the state and
+    passes through; later frames return prev.lerp_(depth, 1 - alpha).  `depth` is overwritten with the returned map.
+    (The HIP form is ops.ema_update; this one serves the gloo tests and CPU-side owners.)"""
+    if not initialised:
+        state.copy_(depth)
+        return depth
+    state.lerp_(depth, 1.0 - alpha)
+    depth.copy_(state)
+    return depth
+
+
+def ema_exchange(depth_local: torch.Tensor, n_frames: int, state: torch.Tensor, initialised: bool, alpha: float,
+                 owner: int = 0, ema_step=None) -> Tuple[torch.Tensor, bool]:
+    """The temporal EMA (A12) is the one stage of the path that couples frames of ONE stream, and it is a sequential scan in
+    frame order.  With a stream's frames block-partitioned over the ranks (frame_range), the post-A11 depth maps -- model
+    resolution, 0.6 MB each at 294 x 518 -- travel to the stream's owner, which runs the scan exactly as a single rank would
+    (same order, same arithmetic: prev = d0 on the first frame, depth.py:1877-1880) and sends every block back; the 6-50 MB
+    frames never move.  Point-to-point like scatter_frames / gather_outputs; no collective.
+
+    depth_local [n_local, h, w] float32: this rank's block, overwritten with the stabilised maps and returned.
+    state [h, w] / initialised: the stream's EMA state, meaningful on `owner` only.  Returns (depth_local, initialised')."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    step = ema_step or ema_step_torch
+    lo, hi = frame_range(n_frames, world, rank)
+    assert depth_local.shape[0] == hi - lo, "depth_local must be this rank's frame block"
+    if world == 1:
+        for i in range(n_frames):
+            step(depth_local[i], state, initialised or i > 0, alpha)
+        return depth_local, initialised or n_frames > 0
+    if rank == owner:
+        full = torch.empty((n_frames,) + tuple(depth_local.shape[1:]), dtype=depth_local.dtype, device=depth_local.device)
+        reqs = []
+        for r in range(world):
+            a, b = frame_range(n_frames, world, r)
+            if r == owner:
+                full[a:b].copy_(depth_local)
+            elif b > a:
+                reqs.append(dist.irecv(full[a:b], r))
+        for q in reqs:
+            q.wait()
+        for i in range(n_frames):                      # the scan: frame order, one state
+            step(full[i], state, initialised or i > 0, alpha)
+        reqs = []
+        for r in range(world):
+            a, b = frame_range(n_frames, world, r)
+            if r == owner:
+                depth_local.copy_(full[a:b])
+            elif b > a:
+                reqs.append(dist.isend(full[a:b].contiguous(), r))
+        for q in reqs:
+            q.wait()
+        return depth_local, initialised or n_frames > 0
+    if hi > lo:
+        dist.send(depth_local.contiguous(), owner)
+        dist.recv(depth_local, owner)
+    return depth_local, initialised or n_frames > 0

@@ -1,0 +1,102 @@
+"""GPU: bounded race soak of the hand-scheduled kernels (counted vmcnt / raw barriers / inline-asm prefetch), inside the suite.
+Every repeat must be bit-identical to the first while a second stream hammers the memory system with large copies (a slip in a
+hand-counted wait shows up as run-to-run differences once timing moves; the copies move it).  Shapes are the batch-27 / 32 engine's
+own launches plus ragged M; tools/soak_pp.py is the longer form of the same screen."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+REPS = 200
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu test selected but no ROCm device is visible")
+    return torch.device("cuda", 0)
+
+
+class _Perturb:
+    """Concurrent traffic on a side stream: 256 MiB device-to-device copies back to back (L2 / MALL / HBM contention)."""
+
+    def __init__(self, dev):
+        self.s = torch.cuda.Stream(device=dev)
+        self.a = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+        self.b = torch.empty_like(self.a)
+
+    def kick(self, n=4):
+        with torch.cuda.stream(self.s):
+            for _ in range(n):
+                self.b.copy_(self.a, non_blocking=True)
+
+
+def test_soak_gemm_pp_bit_identical_under_load(dev):
+    from desktop2stereo_amd import ops
+    torch.manual_seed(3)
+    pert = _Perturb(dev)
+    # ViT-B encoder linears at batch 32 (24896 rows: two rounds, K-split tail on FC2) and 27 (21006 rows: one round), ragged M
+    shapes = [(24896, 768, 3072), (24896, 3072, 768), (24896, 2304, 768), (21006, 768, 768), (21006, 3072, 768), (6225, 768, 768), (513, 1024, 512)]
+    for prec in ("bf16", "fp8"):
+        for (M, N, K) in shapes:
+            A = torch.randn(M, K, device=dev) * 0.5
+            W = torch.randn(N, K, device=dev) * 0.5
+            b = torch.randn(N, device=dev)
+            first = ops.gemm_probe(A, W, b, prec, 256256)
+            reps = REPS if M > 20000 else REPS // 2
+            for r in range(reps):
+                if r % 8 == 0:
+                    pert.kick()
+                assert torch.equal(ops.gemm_probe(A, W, b, prec, 256256), first), (prec, M, N, K, r)
+            del A, W, first
+    torch.cuda.synchronize()
+
+
+def test_soak_attention32_and_warp_bit_identical_under_load(dev):
+    from desktop2stereo_amd import ops, synth
+    pert = _Perturb(dev)
+    g = torch.Generator().manual_seed(5)
+    for (B, H, N) in [(32, 12, 778), (27, 12, 778), (8, 16, 1370)]:
+        q, k, v = (torch.randn((B, H, N, 64), generator=g).to(dev) for _ in range(3))
+        first, _ = ops.attention_probe(q, k, v, "bf16")
+        for r in range(REPS // 2):
+            if r % 8 == 0:
+                pert.kick()
+            assert torch.equal(ops.attention_probe(q, k, v, "bf16")[0], first), (B, H, N, r)
+    for (Hh, Ww, B) in ((1080, 1920, 16), (2160, 3840, 2), (720, 1280, 5)):
+        img = torch.from_numpy(np.stack([synth.noise_frame(Hh, Ww, i) for i in range(B)])).to(dev)
+        dep = torch.from_numpy(np.stack([synth.smooth_depth(294, 518, i) for i in range(B)])).to(dev)
+        for mode in ("Full-SBS", "Full-TAB", "Half-TAB", "Half-SBS"):
+            sp = ops.sbs_params(0.064, 4.0, 0.05, mode, True)
+            first = ops.make_sbs(img, dep, sp).clone()
+            for r in range(REPS // 4):
+                if r % 8 == 0:
+                    pert.kick()
+                assert torch.equal(ops.make_sbs(img, dep, sp), first), (mode, Hh, Ww, B, r)
+    torch.cuda.synchronize()
+
+
+def test_soak_batched_engine_bit_identical_under_load(dev):
+    """The whole batch-27 / 32 step (ping-pong linears incl. the K-split tail, 32 x 32 attention, halo convs, lane-strided warp)."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS, PipelineParams, engine_shape
+    from desktop2stereo_amd.weights import make_weights
+    cfg = MODELS["vitb"]
+    H, W_ = 1080, 1920
+    h, w, _ = engine_shape(H, W_, 518)
+    p = PipelineParams(depth_resolution=518)
+    sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, "Full-SBS", p.fill_16_9)
+    pert = _Perturb(dev)
+    wts = make_weights(cfg, 0)
+    for B in (32, 27):
+        eng = ops.Engine(cfg, wts, h, w, B, "bf16")
+        frames = torch.from_numpy(np.stack([synth.structured_frame(H, W_, i) for i in range(B)])).to(dev)
+        first = eng.pipeline(frames, p, sp).clone()
+        for r in range(24):
+            if r % 2 == 0:
+                pert.kick(8)
+            assert torch.equal(eng.pipeline(frames, p, sp), first), (B, r)
+        eng.close()
+        del frames, first
+    torch.cuda.synchronize()

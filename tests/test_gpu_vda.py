@@ -110,3 +110,31 @@ def test_vda_vits_stream(dev, golden_dir):
         err = np.abs(d - ref).max() / max(1.0, float(ref.max()))
         assert err <= 3e-4, (fi, err)
     eng.close()
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 3e-4), ("bf16x3", 3e-4), ("bf16", None)])
+def test_vda_vitb_stream_at_the_quoted_size(dev, golden_dir, prec, tol):
+    """ViT-B VDA at 294 x 518 on 1080p frames -- the size BASELINE config 4's stream throughput is quoted on -- 3 frames of the
+    REFERENCE's own streaming model (tests/golden/vda_vitb, make_golden_vda.py): fp32 and split-precision engines within 3e-4
+    of the range, the bf16 engine graded in the bf16 class (measured value printed, bound = 1.5 x it)."""
+    path = os.path.join(golden_dir, "vda_vitb.npz")
+    assert os.path.exists(path), "tests/golden/vda_vitb.npz is part of the repo (python tests/golden/make_golden_vda.py vda_vitb)"
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS
+    from desktop2stereo_amd.vda_weights import make_vda_weights
+    cfg = MODELS["vitb"]
+    z = np.load(path)
+    meta = json.load(open(os.path.join(golden_dir, "vda_vitb.json")))
+    eng = ops.Engine(cfg, make_vda_weights(cfg, 0), 294, 518, 1, prec, temporal=True)
+    worst = 0.0
+    for fi, fr in enumerate(meta["frames"]):
+        x = ops.preprocess(_t(synth.structured_frame(fr["h"], fr["w"], fr["seed"]), dev), meta["depth_resolution"])
+        d = eng(x).cpu().numpy()[0]
+        ref = z[f"f{fi}_depth"]
+        worst = max(worst, float(np.abs(d - ref).max() / max(1.0, float(ref.max()))))
+    print(f"[vda ViT-B 294x518, {prec}] worst frame error {worst:.2e} of the range over {len(meta['frames'])} frames")
+    assert worst <= (tol if tol is not None else VDA_VITB_BF16_BOUND), (prec, worst)
+    eng.close()
+
+
+VDA_VITB_BF16_BOUND = 0.05      # set to 1.5 x the measured bf16 error once measured on MI355X (printed by the test)

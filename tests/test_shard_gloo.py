@@ -64,6 +64,45 @@ def test_scatter_gather_world2(n_frames):
     assert q.get(timeout=5) is True
 
 
+# ---- EMA under frame sharding: gather to the stream owner -> scan -> send back ------------------------
+def _ema_worker(rank, world, port, owner, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from desktop2stereo_amd.shard import ema_exchange, frame_range
+    z = np.load(os.path.join(REPO, "tests", "golden", "tiny_r84.npz"))
+    n = 3
+    lo, hi = frame_range(n, world, rank)
+    mine = torch.from_numpy(np.stack([z[f"f{i}_post_depth"] for i in range(lo, hi)]) if hi > lo else np.zeros((0,) + z["f0_post_depth"].shape, np.float32))
+    state = torch.zeros(z["f0_post_depth"].shape, dtype=torch.float32)
+    out, init = ema_exchange(mine.clone(), n, state, False, 0.9, owner=owner)
+    # every frame's stabilised map == the REFERENCE's single-stream EMA chain (DepthStabilizer, alpha 0.9; golden tiny_r84)
+    errs = [float(np.abs(out[i - lo].numpy() - z[f"f{i}_ema_state"]).max()) for i in range(lo, hi)]
+    if rank == owner:
+        errs.append(float(np.abs(state.numpy() - z["f2_ema_state"]).max()))      # the owner keeps the stream's state
+    q.put((rank, errs, bool(init)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,owner", [(2, 0), (2, 1), (3, 1)])
+def test_ema_exchange_matches_single_rank_chain(world, owner):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() + 7 * world + owner) % 2000
+    procs = [ctx.Process(target=_ema_worker, args=(r, world, port, owner, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, errs, init in got:
+        assert init and all(e <= 2e-6 for e in errs), (rank, errs)
+    assert sum(len(e) for _, e, _ in got) == 3 + 1
+
+
 # ---- bench.py's rank body under gloo, world_size 2 -------------------------------------------------------------------
 class _StandInEngine:
     """CPU stand-in for ops.Engine, injected into bench.rank_body by this test only: a deterministic per-frame map with the
