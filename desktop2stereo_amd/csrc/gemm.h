@@ -23,6 +23,7 @@ struct GemmA {
     int Hi, Wi, C;        // A_CONV3: input NHWC [B,Hi,Wi,C], 3x3, pad 1
     int Ho, Wo, stride;   //          output grid, conv stride
     int relu;             // max(x,0) on load (pre-activation)
+    int buf;              // set by the launcher (plain linears with whole K tiles, < 2 GiB operands): LDS-DMA through buffer descriptors
     int bx3;              // D2S_PREC_BF16X3 launches: A is ALREADY in the split unit format (plain rows): LDS-DMA tiles; 0: fp32, split when staged
 };
 

@@ -119,6 +119,33 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     }
     const T* wrow = W + (long)(bn0 + lrow) * Kpad + src_chunk * CE;
     const float inv_c = a.mode == A_CONV3 ? 1.0f / (float)a.C : 0.f;
+    // Plain linears (a.buf, LDS-DMA path): both operands through buffer descriptors.  The per-lane byte offsets below are fixed
+    // for the whole K loop and a K tile is ONE scalar offset -- no 64-bit address arithmetic, bounds selects or zero-page
+    // pointers per load (at batch 1 that was ~20 VALU + ~20 SALU per K tile next to 4 MFMAs).  Rows past M get an offset past
+    // every descriptor's range: the hardware returns zeros for them.
+    constexpr int ES = (int)sizeof(T);
+    __amdgpu_buffer_rsrc_t rsA = {}, rsW = {};
+    unsigned voA[AI], voW[BI];
+    if constexpr (STG == 0) {
+        if (a.buf) {
+            rsA = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.ptr), 0, (unsigned)((long)M * a.lda * ES), 0x00020000);
+            rsW = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(W), 0, (unsigned)((long)((N + 255) / 256 * 256) * Kpad * ES), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const int m = bm0 + i * NW * RPI + lrow;
+                voA[i] = m < M ? (unsigned)((long)m * a.lda * ES) + (unsigned)(src_chunk * 16) : 0x80000000u;
+            }
+#pragma unroll
+            for (int i = 0; i < BI; ++i) voW[i] = (unsigned)((long)(bn0 + lrow + RPI * NW * i) * Kpad * ES) + (unsigned)(src_chunk * 16);
+        }
+    }
+#define D2S_ISSUE_BUF(KT)                                                                                        \
+    {                                                                                                            \
+        u32x4* st_ = lds + ((KT) % NS) * STAGE;                                                                  \
+        const int so_ = ((KT) + kt0) * (BK * ES);                                                                \
+        _Pragma("unroll") for (int i = 0; i < AI; ++i) lds_dma16(rsA, st_ + (i * NW + wid) * 64, voA[i], so_);    \
+        _Pragma("unroll") for (int i = 0; i < BI; ++i) lds_dma16(rsW, st_ + BM * CPR + (i * NW + wid) * 64, voW[i], so_); \
+    }
 
     // D2S_MOVE(slot index, source, LDS destination): LDS-DMA straight into the ring, or a load into staging registers
     u32x4 stg[1][STG ? LPT : 1];
@@ -258,6 +285,23 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
             D2S_COMPUTE(kt, RELU)                                                                                \
         }                                                                                                        \
     }
+    bool done_buf = false;
+    if constexpr (STG == 0) {
+        if (a.buf) {                                 // plain linear, descriptor-addressed ring (same ring, same waits)
+#pragma unroll
+            for (int t = 0; t < PD; ++t)
+                if (t < nkt) D2S_ISSUE_BUF(t)
+            for (int kt = 0; kt < nkt; ++kt) {
+                if (kt + PD - 1 < nkt) wait_vmcnt<(PD - 1) * LPT>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (kt + PD < nkt) D2S_ISSUE_BUF(kt + PD)
+                D2S_COMPUTE(kt, 0)
+            }
+            done_buf = true;
+        }
+    }
+    if (!done_buf) {
     if constexpr (STG == 1) {
         if (nkt > 0) { D2S_ISSUE_TILE(0, 0) D2S_STORE_STG(0, 0) }
         if (nkt > 1) D2S_ISSUE_TILE(1, 0)
@@ -267,6 +311,8 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
             if (t < nkt) D2S_ISSUE_TILE(t, 0)
     }
     if (a.relu) { D2S_K_LOOP(1) } else { D2S_K_LOOP(0) }
+    }
+#undef D2S_ISSUE_BUF
 #undef D2S_K_LOOP
 #undef D2S_COMPUTE
 #undef D2S_ISSUE_TILE
@@ -517,7 +563,14 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
     }
     GemmEpi e1 = e; e1.ksplit = 1;
     if (e.stats_slots) *e.stats_slots = WN > 1 ? cdiv(N, BN) : 1 << 20;        // WN == 1 tiles write no statistics: the caller falls back
-    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn);
+    GemmA a1 = a;
+    {   // descriptor-addressed LDS-DMA: plain A, whole K tiles (the W zero padding covers nothing then), 32-bit byte offsets
+        static const bool nobuf = getenv("D2S_GEMM_NOBUF") && atoi(getenv("D2S_GEMM_NOBUF")) != 0;
+        constexpr int bk = CPR * (16 / (int)sizeof(T));
+        a1.buf = !nobuf && STG == 0 && a.mode == A_PLAIN && !a.relu && K % bk == 0 && (long)M * a.lda * (long)sizeof(T) < (1L << 31) &&
+                 (long)gemm_npad(N) * Kpad * (long)sizeof(T) < (1L << 31);
+    }
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid), dim3(64 * WM * WN), 0, st, a1, (const T*)W, M, N, K, Kpad, e1, xn);
 }
 
 // stride-1 3x3 convs on the large maps go to conv3_halo_kernel (input tile resident in LDS); D2S_NO_HALO=1 keeps the

@@ -16,6 +16,19 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vect
 // either the hi or the lo halves of 8 consecutive elements -- exactly one MFMA operand -- and the byte geometry (128-byte K tile of
 // 32 elements, 8 chunks per row, swizzle) is the float kernels'.  Weights are packed in this format at engine build; activations
 // stay fp32 in HBM and are split on their way into LDS (register-staged tiles), so nothing else in the engine knows the format.
+// 16 bytes per lane, global -> LDS (1 KiB per wave-instruction, lane-linear in LDS) through a buffer descriptor: the per-lane offset
+// is fixed for the whole K loop, a K tile is the scalar offset.  (A __device__ wrapper: called with non-dependent arguments straight
+// from a __global__ template, the device-only builtin makes the HOST pass drop the kernel's launch stub without a diagnostic.)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_lds_;
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, void* lds_dst, unsigned voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+}
+__device__ __forceinline__ void* uniform_ptr(const void* p) {      // a wave-uniform pointer the compiler can SEE is uniform (no waterfall loop)
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (void*)(((unsigned long long)hi32 << 32) | lo);
+}
+
 template <typename T> struct Prec;
 template <> struct Prec<bx3_t>  { static constexpr int CE = 4; };   // "elements" per 16-byte chunk for address arithmetic (as float)
 template <> struct Prec<bf16_t> { static constexpr int CE = 8; };   // elements per 16-byte chunk

@@ -137,4 +137,4 @@ def test_vda_vitb_stream_at_the_quoted_size(dev, golden_dir, prec, tol):
     eng.close()
 
 
-VDA_VITB_BF16_BOUND = 0.05      # set to 1.5 x the measured bf16 error once measured on MI355X (printed by the test)
+VDA_VITB_BF16_BOUND = 0.0224    # 1.5 x the measured 0.0149 (MI355X, round 3)
