@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libd2s_hip.so")
-SOURCES = ["core.cpp", "present.cpp", "ingest.hip", "frame_ops.hip", "dibr.hip", "jpeg.hip", "post.hip", "gemm.hip", "gemm_pp.hip", "vit_ops.hip", "attention.hip", "temporal.hip", "engine.hip"]
+SOURCES = ["core.cpp", "present.cpp", "ingest.hip", "frame_ops.hip", "dibr.hip", "jpeg.hip", "post.hip", "gemm.hip", "conv3.hip", "gemm_pp.hip", "vit_ops.hip", "attention.hip", "temporal.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("D2S_HIPCC_DEFS", "").split()          # tuning aids only (e.g. -DD2S_PP_TIMING); rebuild with --force
 # no FMA contraction in the frame-side / post-process kernels: keeps their float32 op sequence

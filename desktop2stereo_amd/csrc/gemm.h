@@ -69,6 +69,9 @@ struct GemmEpi {
 int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad,
                 const GemmEpi& e, hipStream_t st);
 
+// stride-1 3x3 convolutions with the input tile resident in LDS, second generation (conv3.hip): false = not eligible, nothing launched
+bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st);
+
 // 256 x 256 ping-pong kernel (gemm_pp.hip): batched plain linears
 bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, const GemmEpi& e);
 int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st);

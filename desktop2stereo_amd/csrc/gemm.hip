@@ -124,12 +124,12 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     // pointers per load (at batch 1 that was ~20 VALU + ~20 SALU per K tile next to 4 MFMAs).  Rows past M get an offset past
     // every descriptor's range: the hardware returns zeros for them.
     constexpr int ES = (int)sizeof(T);
-    __amdgpu_buffer_rsrc_t rsA = {}, rsW = {};
+    // (descriptors are built unconditionally -- a few scalar instructions; the offsets only where the path is taken)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.ptr), 0, (unsigned)((long)M * a.lda * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(W), 0, (unsigned)((long)((N + 255) / 256 * 256) * Kpad * ES), 0x00020000);
     unsigned voA[AI], voW[BI];
     if constexpr (STG == 0) {
         if (a.buf) {
-            rsA = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.ptr), 0, (unsigned)((long)M * a.lda * ES), 0x00020000);
-            rsW = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(W), 0, (unsigned)((long)((N + 255) / 256 * 256) * Kpad * ES), 0x00020000);
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 const int m = bm0 + i * NW * RPI + lrow;
@@ -718,6 +718,11 @@ int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, i
         return launch_bx3(tile, a, W, M, N, K, Kpad, e, st);
     }
     if (tile == 256256) return launch_gemm_pp(precision, a, W, M, N, K, Kpad, e, st);      // the ping-pong kernel, forced (tests / sweeps)
+    // batched 3x3 convolutions (and the fused head, whose caller names a tile): input tile resident in LDS, conv3.hip
+    if (precision == D2S_PREC_BF16 && a.mode == A_CONV3 && (tile == 0 || e.map == MAP_HEAD) && launch_conv3_halo2(a, W, M, N, K, Kpad, e, st)) {
+        D2S_CHECK_LAUNCH();
+        return D2S_OK;
+    }
     if (precision == D2S_PREC_BF16) return launch_t<bf16_t>(tile, a, W, M, N, K, Kpad, e, st);
     if (precision == D2S_PREC_FP8_OPERANDS) {
         if (a.mode != A_PLAIN || a.relu) { set_error("launch_gemm: e4m3 operands are for plain linears"); return D2S_E_UNSUPPORTED; }
