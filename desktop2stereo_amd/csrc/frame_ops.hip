@@ -326,7 +326,7 @@ constexpr int SW_DN = (FP_TW + 8 + 255) / 256;         // depth-row values per t
 template <int MODE>
 __global__ void __launch_bounds__(256, 5)
 stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
-                   int B, WarpGeom g) {
+                   int B, WarpGeom g, int ipb /* consecutive rows per block */) {
     __shared__ __attribute__((aligned(16))) uint32_t spix[2][SW_LDS_PX];
     __shared__ float drow[2][FP_TW + 8];
     const int tid = threadIdx.x;
@@ -388,8 +388,10 @@ stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ de
         }                                                                                     \
     }
 
-    int item = blockIdx.x;
+    // a block walks a contiguous band of ipb rows (see stereo_warp_lanes: the band's depth rows are fetched once)
+    int item = blockIdx.x * ipb;
     if (item >= items) return;
+    const int item_end = item + ipb < items ? item + ipb : items;
     int cur_b = item / g.H, cur_y = item - cur_b * g.H, nxt_b = cur_b, nxt_y = cur_y;      // (one division per block)
     // per-thread column constants: the depth taps of this thread's 4 pixels depend on x only, not on the row
     const int x_base = xa + tid * FP_PX;
@@ -410,10 +412,10 @@ stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     __syncthreads();
     int buf = 0;
     while (true) {
-        const int next = item + (int)gridDim.x;
-        const bool has = next < items;
-        nxt_b = cur_b; nxt_y = cur_y + (int)gridDim.x;
-        while (nxt_y >= g.H) { nxt_y -= g.H; ++nxt_b; }
+        const int next = item + 1;
+        const bool has = next < item_end;
+        nxt_b = cur_b; nxt_y = cur_y + 1;
+        if (nxt_y >= g.H) { nxt_y -= g.H; ++nxt_b; }
         if (has) SW_LOAD(next)
         {
             SW_DECODE(item, b, y)
@@ -562,7 +564,7 @@ __device__ __forceinline__ void wl_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n
 template <int MODE>
 __global__ void __launch_bounds__(256, 4)
 stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
-                  int B, WarpGeom g) {
+                  int B, WarpGeom g, int ipb /* consecutive items per block */) {
     __shared__ __attribute__((aligned(16))) float splane[2][3][WL_PLANE];     // 27,648 B
     __shared__ float drow[2][FP_TW + 8];                                        //  8,256 B
     __shared__ __attribute__((aligned(16))) uint32_t tpose[4][256];            //  4,096 B  -> 4 blocks per CU
@@ -632,15 +634,17 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
     // Items are rows (Full modes) or row PAIRS (Half-TAB: output row yp = mean of rows 2 yp, 2 yp + 1); a block walks items
     // it0, it0 + stride, ...; a "step" is one source row, so a pair is two consecutive steps.
     constexpr bool HALF = MODE == D2S_MODE_HALF_TAB;
+    // A block walks a CONTIGUOUS band of ipb items (round 2: items it0, it0 + gridDim.x, ... -- neighbouring rows then sat on
+    // eight different XCDs, every XCD's L2 fetched every depth row, and the launch read 1.7 x its algorithmic bytes, PMC
+    // profiles/r3_04): a band's depth rows are fetched once, and the HBM pages of the band stream in order.
     const int ipf = HALF ? g.H / 2 : g.H;                  // items per frame
-    const int it0 = blockIdx.x;
+    const int it0 = blockIdx.x * ipb;
     if (it0 >= items) return;
-    const int stride = (int)gridDim.x;
-    const int nsteps = ((items - 1 - it0) / stride + 1) * (HALF ? 2 : 1);
+    const int nsteps = (items - it0 < ipb ? items - it0 : ipb) * (HALF ? 2 : 1);
     int cur_b = it0 / ipf, cur_y = (it0 - cur_b * ipf) * (HALF ? 2 : 1);                     // (one division per block)
-    auto advance = [&](int& rb, int& ry) {                 // (frame, row) of the next step, tracked incrementally
-        if (HALF) ry += (ry & 1) ? 2 * stride - 1 : 1; else ry += stride;
-        while (ry >= g.H) { ry -= g.H; ++rb; }
+    auto advance = [&](int& rb, int& ry) {                 // (frame, row) of the next step: the next source row
+        ++ry;
+        if (ry >= g.H) { ry -= g.H; ++rb; }
     };
     // per-thread column constants: pixel k of this lane, its depth taps (they depend on x only) and whether it exists
     const int wave_x0 = xa + wid * 256;
@@ -984,7 +988,7 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
             long pairs = (long)(H / 2) * batch;
             long rounds = (pairs * tiles_x + 256 * 4 - 1) / (256 * 4);
             dim3 pgrid((unsigned)((pairs + rounds - 1) / rounds), tiles_x);
-            hipLaunchKernelGGL(stereo_warp_lanes<D2S_MODE_HALF_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+            hipLaunchKernelGGL(stereo_warp_lanes<D2S_MODE_HALF_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rounds);
         } else if (g.mode == D2S_MODE_HALF_TAB) {
             dim3 grid((unsigned)((long)tiles_x * (H / 2) * batch));
             hipLaunchKernelGGL(stereo_warp_fast_halftab, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
@@ -997,15 +1001,15 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
             long rounds = (rows * tiles_x + 256 * bpc - 1) / (256 * bpc);   // balanced persistent grid: every block walks `rounds` rows
             dim3 pgrid((unsigned)((rows + rounds - 1) / rounds), tiles_x);
             if (lanes && g.mode == D2S_MODE_FULL_SBS)
-                hipLaunchKernelGGL(stereo_warp_lanes<D2S_MODE_FULL_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+                hipLaunchKernelGGL(stereo_warp_lanes<D2S_MODE_FULL_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rounds);
             else if (lanes)
-                hipLaunchKernelGGL(stereo_warp_lanes<D2S_MODE_FULL_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+                hipLaunchKernelGGL(stereo_warp_lanes<D2S_MODE_FULL_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rounds);
             else if (g.mode == D2S_MODE_FULL_SBS)
-                hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+                hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rounds);
             else if (g.mode == D2S_MODE_FULL_TAB)
-                hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+                hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rounds);
             else
-                hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_HALF_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
+                hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_HALF_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rounds);
         }
     } else {
         if (rgb_fmt == D2S_FMT_U8_HWC) launch_generic<D2S_FMT_U8_HWC>(rgb, depth, out, out_fmt, batch, g, st);

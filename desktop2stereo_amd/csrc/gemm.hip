@@ -551,8 +551,10 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
     // 21x37 maps with 768 input channels: 14-112 blocks x 108 K tiles): the caller provides e.part
     int nkt = cdiv(K, CPR * (16 / (int)sizeof(T)));
     int ks = 1;
-    if (e.part && e.part_elems > 0 && grid < 128 && nkt >= 24) {
-        ks = nkt / 6; if (ks > 16) ks = 16;
+    static const int sk_grid = getenv("D2S_SPLITK_GRID") ? atoi(getenv("D2S_SPLITK_GRID")) : 128;       // tuning aids
+    static const int sk_div = getenv("D2S_SPLITK_DIV") ? atoi(getenv("D2S_SPLITK_DIV")) : 6;
+    if (e.part && e.part_elems > 0 && (int)grid < sk_grid && nkt >= 24) {
+        ks = nkt / sk_div; if (ks > 16) ks = 16;
         while (ks > 1 && (size_t)ks * M * N > e.part_elems) --ks;
     }
     if (ks > 1) {
