@@ -514,9 +514,45 @@ def rank_body(args, engine_factory=None, device=None):
         except ImportError:
             pass
 
+    default_run = (args.model, args.res, args.precision, args.mode, H, W, B) == ("vitb", 518, "bf16", "Full-SBS", 1080, 1920, 1) and not args.vda
+    if rank == 0 and world == 1 and not fake and default_run and args.resample == "bilinear" and not args.no_profile:
+        # the reference's IS_CUDA pre-process branch (one bicubic + antialias resample of the full frame, depth.py:698-699) is
+        # what its own GPU path runs; the headline uses the CPU branch (north_star: parity with the reference CPU path)
+        import dataclasses
+        p_aa = dataclasses.replace(p, resample="bicubic_aa")
+        pool_aa = [frames_for(5000 + j, B).to(dev) for j in range(4)]
+        out_aa = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=dev)
+        st_aa = max(20, args.steps // 4)
+        dt_aa = timed(lambda i: eng.pipeline(pool_aa[i % 4], p_aa, sp, use_ema=False, out=out_aa), 3, st_aa)
+        result["resample_bicubic_aa"] = {"value": st_aa * B / dt_aa, "unit": "stereo frames/s", "ms_per_step": 1e3 * dt_aa / st_aa,
+                                         "note": "same step with d2s_pre_params.resample = D2S_RESAMPLE_BICUBIC_AA"}
+
     if rank == 0 and world == 1 and not fake and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, weights, p, H, W, args.mode)
         result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        if default_run:
+            # BASELINE configs[0] (the reference's own CPU-runnable case): ViT-S, Half-SBS, 1080p, fill_16_9, Depth Resolution 518
+            # and 336 -- the CPU port beside the HIP path on the same workload
+            import dataclasses
+            from desktop2stereo_amd.config import MODELS as _M
+            from desktop2stereo_amd.weights import make_weights as _mw
+            cfg1, w1 = _M["vits"], _mw(_M["vits"], 0)
+            rows = {}
+            for res1 in (518, 336):
+                p1 = dataclasses.replace(p, depth_resolution=res1, display_mode="Half-SBS", fill_16_9=True)
+                h1, w1_, _ = engine_shape(H, W, res1)
+                sp1 = ops.sbs_params(p1.ipd, p1.depth_strength, p1.convergence, "Half-SBS", True)
+                oh1, ow1 = ops.sbs_shape(H, W, sp1)
+                e1 = ops.Engine(cfg1, w1, h1, w1_, max_batch=1, precision="bf16", device=local_rank)
+                pool1 = [frames_for(7000 + j, 1).to(dev) for j in range(4)]
+                out1 = torch.empty((1, oh1, ow1, 3), dtype=torch.uint8, device=dev)
+                dt1 = timed(lambda i: e1.pipeline(pool1[i % 4], p1, sp1, use_ema=False, out=out1), 5, 50)
+                e1.close()
+                cb = cpu_baseline(cfg1, w1, p1, H, W, "Half-SBS", budget_s=5.0, max_frames=2)
+                rows[f"res{res1}"] = {"gpu_frames_per_s": 50 / dt1, "cpu_port": {k: cb[k] for k in ("value", "cores", "sample")},
+                                      "cpu_port_one_thread": cb.get("one_thread", {}).get("value")}
+            result["config1_vits_half_sbs"] = dict(rows, workload="DepthAnything-v2-vits, 1920x1080, Half-SBS, fill_16_9, batch 1 (BASELINE configs[0]); "
+                                                                  "GPU: bf16 HIP engine; CPU: numpy oracle (kind 'port') on this host")
 
     eng.close()
     if world > 1:
