@@ -35,6 +35,15 @@ namespace d2s {
 // ================================================================================================
 __device__ u32x4 d2s_zero_page[4];
 
+// tuning aid (build with D2S_HIPCC_DEFS=-DD2S_GLDS_TIMING): thread 0 of every block of gemm_glds_kernel stamps the 100 MHz wall
+// clock at entry / ring primed / first K tile landed / K loop done / epilogue done; tools/glds_timeline.py reads them
+#ifdef D2S_GLDS_TIMING
+__device__ unsigned long long glds_timing[4096 * 8];
+#define GL_STAMP(SLOT) { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) glds_timing[blockIdx.x * 8 + (SLOT)] = wall_clock64(); }
+#else
+#define GL_STAMP(SLOT) {}
+#endif
+
 // max(x, floor) on a fragment: floor = 0 gives ReLU, floor = lowest gives identity (no branch in the MFMA stream).
 // bf16 as int16: sign bit set <=> negative, and positive bf16 order like positive int16 -> v_pk_max_i16.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -72,7 +81,10 @@ template <int CPR> __device__ __forceinline__ int swz_row(int r) { return CPR ==
 template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, int STG = 0>
 __global__ void __launch_bounds__(64 * WM * WN)
 gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
-    static_assert(STG == 0 || (STG == 1 && NS == 2), "the register-staged variant uses two LDS stages");
+    // STG: 0 = LDS-DMA ring, every loader; 1 = register-staged, two LDS stages; 2 = "lean" LDS-DMA ring: descriptor-addressed plain
+    // linears only (a.buf guaranteed by the launcher) -- the pointer / implicit-conv loaders and their per-row set-up are compiled out
+    static_assert(STG == 0 || STG == 2 || (STG == 1 && NS == 2), "the register-staged variant uses two LDS stages");
+    constexpr bool LEAN = STG == 2;
     constexpr bool BX3 = std::is_same<T, bx3_t>::value;   // A: fp32 in memory, split hi / lo when the staging registers are stored
     static_assert(!BX3 || CPR == 8, "bf16x3 units are laid out for 128-byte K tiles");
     // (bf16x3 with STG == 0: both operands already in the unit format, LDS-DMA like any other type; STG == 1: A is fp32)
@@ -91,6 +103,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wid / WN, wave_n = wid % WN;
     int tm_, tn_;
+    GL_STAMP(0)
     if (!tile_of_block(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, xn, tm_, tn_)) return;
     const int bm0 = tm_ * BM, bn0 = tn_ * BN;
     // this lane's slot inside a 64-slot wave-instruction: row lane/CPR of RPI, phys chunk lane%CPR;
@@ -105,6 +118,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     const T* arow[AI];
     int aiy[AI], aix[AI];
     bool aok[AI];
+    if constexpr (!LEAN)
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         int m = bm0 + i * NW * RPI + lrow;
@@ -128,8 +142,8 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.ptr), 0, (unsigned)((long)M * a.lda * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(W), 0, (unsigned)((long)((N + 255) / 256 * 256) * Kpad * ES), 0x00020000);
     unsigned voA[AI], voW[BI];
-    if constexpr (STG == 0) {
-        if (a.buf) {
+    if constexpr (STG != 1) {
+        if (LEAN || a.buf) {
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 const int m = bm0 + i * NW * RPI + lrow;
@@ -148,10 +162,10 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     }
 
     // D2S_MOVE(slot index, source, LDS destination): LDS-DMA straight into the ring, or a load into staging registers
-    u32x4 stg[1][STG ? LPT : 1];
+    u32x4 stg[1][STG == 1 ? LPT : 1];
 #define D2S_MOVE(S, IDX, SRC, DST)                                                                                \
     do {                                                                                                         \
-        if constexpr (STG != 0) stg[S][IDX] = *(const u32x4*)(SRC);                                                 \
+        if constexpr (STG == 1) stg[S][IDX] = *(const u32x4*)(SRC);                                                 \
         else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),             \
                                               (__attribute__((address_space(3))) void*)(DST), 16, 0, 0);         \
     } while (0)
@@ -286,21 +300,24 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
         }                                                                                                        \
     }
     bool done_buf = false;
-    if constexpr (STG == 0) {
-        if (a.buf) {                                 // plain linear, descriptor-addressed ring (same ring, same waits)
+    if constexpr (STG != 1) {
+        if (LEAN || a.buf) {                         // plain linear, descriptor-addressed ring (same ring, same waits)
 #pragma unroll
             for (int t = 0; t < PD; ++t)
                 if (t < nkt) D2S_ISSUE_BUF(t)
+            GL_STAMP(1)
             for (int kt = 0; kt < nkt; ++kt) {
                 if (kt + PD - 1 < nkt) wait_vmcnt<(PD - 1) * LPT>();
                 else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
+                if (kt == 0) { GL_STAMP(2) }
                 if (kt + PD < nkt) D2S_ISSUE_BUF(kt + PD)
                 D2S_COMPUTE(kt, 0)
             }
             done_buf = true;
         }
     }
+    if constexpr (!LEAN)
     if (!done_buf) {
     if constexpr (STG == 1) {
         if (nkt > 0) { D2S_ISSUE_TILE(0, 0) D2S_STORE_STG(0, 0) }
@@ -312,6 +329,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     }
     if (a.relu) { D2S_K_LOOP(1) } else { D2S_K_LOOP(0) }
     }
+    GL_STAMP(3)
 #undef D2S_ISSUE_BUF
 #undef D2S_K_LOOP
 #undef D2S_COMPUTE
@@ -413,6 +431,10 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
             if (bm0 + r < M) ((float2*)e.stats_out)[(long)(bn0 / BN) * M + bm0 + r] = t;
         }
     }
+#ifdef D2S_GLDS_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the epilogue's stores have left
+    GL_STAMP(4)
+#endif
 }
 
 // split-K second pass: sum the fp32 partials of all splits and run the fused epilogue once
@@ -542,6 +564,11 @@ conv3_halo_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpa
     });
 }
 
+// descriptor-addressed LDS-DMA: plain A, whole K tiles, 32-bit byte offsets
+static inline bool buf_eligible(const GemmA& a, int M, int N, int K, int Kpad, int bk, size_t es) {
+    return a.mode == A_PLAIN && !a.relu && K % bk == 0 && (long)M * a.lda * (long)es < (1L << 31) && (long)gemm_npad(N) * Kpad * (long)es < (1L << 31);
+}
+
 // tile codes: 64 (64x64), 128 (128x128), 256128 / 256256 (8 waves), 25664 / 25632 (256 x 64|32, 4 waves); 0 = auto
 template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR = 8, int STG = 0>
 static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
@@ -569,8 +596,7 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
     {   // descriptor-addressed LDS-DMA: plain A, whole K tiles (the W zero padding covers nothing then), 32-bit byte offsets
         static const bool nobuf = getenv("D2S_GEMM_NOBUF") && atoi(getenv("D2S_GEMM_NOBUF")) != 0;
         constexpr int bk = CPR * (16 / (int)sizeof(T));
-        a1.buf = !nobuf && STG == 0 && a.mode == A_PLAIN && !a.relu && K % bk == 0 && (long)M * a.lda * (long)sizeof(T) < (1L << 31) &&
-                 (long)gemm_npad(N) * Kpad * (long)sizeof(T) < (1L << 31);
+        a1.buf = !nobuf && STG != 1 && buf_eligible(a, M, N, K, Kpad, bk, sizeof(T));
     }
     hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid), dim3(64 * WM * WN), 0, st, a1, (const T*)W, M, N, K, Kpad, e1, xn);
 }
@@ -618,7 +644,13 @@ static int launch_bx3(int tile, const GemmA& a, const void* W, int M, int N, int
             else if (b64 >= 384) t = 64648;
             else t = 3264;
         }
-        if (t == 3264) launch_glds<T, 32, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
+        // (latency regime: the deep-ring lean instantiations, as in launch_t)
+        static const int deep = getenv("D2S_GEMM_DEEP") ? atoi(getenv("D2S_GEMM_DEEP")) : 1;
+        const bool dp = deep && buf_eligible(a, M, N, K, Kpad, 32, 4);
+        if (t == 3264 && dp && (long)cdiv(M, 32) * cdiv(N, 64) <= 512) launch_glds<T, 32, 64, 2, 2, 6, 8, 2>(a, W, M, N, K, Kpad, e, st);
+        else if (t == 64648 && dp && (long)cdiv(M, 64) * cdiv(N, 64) <= 512) launch_glds<T, 64, 64, 4, 2, 4, 8, 2>(a, W, M, N, K, Kpad, e, st);
+        else if (t == 641288 && dp && (long)cdiv(M, 64) * cdiv(N, 128) <= 512) launch_glds<T, 64, 128, 2, 4, 3, 8, 2>(a, W, M, N, K, Kpad, e, st);
+        else if (t == 3264) launch_glds<T, 32, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
         else if (t == 64648) launch_glds<T, 64, 64, 4, 2, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);
         else if (t == 641288) launch_glds<T, 64, 128, 2, 4, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);
         else if (t == 1281288) launch_glds<T, 128, 128, 2, 4, 2, 8, 0>(a, W, M, N, K, Kpad, e, st);
@@ -646,6 +678,19 @@ static int launch_bx3(int tile, const GemmA& a, const void* W, int M, int N, int
     return D2S_OK;
 }
 
+// the (BM, BN) of the LDS-DMA tile launch_t picks for a plain linear of this shape (tile == 0 rule below, N > 64)
+static void small_tile_of(int M, int N, int& bm, int& bn) {
+    const long b128 = (long)cdiv(M, 128) * cdiv(N, 128), b64128 = (long)cdiv(M, 64) * cdiv(N, 128), b64 = (long)cdiv(M, 64) * cdiv(N, 64);
+    if (b128 >= 400 && (N >= 1536 || b128 >= 900)) { bm = 128; bn = 128; }
+    else if (b64128 >= 280) { bm = 64; bn = 128; }
+    else if (b64 >= 384) { bm = 64; bn = 64; }
+    else { bm = 32; bn = 64; }
+}
+
+// (Weight warm-up, measured and removed: a small kernel on its own stream pulling the NEXT linear's weight rows into the L2 of the
+//  XCDs that will read them, two launches ahead -- 761-778 frames/s at batch 1 with and without.  Like the K-loop instruction
+//  count (descriptor addressing: +2 %), the K-tile size (256-byte tiles: +-0) and split-K for FC2 (-5 %), cold weights are not
+//  what paces the batch-1 launches.)
 template <typename T>
 static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
     static const int force_tile = getenv("D2S_GEMM_TILE") ? atoi(getenv("D2S_GEMM_TILE")) : 0;
@@ -676,15 +721,34 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
             if ((long)cdiv(M, 256) >= 224) tile = N <= 32 ? (t32 ? t32 : 912832) : (t64 ? t64 : 9256648);
             else tile = 3264;
         }
-        else if (b128 >= 400 && (N >= 1536 || b128 >= 900)) tile = 1281288;
-        else if (b64128 >= 280) tile = 641288;
-        else if (b64 >= 384) tile = 64648;
-        else tile = 3264;                           // skinny launches (batch 1, N = 768): more, smaller blocks
+        else {
+            int bm = 0, bn = 0;
+            small_tile_of(M, N, bm, bn);
+            tile = bm == 128 ? 1281288 : (bn == 128 ? 641288 : (bm == 64 ? 64648 : 3264));     // 3264: skinny launches (batch 1, N = 768)
+        }
+    }
+    // Latency regime (batch 1-2: every block of the launch is resident at once, 1-2 per CU).  In-kernel stamps (tools/glds_timeline.py)
+    // put a K tile at (LDS-DMA latency ~ 1 800 cycles) / (tiles in flight): 615 cycles with the 4-stage ring of the 32 x 64 tile, 1 100-1 300
+    // with the 2-stage rings of the 8-wave tiles, next to 64-256 cycles of MFMA work.  The LDS those few blocks leave unused buys
+    // ring depth: as many stages as still let ALL blocks be resident.  "Lean" instantiations (descriptor loader only).
+    if constexpr (std::is_same<T, bf16_t>::value || std::is_same<T, fp8_t>::value) {
+        static const int deep = getenv("D2S_GEMM_DEEP") ? atoi(getenv("D2S_GEMM_DEEP")) : 1;
+        static const bool nobuf = getenv("D2S_GEMM_NOBUF") && atoi(getenv("D2S_GEMM_NOBUF")) != 0;
+        if (deep && !nobuf && !(e.part && e.ksplit > 1) && buf_eligible(a, M, N, K, Kpad, 128 / (int)sizeof(T), sizeof(T)) && e.map != MAP_HEAD) {
+            bool done = true;
+            if (tile == 3264 && (long)cdiv(M, 32) * cdiv(N, 64) <= 512) launch_glds<T, 32, 64, 2, 2, 6, 8, 2>(a, W, M, N, K, Kpad, e, st);            // 72 KiB: 2 blocks / CU
+            else if (tile == 64648 && (long)cdiv(M, 64) * cdiv(N, 64) <= 512) launch_glds<T, 64, 64, 4, 2, 4, 8, 2>(a, W, M, N, K, Kpad, e, st);       // 64 KiB: 2 blocks / CU
+            else if (tile == 641288 && (long)cdiv(M, 64) * cdiv(N, 128) <= 512) launch_glds<T, 64, 128, 2, 4, 3, 8, 2>(a, W, M, N, K, Kpad, e, st);    // 72 KiB: 2 blocks / CU
+            else done = false;
+            if (done) { D2S_CHECK_LAUNCH(); return D2S_OK; }
+        }
     }
     // LDS-DMA ring (NS stages)
     if (tile == 256128) launch_glds<T, 256, 128, 4, 2, 3>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 128) launch_glds<T, 128, 128, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 64) launch_glds<T, 64, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
+    // (256-byte K tiles for this tile -- half the barrier-paced iterations -- measured at batch 1: 768 vs 766 frames/s with three
+    //  ring stages, 726 with two: the batch-1 launches are not paced by their K-loop iteration count)
     else if (tile == 3264) launch_glds<T, 32, 64, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
     // (One-round shapes for M = 778 -- 48 x 64, 96 x 64, 48 / 96 / 80 / 112 x 128, 112 x 96: 108-240 blocks of 2-4 waves, fewer
     //  fill bytes per CU than two rounds of a small tile -- were instantiated and swept at batch 1: 1.2-4 x SLOWER than the
@@ -779,3 +843,11 @@ extern "C" int d2s_gemm_probe(const float* A, const float* Wt, const float* bias
     D2S_HIP(err);
     return D2S_OK;
 }
+
+#ifdef D2S_GLDS_TIMING
+extern "C" int d2s_glds_timing(unsigned long long* out, int clear) {      // out != null: read 4096 x 8 stamps
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(d2s::glds_timing), sizeof(unsigned long long) * 4096 * 8) != hipSuccess) return 1;
+    if (clear) { static unsigned long long zeros[4096 * 8]; return hipMemcpyToSymbol(HIP_SYMBOL(d2s::glds_timing), zeros, sizeof(zeros)) != hipSuccess; }
+    return 0;
+}
+#endif
