@@ -11,6 +11,14 @@ namespace d2s {
 void set_error(const std::string& msg);
 int hip_fail(hipError_t err, const char* what, const char* file, int line);
 
+// Integer switch from the environment (kernel selection for A/B runs and tests): cached, re-read after
+// d2s_debug_reload_env() so that one process can run both sides.  Usage:  static EnvInt f{"D2S_NO_X", 0};  if (f.get()) ...
+int env_generation();
+struct EnvInt {
+    const char* name; int dflt; int gen = 0; int val = 0;
+    int get();
+};
+
 #define D2S_HIP(call)                                                           \
     do {                                                                        \
         hipError_t _e = (call);                                                 \

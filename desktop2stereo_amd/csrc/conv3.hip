@@ -21,6 +21,24 @@ namespace d2s {
 
 template <int N_> __device__ __forceinline__ void c3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory"); }
 
+// Bank rule of the halo reads.  ds_read_b128 serves the wave in four groups of 16 lanes, {0-3, 12-15, 20-27}, {4-11, 16-19,
+// 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS table): with lane = 16 fg + fr a group holds fr in S = {0-3, 12-15} of
+// one k group and fr in S' = {4-11} of the NEXT k group.  Chunk slot mod 16 of a lane = pixel * PST + chunk.
+//   * even PST (10, C = 64): pixel * 10 is even, the neighbouring k group is one chunk on -> evens and odds, conflict-free;
+//   * odd PST (17, C = 128; 18 would need 2 x 84.6 KB of LDS -- one block per CU instead of two): slot = pixel + chunk mod 16,
+//     and with pixel = fr the two halves {S + k} and {S' + k + 1} collide in one bank quad per group (PMC: 39 % of the LDS
+//     cycles were conflict cycles, profiles/r3_02).  Fix: lanes of S take the EVEN tile columns and lanes of S' the odd ones
+//     (which lane owns which pixel is free: the epilogue follows), and the chunks of a pixel are stored with bits 0 / 1
+//     swapped, so that neighbouring k groups sit TWO slots apart: evens + k and odds + k + 2 never meet.
+template <int PST> __device__ __forceinline__ int c3_lane_pixel(int fr) {
+    if constexpr ((PST & 1) == 0) return fr;
+    else return fr < 4 ? 2 * fr : (fr < 12 ? 2 * (fr - 4) + 1 : 2 * (fr - 8));
+}
+template <int PST> __device__ __forceinline__ int c3_chunk_slot(int c) {
+    if constexpr ((PST & 1) == 0) return c;
+    else return (c & ~3) | ((c & 1) << 1) | ((c >> 1) & 1);
+}
+
 // CPP: 16-byte chunks per input pixel (C / 8: 8 | 16);  PST: pixel stride in LDS, in chunks;  BN: output channels per block;
 // WM x WN waves over the 8 x 16 pixel tile (wave_m owns FM = 8 / WM tile rows) and the BN channels;  NS: weight ring stages.
 template <int CPP, int PST, int BN, int WM, int WN, int NS>
@@ -77,7 +95,7 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
             if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) v = *(const u32x4*)(img + ((long)iy * a.Wi + ix) * a.C + c * 8);
             s16x8_ x = __builtin_bit_cast(s16x8_, v);
             x = __builtin_elementwise_max(x, (s16x8_){floor_, floor_, floor_, floor_, floor_, floor_, floor_, floor_});
-            halo[p * PST + c] = __builtin_bit_cast(u32x4, x);
+            halo[p * PST + c3_chunk_slot<PST>(c)] = __builtin_bit_cast(u32x4, x);
         }
     }
 
@@ -87,10 +105,11 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
-    // A fragment of tile row i: halo pixel (row i + ky, column fr + kx), chunk 8 sub + 4 ks + fg  =  hb[i] + constant
+    const int px = c3_lane_pixel<PST>(fr);                 // tile column of this lane's pixel (see c3_lane_pixel)
+    // A fragment of tile row i: halo pixel (row i + ky, column px + kx), chunk 8 sub + 4 ks + fg  =  hb[i] + constant
     const u32x4* hb[FM];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) hb[i] = halo + ((wave_m * FM + i) * HWD + fr) * PST + fg;
+    for (int i = 0; i < FM; ++i) hb[i] = halo + ((wave_m * FM + i) * HWD + px) * PST + c3_chunk_slot<PST>(fg);
     // W fragment rows of this wave: row j * 16 + fr of its BN / WN rows, chunk (4 ks + fg) ^ swizzle(row)
     int wro[FN], wsw[FN];
 #pragma unroll
@@ -119,8 +138,8 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
     });
 #undef C3_ISSUE_W
 
-    // ---- epilogue: tile row -> output pixel (ty0 + row, tx0 + fr)
-    const int x = tx0 + fr;
+    // ---- epilogue: tile row -> output pixel (ty0 + row, tx0 + px)
+    const int x = tx0 + px;
     if constexpr (WN == 1) {
         // MAP_HEAD: depth[m] = act(b3 + sum_n w3[n] * relu(acc[m][n] + bias[n]))  (conv2 -> ReLU -> conv3 1x1 -> ReLU | sigmoid)
         if (e.map == MAP_HEAD) {
@@ -291,6 +310,252 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
     }
 }
 
+// ================================================================================================
+// C = 128 -> N = 128 on the large maps in the batched regime (the fusion stages' residual units: 8 of the 21 convolutions at batch
+// 32, 60 % of their time): persistent 8-wave blocks, 256-pixel tiles, the W ring running on ACROSS tiles, two wave groups in
+// ping-pong.  conv3_wide_kernel<TH, TW>.
+// The one-shot blocks above are DMA-latency bound: with the 49 KB halo two blocks per CU leave room for TWO 16 KB weight stages
+// each, so the refill of a stage has one K tile of cover (~500 MFMA cycles per SIMD) against ~2 000 cycles of LDS-DMA latency
+// under load -- waves wait 60 % of their cycles (profiles/r3_02).  Here
+//   * ONE block per CU: tile 8 x 32 or 16 x 16 pixels (whichever pads the map less), halo 10 x 34 | 18 x 18 pixels x 272 B
+//     = 92 | 88 KB, and an EIGHT-stage W ring of 8 KB stages (128 rows x 32 channels of one tap = one MFMA K step; 36 K tiles per
+//     tile): a stage is requested seven K tiles before its MFMAs and waited for five K tiles after the request;
+//   * wave tile 64 pixels x 64 channels (4 x 4 fragments, 64 accumulators): 8 fragment reads per 16 MFMAs instead of 6 per 8;
+//   * the ring never drains: the K tiles of W are the same for every tile, so K tiles 29..34 of a tile request the first six of the
+//     next (36 = 4 mod 8: the stage of K tile 0 alternates between 0 and 4 -- one scalar per tile);
+//   * the NEXT tile's halo is fetched into registers (11 x 16 B per thread) at K tile 28 and stored over the halo buffer after the
+//     last K tile;
+//   * the epilogue requests every residual value of the wave before it touches the first (the output may alias the residual, so the
+//     compiler keeps each load behind the previous store: sixteen dependent round trips, 17.9 us per tile, measured -> 3.4 us).
+// Schedule inside a tile: see the K loop.  Measured per tile (tools/c3_timeline.py, batch 32): K loop 12.4 us (7.7 us of MFMA at
+// 2.4 GHz), epilogue + halo store 4.5 us; the eight launches of a batch-32 step 1.29 ms -> 0.62 ms of block lifetime, the step's
+// convolutions 2.01 -> 1.85 ms (0.25 -> 0.275 of the dense bf16 peak), +2.3 % frames/s.
+// vmcnt bookkeeping (in-order retire): in its M slot of K tile kt a wave waits for its part of W(kt + 2); younger than it are
+// W(kt + 3 .. kt + 7) = 5 requests, and -- for kt = 28..33, the last wait of the loop -- the halo loads issued at K tile 28 (+ NLD):
+// no wait inside the K loop depends on HBM answering them; at the start of a tile everything is drained once (W(0..5), the halo
+// registers were consumed, the previous tile's stores).
+// ================================================================================================
+// tuning aid (D2S_HIPCC_DEFS=-DD2S_C3_TIMING): thread 0 of every block accumulates the 100 MHz wall-clock time it spends per phase
+// over all its tiles: [0] K loop, [1] epilogue, [2] barrier + halo store, [3] tiles, [4] K tile 0 (incl. the drain), [5] lifetime
+#ifdef D2S_C3_TIMING
+__device__ unsigned long long c3_timing[256 * 8];
+#define C3_T(var) const long var = wall_clock64();
+#define C3_ACC(SLOT, expr) { if (threadIdx.x == 0 && blockIdx.x < 256) c3_timing[blockIdx.x * 8 + (SLOT)] += (unsigned long long)(expr); }
+#else
+#define C3_T(var) {}
+#define C3_ACC(SLOT, expr) {}
+#endif
+
+template <int TH, int TW>
+__global__ void __launch_bounds__(512)
+conv3_wide_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEpi e, int ntiles) {
+    constexpr int CPP = 16, PST = 17, HWD = TW + 2, HPX = (TH + 2) * HWD, HALO = HPX * PST;
+    constexpr int NCH = HPX * CPP, NLD = (NCH + 511) / 512;
+    constexpr int NW = 8, WN = 2, FM = 4, FN = 4, FPR = TW / 16;
+    constexpr int NS = 8, WST = 128 * 4, NKT = 36, PD = NS - 1;  // W ring: 8 stages of 128 rows x 64 B (32 channels of one tap), 36 K tiles
+    constexpr int HKT = 28;                                   // K tile whose issue slot also requests the next halo (see below)
+    static_assert(TH * TW == 256 && TW % 16 == 0, "256-pixel tiles of 16-pixel fragments");
+    __shared__ __attribute__((aligned(16))) u32x4 lds[NS * WST + HALO];
+    u32x4* const halo = lds + NS * WST;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wid / WN, wave_n = wid % WN, grp = wid >> 2;
+    const int fr = lane & 15, fg = lane >> 4, px = c3_lane_pixel<PST>(fr);
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+
+    // tiles: XCD x (= blockIdx % 8) owns the contiguous run [x per, (x + 1) per) and its CUs walk it together
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3, per = (ntiles + 7) >> 3;
+    auto tile_id = [&](int j) { return (j < per && xcd * per + j < ntiles) ? xcd * per + j : -1; };
+    int j = slot, t = tile_id(j);
+    if (t < 0) return;
+
+    // W stage = 128 rows x 4 chunks; one LDS-DMA instruction per wave per stage: wave w brings rows 16 w .. 16 w + 15, lane l row
+    // l / 4, slot l % 4.  Row r keeps chunk c in slot c ^ g(r / 4), g = {0, 2, 3, 1}: the 16-lane groups of a fragment read
+    // (c3 bank rule above: rows S of k group c with rows S' of k group c + 1) then cover all 16 slots mod 16 once.
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(W), 0, (unsigned)((long)((N + 255) / 256 * 256) * Kpad * 2), 0x00020000);
+    auto wswz = [](int r) { const int k = (r >> 2) & 3; return (((k ^ (k >> 1)) & 1) << 1) | (k >> 1); };
+    unsigned voW;
+    {
+        const int r = wid * 16 + (lane >> 2);
+        voW = (unsigned)((long)r * Kpad * 2) + (unsigned)(((lane & 3) ^ wswz(r)) * 16);
+    }
+    auto issue_w = [&](int stage, int kt) { lds_dma16(rsW, lds + stage * WST + wid * 64, voW, kt * 64); };
+
+    typedef short s16x8_ __attribute__((ext_vector_type(8)));
+    const short floor_ = a.relu ? (short)0 : (short)0x8000;
+    u32x4 hr[NLD];
+    auto tile_org = [&](int tt, int& b, int& ty0, int& tx0) {
+        b = tt / (tiles_y * tiles_x);
+        const int r = tt - b * (tiles_y * tiles_x);
+        ty0 = (r / tiles_x) * TH; tx0 = (r % tiles_x) * TW;
+    };
+    auto load_halo = [&](int tt) {
+        int b, ty0, tx0;
+        tile_org(tt, b, ty0, tx0);
+        const bf16_t* img = (const bf16_t*)a.ptr + (long)b * a.Hi * a.Wi * a.C;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 512;
+            const int p = idx >> 4, c = idx & 15;
+            const int hy = p / HWD, hx = p - hy * HWD;
+            int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+            const bool in = idx < NCH && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+            iy = in ? iy : 0; ix = in ? ix : 0;                 // (always ONE load per k: the vmcnt arithmetic counts them)
+            const u32x4 v = *(const u32x4*)(img + ((long)iy * a.Wi + ix) * a.C + c * 8);
+            hr[k] = in ? v : (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 512;
+            if (idx < NCH) {
+                s16x8_ x = __builtin_bit_cast(s16x8_, hr[k]);
+                x = __builtin_elementwise_max(x, (s16x8_){floor_, floor_, floor_, floor_, floor_, floor_, floor_, floor_});
+                halo[(idx >> 4) * PST + c3_chunk_slot<PST>(idx & 15)] = __builtin_bit_cast(u32x4, x);
+            }
+        }
+    };
+
+    // A fragment i of this wave = tile fragment 4 wave_m + i: tile row f / FPR, columns 16 (f % FPR) ..; halo pixel (row + ky, col + kx)
+    const u32x4* hb[FM];
+    int frow[FM], fcol[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int f = wave_m * FM + i;
+        frow[i] = f / FPR; fcol[i] = (f % FPR) * 16 + px;
+        hb[i] = halo + (frow[i] * HWD + fcol[i]) * PST + c3_chunk_slot<PST>(fg);
+    }
+    int wro[FN];                                              // W fragment of n block jn: row wave_n 64 + 16 jn + fr, chunk fg
+#pragma unroll
+    for (int jn = 0; jn < FN; ++jn) { const int r = wave_n * 64 + jn * 16 + fr; wro[jn] = r * 4 + (fg ^ wswz(r)); }
+
+#pragma unroll
+    for (int k = 0; k < PD - 1; ++k) issue_w(k, k);
+    load_halo(t);
+    store_halo();
+    int gb = 0;                                               // ring stage of this tile's K tile 0
+    C3_T(t_begin)
+    while (t >= 0) {
+        C3_T(t_a)
+        const int tn = tile_id(j + nslot);
+        const int tl = tn >= 0 ? tn : t;                      // (no next tile: the loads are still issued -- counted -- and dropped)
+        f32x4 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) acc[i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // K tile kt = tap kt / 4, channels 32 (kt % 4) ..: one MFMA K step.  Fragments are read ONE K tile ahead of the MFMAs that use
+        // them (two register sets), right behind the barrier that makes that stage visible.
+        u32x4 fa[2][FM], fb[2][FN];
+        auto read_frags = [&](auto ktc, u32x4* fa_, u32x4* fb_) {
+            constexpr int kt = decltype(ktc)::value;
+            constexpr int tap = kt / 4, q = kt % 4, ky = tap / 3, kx = tap % 3;
+            const u32x4* B_l = lds + ((gb + kt) & (NS - 1)) * WST;
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) fb_[jn] = B_l[wro[jn]];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa_[i] = hb[i][(ky * HWD + kx) * PST + q * 4];
+        };
+        // Schedule: the eight waves are two groups of four (waves w and w + 4 share a SIMD) that run the same K loop ONE BARRIER SLOT
+        // apart: slot = X (the 16 MFMAs of K tile kt) or M (request W(kt + 7), read the fragments of kt + 1, wait for my part of
+        // W(kt + 2)); while one group is in X its SIMD partner is in M.  With everybody in the same phase a barrier per K tile cost
+        // ~340 cycles of idle matrix pipe (barrier release + LDS-DMA issue + fragment reads: K loop 13.9 us against 8.9 without
+        // barriers, tools/c3_timeline.py).  Dependences: frags(kt + 1) are read in M(kt); every wave waited for its part of
+        // W(kt + 1) in its M(kt - 1), at least one barrier earlier; W(kt + 7) overwrites the stage of K tile kt - 1, whose MFMAs every
+        // wave has issued before the barrier in front of anybody's M(kt).
+        c3_wait_vm<0>();                                      // W(0 .. 5) of this tile, the previous tile's stores; my halo stores (lgkmcnt)
+        __builtin_amdgcn_s_barrier();
+        issue_w((gb + PD - 1) & (NS - 1), PD - 1);            // W(6) (stage of the previous tile's K tile 34: free since that barrier)
+        read_frags(std::integral_constant<int, 0>{}, fa[0], fb[0]);
+        if (grp) __builtin_amdgcn_s_barrier();                // group 1 runs one slot behind
+        static_for<NKT>([&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < FN; ++jn) mma_chunk(acc[i][jn], fb[kt & 1][jn], fa[kt & 1][i], bf16_t());
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if constexpr (kt < NKT - 1) {
+                issue_w((gb + kt + PD) & (NS - 1), (kt + PD) % NKT);    // (among the MFMAs of the X slot instead: K loop 12.4 -> 13.9 us)
+                if constexpr (kt == HKT) load_halo(tl);
+                read_frags(std::integral_constant<int, kt + 1>{}, fa[(kt + 1) & 1], fb[(kt + 1) & 1]);
+                // my part of W(kt + 2) (younger: W(kt + 3 .. kt + 7), and the halo loads where they are younger)
+                if constexpr (kt + 2 < NKT) {
+                    if constexpr (kt >= HKT && kt <= HKT + PD - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD + PD - 2) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD - 2) : "memory");
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+#ifdef D2S_C3_TIMING
+            if constexpr (kt == 0) { C3_ACC(4, wall_clock64() - t_a) }
+#endif
+        });
+        if (!grp) __builtin_amdgcn_s_barrier();               // the groups meet again
+        C3_T(t_b)
+        C3_ACC(0, t_b - t_a)
+        // ---- epilogue, in two phases: every residual load of the wave first (one round trip instead of sixteen dependent ones:
+        // the output may alias the residual, so the compiler keeps each load behind the previous store), the barrier and the halo
+        // store under their latency, then bias / activation / residual / packed stores.  Same operation order as epilogue4<bf16_t>.
+        // (requesting the residual values inside the K loop -- K tile 28 with the halo, or K tile 33 -- made the loop 3-4 us slower
+        // per tile than it saved here, measured)
+        int b, ty0, tx0;
+        tile_org(t, b, ty0, tx0);
+        bool ok[FM];
+        long mo[FM];
+        uint2 rr[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int y = ty0 + frow[i], x = tx0 + fcol[i];
+            ok[i] = y < a.Ho && x < a.Wo;
+            mo[i] = ok[i] ? ((long)(b * a.Ho + y) * a.Wo + x) * e.ldc + wave_n * 64 + fg * 4 : (long)(wave_n * 64 + fg * 4);
+        }
+        auto load_res = [&]() {
+            const bf16_t* rp = (const bf16_t*)e.res1;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < FN; ++jn) rr[i][jn] = *(const uint2*)(rp + mo[i] + jn * 16);
+        };
+        float cb[FN][4];                                      // bias of this lane's columns
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn) {
+            if (e.bias) load4(e.bias + wave_n * 64 + jn * 16 + fg * 4, cb[jn]);
+            else cb[jn][0] = cb[jn][1] = cb[jn][2] = cb[jn][3] = 0.f;
+        }
+        if (e.res1) load_res();
+        C3_T(t_c)
+        C3_ACC(1, t_c - t_b)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): my halo reads are done
+        __builtin_amdgcn_s_barrier();                         // everybody's are: the halo buffer may be overwritten
+        if (tn >= 0) store_halo();
+        C3_T(t_d)
+        C3_ACC(2, t_d - t_c)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) {
+                float v[4] = {acc[i][jn][0] + cb[jn][0], acc[i][jn][1] + cb[jn][1], acc[i][jn][2] + cb[jn][2], acc[i][jn][3] + cb[jn][3]};
+                if (e.act == ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (e.res1) {
+                    const uint2 r = rr[i][jn];
+                    v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+                    v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+                }
+                if (ok[i]) *(uint2*)((bf16_t*)e.out + mo[i] + jn * 16) = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+            }
+        C3_ACC(6, wall_clock64() - t_d)
+        C3_ACC(3, 1)
+        gb = (gb + NKT) & (NS - 1); t = tn; j += nslot;
+    }
+    c3_wait_vm<0>();                                          // the ring's last requests must land before the LDS is released
+    C3_ACC(5, wall_clock64() - t_begin)
+}
+
 // (A persistent form of the 128-channel kernel -- one 8-wave block per CU, next halo prefetched by four "halo" waves while four
 // "weight" waves ran a 3-stage LDS-DMA ring across tile boundaries -- was built and measured at batch 32: 226-246 us per
 // 84 x 148 convolution against 168-185 us for the one-shot blocks above, head conv1 446 against 370.  With 16 KiB weight stages the
@@ -300,20 +565,35 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
 // Eligible: bf16, stride 1, same-size output, C = 64 | 128, K = 9 C, plain row mapping or the fused head, enough tiles to fill the
 // chip.  D2S_NO_HALO2=1 keeps the first-generation kernels (the parity tests run both).
 bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
-    static const bool off = getenv("D2S_NO_HALO2") && atoi(getenv("D2S_NO_HALO2")) != 0;
-    if (off) return false;
+    static EnvInt off{"D2S_NO_HALO2", 0};
+    if (off.get()) return false;
     if (a.mode != A_CONV3 || a.stride != 1 || a.Hi != a.Ho || a.Wi != a.Wo || (a.C != 64 && a.C != 128) || K != 9 * a.C) return false;
     if (!(e.map == MAP_ROWS || e.map == MAP_HEAD) || e.rows_per_img || e.ln_stats || e.stats_out || e.deq || e.ksplit > 1) return false;
     if (e.map == MAP_HEAD && N > 32) return false;
     if (N != 32 && N != 64 && (N & 127)) return false;
     const int nimg = M / (a.Ho * a.Wo);
     if ((long)nimg * a.Ho * a.Wo != M) return false;
-    static const bool no_persist = getenv("D2S_NO_HEADP") && atoi(getenv("D2S_NO_HEADP")) != 0;
-    if (!no_persist && e.map == MAP_HEAD && a.C == 64 && N <= 32 && (long)nimg * cdiv(a.Ho, 16) * cdiv(a.Wo, 16) >= 256) {
+    static EnvInt no_persist{"D2S_NO_HEADP", 0};
+    if (!no_persist.get() && e.map == MAP_HEAD && a.C == 64 && N <= 32 && (long)nimg * cdiv(a.Ho, 16) * cdiv(a.Wo, 16) >= 256) {
         static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
         const int ntiles = nimg * cdiv(a.Ho, 16) * cdiv(a.Wo, 16);
         hipLaunchKernelGGL((conv3_head_kernel<0>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         return true;
+    }
+    static EnvInt no_wide{"D2S_NO_WIDE", 0};
+    if (!no_wide.get() && e.map == MAP_ROWS && a.C == 128 && N == 128 && (long)gemm_npad(N) * Kpad * 2 < (1L << 31) &&
+        (e.out_type == OUT_T || e.out_type == OUT_BF16) && !e.scale && !e.res2 && !e.res1_mod && (e.act == ACT_NONE || e.act == ACT_RELU)) {
+        static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+        static EnvInt wide_min{"D2S_WIDE_MIN", 384};                                                       // tiles (1.5 rounds of the CUs)
+        const long pad_a = (long)cdiv(a.Ho, 8) * cdiv(a.Wo, 32), pad_b = (long)cdiv(a.Ho, 16) * cdiv(a.Wo, 16);   // 256-pixel tiles per image
+        const long ntl = nimg * std::min(pad_a, pad_b);
+        const int grid_w = ncu & ~7;
+        if (ntl >= wide_min.get() && ntl < (1L << 30) && grid_w >= 8) {
+            GemmEpi e1 = e; e1.ksplit = 1;
+            if (pad_a <= pad_b) hipLaunchKernelGGL((conv3_wide_kernel<8, 32>), dim3(grid_w), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e1, (int)ntl);
+            else hipLaunchKernelGGL((conv3_wide_kernel<16, 16>), dim3(grid_w), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e1, (int)ntl);
+            return true;
+        }
     }
     const long tiles_m = (long)nimg * cdiv(a.Ho, 8) * cdiv(a.Wo, 16);
     const int bn = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
@@ -339,3 +619,11 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
 }
 
 }  // namespace d2s
+
+#ifdef D2S_C3_TIMING
+extern "C" int d2s_c3_timing(unsigned long long* out, int clear) {        // out != null: read 256 x 8 counters
+    if (out) D2S_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(d2s::c3_timing), sizeof(unsigned long long) * 256 * 8));
+    if (clear) { static unsigned long long z[256 * 8]; D2S_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d2s::c3_timing), z, sizeof(z))); }
+    return D2S_OK;
+}
+#endif

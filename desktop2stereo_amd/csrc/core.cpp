@@ -1,6 +1,8 @@
 // Error plumbing and version of libd2s_hip.so.
 #include "common.h"
 
+#include <atomic>
+#include <cstdlib>
 #include <mutex>
 
 namespace d2s {
@@ -15,7 +17,16 @@ int hip_fail(hipError_t err, const char* what, const char* file, int line) {
     return D2S_E_HIP;
 }
 
+static std::atomic<int> g_env_gen{1};
+int env_generation() { return g_env_gen.load(std::memory_order_relaxed); }
+int EnvInt::get() {
+    const int g = env_generation();
+    if (gen != g) { const char* v = getenv(name); val = v ? atoi(v) : dflt; gen = g; }
+    return val;
+}
+
 }  // namespace d2s
 
+extern "C" int d2s_debug_reload_env(void) { return d2s::g_env_gen.fetch_add(1) + 1; }
 extern "C" const char* d2s_last_error(void) { return d2s::g_err.c_str(); }
 extern "C" int d2s_version(void) { return 100; }

@@ -605,8 +605,8 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
 // implicit-GEMM loader (the parity tests run both)
 template <typename T>
 static bool launch_conv_halo(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
-    static const bool off = getenv("D2S_NO_HALO") && atoi(getenv("D2S_NO_HALO")) != 0;
-    if (off) return false;
+    static EnvInt off{"D2S_NO_HALO", 0};
+    if (off.get()) return false;
     if constexpr (std::is_same<T, fp8_t>::value) return false;
     else {
     const int cpp = a.C * (int)sizeof(T) / 16;

@@ -412,6 +412,11 @@ class Engine:
             pass
 
 
+def reload_env() -> int:
+    """Make libd2s_hip.so re-read its kernel-selection switches (D2S_NO_HALO2, D2S_NO_WIDE, ...) from the environment."""
+    return int(_lib.load().d2s_debug_reload_env())
+
+
 def gemm_probe(A: torch.Tensor, Wt: torch.Tensor, bias: Optional[torch.Tensor], precision: str, tile: int = 0, iters: int = 1):
     """C = A @ Wt^T (+bias) through the engine's MFMA kernel (test / micro-benchmark)."""
     M, K = A.shape

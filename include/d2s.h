@@ -137,6 +137,9 @@ typedef struct d2s_dibr_params {
 
 const char* d2s_last_error(void);
 int d2s_version(void);
+/* Kernel-selection switches (D2S_NO_HALO2, D2S_NO_WIDE, ... -- tuning aids) are read from the environment once and
+ * cached; this makes the library read them again (tests run both sides of a switch in one process).  Returns the new generation. */
+int d2s_debug_reload_env(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Engine life cycle -- replaces DepthModelWrapper construction + lazy engine build
