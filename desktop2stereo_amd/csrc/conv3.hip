@@ -164,6 +164,25 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
             return;
         }
     }
+    EpiCols cols[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n0 = bn0 + wave_n * (BN / WN) + j * 16 + fg * 4;
+        if (n0 < N) epi_cols_load(e, n0, cols[j]);
+    }
+    float pre[FM][FN][4];                                   // residual values, all requested before the first store (gemm_epi.h)
+    const bool pre_on = epi_res1_ahead(e);
+    if (pre_on) {
+        static_for<FM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int y = ty0 + wave_m * FM + i;
+            static_for<FN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int n0 = bn0 + wave_n * (BN / WN) + j * 16 + fg * 4;
+                if (y < a.Ho && x < a.Wo && n0 < N) epi_res1_load<bf16_t>(e, (b * a.Ho + y) * a.Wo + x, n0, pre[i][j]);
+            });
+        });
+    }
     static_for<FM>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int y = ty0 + wave_m * FM + i;
@@ -174,7 +193,7 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
                 const int n0 = bn0 + wave_n * (BN / WN) + j * 16 + fg * 4;
                 if (n0 < N) {
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    epilogue_dispatch<bf16_t>(e, m, n0, v);
+                    epilogue_dispatch<bf16_t>(e, m, n0, v, false, pre_on ? pre[i][j] : nullptr, &cols[j]);
                 }
             });
         }

@@ -374,6 +374,34 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
             else { ln_cs[j][0] = ln_cs[j][1] = ln_cs[j][2] = ln_cs[j][3] = 0.f; }
         }
     }
+    // Latency regime only (the lean instantiations, every block resident): column vectors and residual values of all the wave's
+    // fragments are requested before the first store (gemm_epi.h, epi_res1_load).  In the throughput tiles the extra registers
+    // cost resident waves (64 x 128: 70 -> 100 VGPRs, 6 -> 4 waves / SIMD; batch 4: -12 % frames/s, measured) and the other
+    // waves cover the round trips anyway.
+    constexpr bool PRE = STG == 2 && FM * FN <= 8;
+    EpiCols cols[PRE ? FN : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n0 = bn0 + wave_n * (BN / WN) + j * 16 + fg * 4;
+            if (n0 < N) epi_cols_load(e, n0, cols[j]);
+        }
+    }
+    float pre[PRE ? FM : 1][PRE ? FN : 1][4];
+    const bool pre_on = PRE && ksplit == 1 && epi_res1_ahead(e);
+    if constexpr (PRE) {
+        if (pre_on) {
+            static_for<FM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const int m = bm0 + wave_m * (BM / WM) + i * 16 + fr;
+                static_for<FN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const int n0 = bn0 + wave_n * (BN / WN) + j * 16 + fg * 4;
+                    if (m < M && n0 < N) epi_res1_load<T>(e, m, n0, pre[i][j]);
+                });
+            });
+        }
+    }
     // compile-time indices (a plain `#pragma unroll` over this large body is not honoured for the
     // 32-fragment tiles, and a run-time index would put the accumulators in scratch)
     static_for<FM>([&](auto ic) {
@@ -403,7 +431,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
                             v[0] = ln_rstd * (v[0] - ln_mean * ln_cs[j][0]); v[1] = ln_rstd * (v[1] - ln_mean * ln_cs[j][1]);
                             v[2] = ln_rstd * (v[2] - ln_mean * ln_cs[j][2]); v[3] = ln_rstd * (v[3] - ln_mean * ln_cs[j][3]);
                         }
-                        epilogue_dispatch<T>(e, m, n0, v, ln);
+                        epilogue_dispatch<T>(e, m, n0, v, ln, PRE && pre_on ? pre[PRE ? i : 0][PRE ? j : 0] : nullptr, PRE ? &cols[PRE ? j : 0] : nullptr);
                         s1 += (v[0] + v[1]) + (v[2] + v[3]);
                         s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                     }
@@ -547,6 +575,25 @@ conv3_halo_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpa
 #undef D2S_ISSUE_W
     // ---- epilogue: tile row ty -> output pixel (ty0 + ty, tx0 + fr)
     const int x = tx0 + fr;
+    EpiCols cols[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n0 = bn0 + wave_n * (BN / WN) + j * 16 + fg * 4;
+        if (n0 < N) epi_cols_load(e, n0, cols[j]);
+    }
+    float pre[FM][FN][4];                               // residual values, all requested before the first store (gemm_epi.h)
+    const bool pre_on = epi_res1_ahead(e);
+    if (pre_on) {
+        static_for<FM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int y = ty0 + wave_m * FM + i;
+            static_for<FN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int n0 = bn0 + wave_n * (BN / WN) + j * 16 + fg * 4;
+                if (y < a.Ho && x < a.Wo && n0 < N) epi_res1_load<T>(e, (b * a.Ho + y) * a.Wo + x, n0, pre[i][j]);
+            });
+        });
+    }
     static_for<FM>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int y = ty0 + wave_m * FM + i;
@@ -557,7 +604,7 @@ conv3_halo_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpa
                 const int n0 = bn0 + wave_n * (BN / WN) + j * 16 + fg * 4;
                 if (n0 < N) {
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    epilogue_dispatch<T>(e, m, n0, v);
+                    epilogue_dispatch<T>(e, m, n0, v, false, pre_on ? pre[i][j] : nullptr, &cols[j]);
                 }
             });
         }

@@ -141,15 +141,66 @@ template <> __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float v) { return 
 template <> __device__ __forceinline__ fp8_t cvt_out<fp8_t>(float v) { return (fp8_t)(pk_fp8x4(v, 0.f, 0.f, 0.f) & 255u); }
 template <> __device__ __forceinline__ bx3_t cvt_out<bx3_t>(float v) { return bx3_t{__float_as_uint(v)}; }     // (never stored element-wise: MAP_QKV outputs stay fp32)
 
-// skip_deq: the caller (LN-folded consumer on e4m3 operands) already turned the accumulators into real units
+// element offset of (row m, column n0) in the output -- and residual -- layout: plain / remapped rows, or the ConvTranspose(k = s)
+// pixel shuffle
+__device__ __forceinline__ long epi_out_offset(const GemmEpi& e, int m, int n0) {
+    if (e.map == MAP_SHUFFLE) {
+        int x = m % e.gw, y = (m / e.gw) % e.gh, b = m / (e.gw * e.gh);
+        int tap = n0 / e.cout, co = n0 - tap * e.cout;
+        int ky = tap / e.ks, kx = tap - ky * e.ks;
+        return (((long)b * e.gh * e.ks + (long)y * e.ks + ky) * ((long)e.gw * e.ks) + (long)x * e.ks + kx) * e.cout + co;
+    }
+    long row = m;
+    if (e.rows_per_img) row = (long)(m / e.rows_per_img) * e.img_rows + (m % e.rows_per_img) + e.row_off;
+    return row * e.ldc + n0;
+}
+
+// The first residual of (m, n0), requested AHEAD of the epilogue.  The output may alias the residual (the ViT residual stream is
+// updated in place) and, for all the compiler knows, the bias / scale vectors, so inside epilogue4 every load stays behind the
+// previous fragment's store: a wave's FM x FN fragments become as many dependent load -> store round trips (measured in
+// conv3_wide_kernel: 17.9 us per tile against 3.4 with all requests first).  Kernels call epi_res1_load / epi_cols_load for all
+// their fragments first, then epilogue_dispatch(..., pre, cols).
 template <typename OT>
-__device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float v[4], bool skip_deq = false) {
+__device__ __forceinline__ void epi_res1_load4(const GemmEpi& e, int m, int n0, float r[4]) {
+    const long off = epi_out_offset(e, m, n0);
+    const long roff = e.res1_mod ? ((long)(m % e.res1_mod) + e.res1_off) * e.ldc + n0 : off;
+    load4((const OT*)e.res1 + roff, r);
+}
+template <typename T>
+__device__ __forceinline__ void epi_res1_load(const GemmEpi& e, int m, int n0, float r[4]) {
+    if (e.out_type == OUT_F32) epi_res1_load4<float>(e, m, n0, r);
+    else if (e.out_type == OUT_BF16) epi_res1_load4<bf16_t>(e, m, n0, r);
+    else if constexpr (std::is_same<T, bx3_t>::value) {
+        if (e.out_type == OUT_BX3) epi_res1_load4<bx3_t>(e, m, n0, r);
+        else epi_res1_load4<float>(e, m, n0, r);
+    }
+    else epi_res1_load4<T>(e, m, n0, r);
+}
+__device__ __forceinline__ bool epi_res1_ahead(const GemmEpi& e) { return e.res1 != nullptr && (e.map == MAP_ROWS || e.map == MAP_SHUFFLE); }
+
+// Column vectors of a lane's n block (bias, LayerScale), loaded once per column fragment ahead of the stores
+struct EpiCols { float bias[4], scale[4]; };
+__device__ __forceinline__ void epi_cols_load(const GemmEpi& e, int n0, EpiCols& c) {
+    if (e.bias) load4(e.bias + n0, c.bias);
+    if (e.scale) load4(e.scale + n0, c.scale);
+}
+
+// skip_deq: the caller (LN-folded consumer on e4m3 operands) already turned the accumulators into real units;
+// pre: the first residual's values if the caller requested them ahead (epi_res1_load), else null; cols: bias / scale likewise
+template <typename OT>
+__device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float v[4], bool skip_deq = false, const float* pre = nullptr,
+                                          const EpiCols* cols = nullptr) {
     if (e.deq && !skip_deq) { float q[4]; load4(e.deq + n0, q); v[0] *= q[0]; v[1] *= q[1]; v[2] *= q[2]; v[3] *= q[3]; }   // fp8 operands -> real units
-    if (e.bias) { float b[4]; load4(e.bias + n0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+    if (e.bias) {
+        if (cols) { v[0] += cols->bias[0]; v[1] += cols->bias[1]; v[2] += cols->bias[2]; v[3] += cols->bias[3]; }
+        else { float b[4]; load4(e.bias + n0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+    }
     if (e.act == ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
     else if (e.act == ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-    if (e.scale) { float s[4]; load4(e.scale + n0, s); v[0] *= s[0]; v[1] *= s[1]; v[2] *= s[2]; v[3] *= s[3]; }
-    long off;
+    if (e.scale) {
+        if (cols) { v[0] *= cols->scale[0]; v[1] *= cols->scale[1]; v[2] *= cols->scale[2]; v[3] *= cols->scale[3]; }
+        else { float s[4]; load4(e.scale + n0, s); v[0] *= s[0]; v[1] *= s[1]; v[2] *= s[2]; v[3] *= s[3]; }
+    }
     if (e.map == MAP_QKV && n0 >= e.qk_cols) {
         int b = m / e.ntok, t = m - b * e.ntok;
         int c = n0 - e.qk_cols;                       // h*64 + d, 4 consecutive d
@@ -161,19 +212,13 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float
         }
         return;
     }
-    if (e.map == MAP_SHUFFLE) {
-        int x = m % e.gw, y = (m / e.gw) % e.gh, b = m / (e.gw * e.gh);
-        int tap = n0 / e.cout, co = n0 - tap * e.cout;
-        int ky = tap / e.ks, kx = tap - ky * e.ks;
-        off = (((long)b * e.gh * e.ks + (long)y * e.ks + ky) * ((long)e.gw * e.ks) + (long)x * e.ks + kx) * e.cout + co;
-    } else {
-        long row = m;
-        if (e.rows_per_img) row = (long)(m / e.rows_per_img) * e.img_rows + (m % e.rows_per_img) + e.row_off;
-        off = row * e.ldc + n0;
-    }
+    const long off = epi_out_offset(e, m, n0);
     if (e.res1) {
-        long roff = e.res1_mod ? ((long)(m % e.res1_mod) + e.res1_off) * e.ldc + n0 : off;
-        float r[4]; load4((const OT*)e.res1 + roff, r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+        if (pre) { v[0] += pre[0]; v[1] += pre[1]; v[2] += pre[2]; v[3] += pre[3]; }
+        else {
+            long roff = e.res1_mod ? ((long)(m % e.res1_mod) + e.res1_off) * e.ldc + n0 : off;
+            float r[4]; load4((const OT*)e.res1 + roff, r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+        }
     }
     if (e.res2) { float r[4]; load4((const OT*)e.res2 + off, r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
     if constexpr (std::is_same<OT, fp8_t>::value) { v[0] *= e.out_qscale; v[1] *= e.out_qscale; v[2] *= e.out_qscale; v[3] *= e.out_qscale; }
@@ -190,14 +235,15 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float
 
 // out_type -> element type of the output / residuals
 template <typename T>
-__device__ __forceinline__ void epilogue_dispatch(const GemmEpi& e, int m, int n0, float v[4], bool skip_deq = false) {
-    if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v, skip_deq);
-    else if (e.out_type == OUT_BF16) epilogue4<bf16_t>(e, m, n0, v, skip_deq);
+__device__ __forceinline__ void epilogue_dispatch(const GemmEpi& e, int m, int n0, float v[4], bool skip_deq = false, const float* pre = nullptr,
+                                                  const EpiCols* cols = nullptr) {
+    if (e.out_type == OUT_F32) epilogue4<float>(e, m, n0, v, skip_deq, pre, cols);
+    else if (e.out_type == OUT_BF16) epilogue4<bf16_t>(e, m, n0, v, skip_deq, pre, cols);
     else if constexpr (std::is_same<T, bx3_t>::value) {
-        if (e.out_type == OUT_BX3) epilogue4<bx3_t>(e, m, n0, v, skip_deq);                     // pre-split for the next bf16x3 linear
-        else epilogue4<float>(e, m, n0, v, skip_deq);                                           // bf16x3 engines keep fp32 activations
+        if (e.out_type == OUT_BX3) epilogue4<bx3_t>(e, m, n0, v, skip_deq, pre, cols);               // pre-split for the next bf16x3 linear
+        else epilogue4<float>(e, m, n0, v, skip_deq, pre, cols);                                     // bf16x3 engines keep fp32 activations
     }
-    else epilogue4<T>(e, m, n0, v, skip_deq);
+    else epilogue4<T>(e, m, n0, v, skip_deq, pre, cols);
 }
 
 // XCD-aware block -> tile map.  Workgroup b is dispatched to XCD b % 8 (observed, used for speed
