@@ -786,6 +786,9 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
             if (tile == 3264 && (long)cdiv(M, 32) * cdiv(N, 64) <= 512) launch_glds<T, 32, 64, 2, 2, 6, 8, 2>(a, W, M, N, K, Kpad, e, st);            // 72 KiB: 2 blocks / CU
             else if (tile == 64648 && (long)cdiv(M, 64) * cdiv(N, 64) <= 512) launch_glds<T, 64, 64, 4, 2, 4, 8, 2>(a, W, M, N, K, Kpad, e, st);       // 64 KiB: 2 blocks / CU
             else if (tile == 641288 && (long)cdiv(M, 64) * cdiv(N, 128) <= 512) launch_glds<T, 64, 128, 2, 4, 3, 8, 2>(a, W, M, N, K, Kpad, e, st);    // 72 KiB: 2 blocks / CU
+            // (one block per CU with a 128 KiB ring -- 64 x 192 x 4 stages, 128 x 128 on 64-byte K tiles x 4 stages -- for FC1, whose 312
+            //  blocks of 64 x 128 leave 56 CUs with two blocks: 13.5 / 15.6 us against 13.4 back to back; a single block does not reach
+            //  the fill rate two reach together.  Measured, removed.)
             else done = false;
             if (done) { D2S_CHECK_LAUNCH(); return D2S_OK; }
         }
