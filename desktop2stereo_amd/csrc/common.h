@@ -138,6 +138,11 @@ __device__ static inline float head_activation(float v, float max_depth) {
 struct Tap { int i0, i1; float w0, w1; };
 
 __host__ __device__ static inline Tap linear_tap(int dst, float scale, int in_size, bool align_corners) {
+    // no FMA contraction in here: with it, w1 = src - i0 becomes fma(scale, dst, -i0) in one kernel and round(scale * dst) - i0 in
+    // another, depending on what else the inlining context does with src (the stand-alone up-sample and the loader that folds it
+    // into the head convolution differed in a quarter of the output pixels, by one bf16 ulp of an input); the reference multiplies
+    // and subtracts separately
+#pragma clang fp contract(off)
     float src;
     if (align_corners) src = scale * (float)dst;
     else { src = scale * ((float)dst + 0.5f) - 0.5f; if (src < 0.f) src = 0.f; }
@@ -146,6 +151,14 @@ __host__ __device__ static inline Tap linear_tap(int dst, float scale, int in_si
     int i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
     Tap t; t.i0 = i0; t.i1 = i1; t.w1 = src - (float)i0; t.w0 = 1.0f - t.w1;
     return t;
+}
+// one bilinear sample: the expression every up-sample in the library evaluates, spelled with explicit fused multiply-adds so that the
+// stand-alone kernel (vit_ops.hip) and the halo loader that folds the up-sample into a convolution (conv3.hip, two values at a time
+// as v_pk_fma_f32) round identically whatever the compiler would contract on its own
+__device__ static inline float bilerp1(const Tap& tx, const Tap& ty, float v00, float v01, float v10, float v11) {
+    const float top = fmaf(tx.w1, v01, tx.w0 * v00);
+    const float bot = fmaf(tx.w1, v11, tx.w0 * v10);
+    return fmaf(ty.w1, bot, ty.w0 * top);
 }
 static inline float linear_scale(int in_size, int out_size, bool align_corners) {
     if (align_corners) return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;

@@ -213,12 +213,20 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
 //   * padded pixel stride (10 chunks for 8): compile-time LDS offsets, conflict-free ds_read_b128 (PMC: 0 conflict cycles).
 // At this arithmetic intensity (N = 32) the launch is HBM-bound once the latency is hidden: 41.5 KB of halo per 256 pixels.
 // ================================================================================================
-template <int DUMMY>
+// UPS = 1: the align_corners bilinear up-sample in front of the convolution (HF DepthAnythingDepthEstimationHead: conv1 -> interpolate
+// -> conv2) happens in the halo loader.  Stand-alone it writes and the convolution re-reads the largest activation of the model
+// (294 x 518 x 64 bf16 = 19.5 MB per frame: 292 + 223 us at batch 32, both HBM-bound); here a block fetches the SOURCE pixels under
+// its next tile (at most 13 x 13 for scales <= 0.6: 21 KB instead of 41.5 KB of halo, and from a map a quarter the size that stays
+// in L2) into registers during the current tile, parks them in an LDS staging area afterwards and interpolates the 18 x 18 halo
+// from there with bilerp1 -- the same expression, the same rounding to bf16 as the stand-alone kernel (bit-identical results).
+template <int UPS>
 __global__ void __launch_bounds__(512)
 conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEpi e, int ntiles) {
     constexpr int CPP = 8, PST = 10, TH = 16, TW = 16, HWD = TW + 2, HPX = (TH + 2) * HWD, HALO = HPX * PST;
     constexpr int NCH = HPX * CPP, NLD = (NCH + 511) / 512;       // halo chunks, loads per thread (6)
-    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * HALO];
+    constexpr int SR = 13, SCH = SR * SR * CPP, NSL = (SCH + 511) / 512;   // UPS: source window (pixels per side), its chunks, loads per thread (3)
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * HALO + (UPS ? 2 * SCH : 0)];
+    f32x4* const stg = (f32x4*)(lds + 2 * HALO);            // UPS: the source window as floats (unpacked once, tapped ~8 times): [pixel][64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -253,28 +261,99 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
         const int r = t - b * (tiles_y * tiles_x);
         ty0 = (r / tiles_x) * TH; tx0 = (r % tiles_x) * TW;
     };
+    // UPS: first source row / column under the halo of the tile at (ty0, tx0); the window is SR x SR pixels from there
+    auto src_org = [&](int ty0, int tx0, int& rs0, int& cs0) {
+        rs0 = linear_tap(ty0 > 0 ? ty0 - 1 : 0, a.usy, a.Hs, true).i0;
+        cs0 = linear_tap(tx0 > 0 ? tx0 - 1 : 0, a.usx, a.Ws, true).i0;
+    };
     auto load_halo = [&](int t) {
         int b, ty0, tx0;
         tile_org(t, b, ty0, tx0);
-        const bf16_t* img = (const bf16_t*)a.ptr + (long)b * a.Hi * a.Wi * a.C;
+        if constexpr (UPS) {
+            int rs0, cs0;
+            src_org(ty0, tx0, rs0, cs0);
+            const bf16_t* img = (const bf16_t*)a.ptr + (long)b * a.Hs * a.Ws * a.C;
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 512;
-            const int p = idx >> 3, c = idx & 7;
-            const int hy = p / HWD, hx = p - hy * HWD;
-            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-            hr[k] = (u32x4){0u, 0u, 0u, 0u};
-            if (idx < NCH && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) hr[k] = *(const u32x4*)(img + ((long)iy * a.Wi + ix) * a.C + c * 8);
+            for (int k = 0; k < NSL; ++k) {
+                const int idx = tid + k * 512;
+                const int p = idx >> 3, c = idx & 7;
+                const int sr = p / SR, sc = p - sr * SR;
+                const int row = rs0 + sr < a.Hs ? rs0 + sr : a.Hs - 1, col = cs0 + sc < a.Ws ? cs0 + sc : a.Ws - 1;
+                hr[k] = (u32x4){0u, 0u, 0u, 0u};
+                if (idx < SCH) hr[k] = *(const u32x4*)(img + ((long)row * a.Ws + col) * a.C + c * 8);
+            }
+        } else {
+            const bf16_t* img = (const bf16_t*)a.ptr + (long)b * a.Hi * a.Wi * a.C;
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int idx = tid + k * 512;
+                const int p = idx >> 3, c = idx & 7;
+                const int hy = p / HWD, hx = p - hy * HWD;
+                const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+                hr[k] = (u32x4){0u, 0u, 0u, 0u};
+                if (idx < NCH && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) hr[k] = *(const u32x4*)(img + ((long)iy * a.Wi + ix) * a.C + c * 8);
+            }
         }
     };
-    auto store_halo = [&](int buf) {
+    // t: the tile whose data sits in hr (UPS needs its origin again)
+    auto store_halo = [&](int buf, int t) {
+        if constexpr (UPS) {
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 512;
-            if (idx < NCH) {
-                s16x8_ x = __builtin_bit_cast(s16x8_, hr[k]);
-                x = __builtin_elementwise_max(x, (s16x8_){floor_, floor_, floor_, floor_, floor_, floor_, floor_, floor_});
-                lds[buf * HALO + (idx >> 3) * PST + (idx & 7)] = __builtin_bit_cast(u32x4, x);
+            for (int k = 0; k < NSL; ++k) {
+                const int idx = tid + k * 512;
+                if (idx < SCH) {
+                    const u32x4 v = hr[k];
+                    stg[2 * idx] = (f32x4){__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+                    stg[2 * idx + 1] = (f32x4){__uint_as_float(v[2] << 16), __uint_as_float(v[2] & 0xffff0000u), __uint_as_float(v[3] << 16), __uint_as_float(v[3] & 0xffff0000u)};
+                }
+            }
+            __syncthreads();
+            int b, ty0, tx0, rs0, cs0;
+            tile_org(t, b, ty0, tx0);
+            src_org(ty0, tx0, rs0, cs0);
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int idx = tid + k * 512;
+                if (idx < NCH) {
+                    const int p = idx >> 3, c = idx & 7;
+                    const int hy = p / HWD, hx = p - hy * HWD;
+                    const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+                    u32x4 r = {0u, 0u, 0u, 0u};
+                    if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+                        const Tap ty = linear_tap(iy, a.usy, a.Hs, true), tx = linear_tap(ix, a.usx, a.Ws, true);
+                        const int r0 = (ty.i0 - rs0) * SR, r1 = (ty.i1 - rs0) * SR, c0 = tx.i0 - cs0, c1 = tx.i1 - cs0;
+                        const f32x4* q00 = stg + ((r0 + c0) * CPP + c) * 2; const f32x4* q01 = stg + ((r0 + c1) * CPP + c) * 2;
+                        const f32x4* q10 = stg + ((r1 + c0) * CPP + c) * 2; const f32x4* q11 = stg + ((r1 + c1) * CPP + c) * 2;
+                        typedef float f2_ __attribute__((ext_vector_type(2)));
+                        const f2_ w0x = {tx.w0, tx.w0}, w1x = {tx.w1, tx.w1}, w0y = {ty.w0, ty.w0}, w1y = {ty.w1, ty.w1};
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {          // bilerp1, two channels per instruction
+                            const f32x4 a00 = q00[h], a01 = q01[h], a10 = q10[h], a11 = q11[h];
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const f2_ v00 = {a00[2 * u], a00[2 * u + 1]}, v01 = {a01[2 * u], a01[2 * u + 1]};
+                                const f2_ v10 = {a10[2 * u], a10[2 * u + 1]}, v11 = {a11[2 * u], a11[2 * u + 1]};
+                                const f2_ top = __builtin_elementwise_fma(w1x, v01, w0x * v00);
+                                const f2_ bot = __builtin_elementwise_fma(w1x, v11, w0x * v10);
+                                const f2_ o = __builtin_elementwise_fma(w1y, bot, w0y * top);
+                                r[2 * h + u] = pk_bf16(o[0], o[1]);
+                            }
+                        }
+                    }
+                    s16x8_ x = __builtin_bit_cast(s16x8_, r);
+                    x = __builtin_elementwise_max(x, (s16x8_){floor_, floor_, floor_, floor_, floor_, floor_, floor_, floor_});
+                    lds[buf * HALO + p * PST + c] = __builtin_bit_cast(u32x4, x);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int idx = tid + k * 512;
+                if (idx < NCH) {
+                    s16x8_ x = __builtin_bit_cast(s16x8_, hr[k]);
+                    x = __builtin_elementwise_max(x, (s16x8_){floor_, floor_, floor_, floor_, floor_, floor_, floor_, floor_});
+                    lds[buf * HALO + (idx >> 3) * PST + (idx & 7)] = __builtin_bit_cast(u32x4, x);
+                }
             }
         }
     };
@@ -282,7 +361,7 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
     int t = blockIdx.x;
     if (t >= ntiles) return;
     load_halo(t);
-    store_halo(0);
+    store_halo(0, t);
     __syncthreads();
     // A fragment of this wave's tile row i (rows 2 wid, 2 wid + 1): pixel (row + ky, fr + kx), chunk 4 ks + fg = hb + constant
     const int hb0 = ((wid * 2) * HWD + fr) * PST + fg;
@@ -323,7 +402,7 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
             s += __shfl_xor(s, 32);
             if (fg == 0 && y < a.Ho && x < a.Wo) ((float*)e.out)[((long)b * a.Ho + y) * a.Wo + x] = head_activation(s + e.head_b3, e.head_max_depth);
         }
-        if (tn < ntiles) store_halo(buf ^ 1);
+        if (tn < ntiles) store_halo(buf ^ 1, tn);
         __syncthreads();                                       // tile t is read out, tile t + 1's halo is in place
         buf ^= 1;
     }
@@ -583,6 +662,17 @@ conv3_wide_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
 
 // Eligible: bf16, stride 1, same-size output, C = 64 | 128, K = 9 C, plain row mapping or the fused head, enough tiles to fill the
 // chip.  D2S_NO_HALO2=1 keeps the first-generation kernels (the parity tests run both).
+// Same conditions as the persistent-head branch of launch_conv3_halo2 below, plus the up-sample's: scales <= 0.6 (13 x 13 source window)
+bool conv3_head_upsample_ok(int precision, const GemmA& a, int M, int N, int K, const GemmEpi& e) {
+    static EnvInt off{"D2S_NO_HALO2", 0}, no_persist{"D2S_NO_HEADP", 0}, no_ups{"D2S_NO_HEADUPS", 0};
+    if (off.get() || no_persist.get() || no_ups.get() || precision != D2S_PREC_BF16) return false;
+    if (a.mode != A_CONV3 || a.stride != 1 || a.Hi != a.Ho || a.Wi != a.Wo || a.C != 64 || K != 9 * a.C || a.relu) return false;
+    if (e.map != MAP_HEAD || N > 32 || e.rows_per_img || e.ln_stats || e.stats_out || e.deq || e.ksplit > 1) return false;
+    const int nimg = M / (a.Ho * a.Wo);
+    if ((long)nimg * a.Ho * a.Wo != M || (long)nimg * cdiv(a.Ho, 16) * cdiv(a.Wo, 16) < 256) return false;
+    return a.Hs >= 2 && a.Ws >= 2 && a.usy > 0.f && a.usy <= 0.6f && a.usx > 0.f && a.usx <= 0.6f;
+}
+
 bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
     static EnvInt off{"D2S_NO_HALO2", 0};
     if (off.get()) return false;
@@ -596,9 +686,11 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
     if (!no_persist.get() && e.map == MAP_HEAD && a.C == 64 && N <= 32 && (long)nimg * cdiv(a.Ho, 16) * cdiv(a.Wo, 16) >= 256) {
         static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
         const int ntiles = nimg * cdiv(a.Ho, 16) * cdiv(a.Wo, 16);
-        hipLaunchKernelGGL((conv3_head_kernel<0>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
+        if (a.ups) hipLaunchKernelGGL((conv3_head_kernel<1>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
+        else hipLaunchKernelGGL((conv3_head_kernel<0>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         return true;
     }
+    if (a.ups) return false;                                      // (only the persistent head kernel folds the up-sample; the caller asked first)
     static EnvInt no_wide{"D2S_NO_WIDE", 0};
     if (!no_wide.get() && e.map == MAP_ROWS && a.C == 128 && N == 128 && (long)gemm_npad(N) * Kpad * 2 < (1L << 31) &&
         (e.out_type == OUT_T || e.out_type == OUT_BF16) && !e.scale && !e.res2 && !e.res1_mod && (e.act == ACT_NONE || e.act == ACT_RELU)) {

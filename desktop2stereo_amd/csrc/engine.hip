@@ -564,16 +564,21 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     }
     // ---- head (HF DepthAnythingDepthEstimationHead)
     RC(conv3(e, fused, B, Hc, Wc, F, 1, 0, e->head1, X, ACT_NONE, nullptr, nullptr, st));
-    PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, X, Y, B, Hc, Wc, e->h, e->w, F / 2, st));
     {
         const int Mh = B * e->h * e->w, Nh = d.head_hidden;
         const int bn = Nh <= 32 ? 32 : 64;
-        if (Nh <= 64 && (long)cdiv(Mh, 256) * cdiv(Nh, bn) >= 224) {
+        const bool fused_tail = Nh <= 64 && (long)cdiv(Mh, 256) * cdiv(Nh, bn) >= 224;
+        GemmA a = convA(Y, e->h, e->w, F / 2, e->h, e->w, 1, 0);
+        GemmEpi ep = rowsE(depth, OUT_F32, 1, e->head2.bias);
+        ep.map = MAP_HEAD; ep.scale = e->w3; ep.head_b3 = e->b3; ep.head_max_depth = d.max_depth;
+        // the interpolate between conv1 and conv2 folded into conv2's halo loader where the persistent head kernel runs (conv3.hip)
+        GemmA au = a;
+        au.ptr = X; au.ups = 1; au.Hs = Hc; au.Ws = Wc; au.usy = linear_scale(Hc, e->h, true); au.usx = linear_scale(Wc, e->w, true);
+        const bool ups = fused_tail && conv3_head_upsample_ok(e->wprec, au, Mh, Nh, e->head2.K, ep);
+        if (!ups) PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, X, Y, B, Hc, Wc, e->h, e->w, F / 2, st));
+        if (fused_tail) {
             // conv2 + ReLU + conv3 (1x1 -> 1 channel) + ReLU | sigmoid in one launch (MAP_HEAD, WN == 1 tiles)
-            GemmA a = convA(Y, e->h, e->w, F / 2, e->h, e->w, 1, 0);
-            GemmEpi ep = rowsE(depth, OUT_F32, 1, e->head2.bias);
-            ep.map = MAP_HEAD; ep.scale = e->w3; ep.head_b3 = e->b3; ep.head_max_depth = d.max_depth;
-            PROF(PC_CONV, 2.0 * Mh * Nh * e->head2.K, 0, launch_gemm(e->wprec, head_tile(bn), a, e->head2.w, Mh, Nh, e->head2.K, e->head2.Kpad, ep, st));
+            PROF(PC_CONV, 2.0 * Mh * Nh * e->head2.K, 0, launch_gemm(e->wprec, head_tile(bn), ups ? au : a, e->head2.w, Mh, Nh, e->head2.K, e->head2.Kpad, ep, st));
         } else {
             RC(conv3(e, Y, B, e->h, e->w, F / 2, 1, 0, e->head2, Z, ACT_RELU, nullptr, nullptr, st));
             PROF(PC_ELT, 0, 0, launch_head_final(prec, Z, e->w3, e->b3, d.max_depth, depth, (long)B * e->h * e->w, d.head_hidden, st));

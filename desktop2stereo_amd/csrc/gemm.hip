@@ -839,6 +839,7 @@ int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, i
         D2S_CHECK_LAUNCH();
         return D2S_OK;
     }
+    if (a.ups) { set_error("launch_gemm: this launch cannot fold the up-sample into its loader (conv3_head_upsample_ok says when)"); return D2S_E_UNSUPPORTED; }
     if (precision == D2S_PREC_BF16) return launch_t<bf16_t>(tile, a, W, M, N, K, Kpad, e, st);
     if (precision == D2S_PREC_FP8_OPERANDS) {
         if (a.mode != A_PLAIN || a.relu) { set_error("launch_gemm: e4m3 operands are for plain linears"); return D2S_E_UNSUPPORTED; }

@@ -106,40 +106,42 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const
     }
 }
 
-// thread per (output pixel, 4 channels)
+// align_corners=True bilinear up-sample, NHWC.  One thread = one output pixel x one 16-byte channel chunk (8 bf16 / 4 f32): 4 x 16-B tap
+// loads, one 16-B store.  Grid (x chunks of a row, output row, frame): the row's vertical tap is block-uniform and the column / chunk
+// split is 32-bit arithmetic (round 2 decoded a flat 64-bit index per thread -- three emulated 64-bit divisions, ~2.5 TB/s of the
+// 5+ this streaming pattern reaches).
+// addend (optional, output-shaped): out = upsample(in) + addend -- the next fusion stage's "fused + RCU1(m)" sum
 template <typename T>
 __global__ void __launch_bounds__(256)
 bilinear_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo, int C,
                      float sy, float sx, const T* __restrict__ addend) {
-    // one thread = one output pixel x one 16-byte channel chunk (8 bf16 / 4 f32): 4 x 16-B tap loads, one 16-B store.
-    // addend (optional, output-shaped): out = upsample(in) + addend -- the next fusion stage's "fused + RCU1(m)" sum
     constexpr int CE = 16 / sizeof(T);
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int cc = C / CE;
-    long total = (long)B * Ho * Wo * cc;
-    if (idx >= total) return;
-    int c = (int)(idx % cc) * CE;
-    long pix = idx / cc;
-    int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
-    Tap ty = linear_tap(oy, sy, Hi, true), tx = linear_tap(ox, sx, Wi, true);
+    const int cc = C / CE;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const int ox = (int)(t / (unsigned)cc);
+    if (ox >= Wo) return;
+    const int c = (int)(t - (unsigned)ox * (unsigned)cc) * CE;
+    const int oy = blockIdx.y, b = blockIdx.z;
+    const Tap ty = linear_tap(oy, sy, Hi, true), tx = linear_tap(ox, sx, Wi, true);
     const T* base = in + (long)b * Hi * Wi * C + c;
-    u32x4 v00 = *(const u32x4*)(base + ((long)ty.i0 * Wi + tx.i0) * C);
-    u32x4 v01 = *(const u32x4*)(base + ((long)ty.i0 * Wi + tx.i1) * C);
-    u32x4 v10 = *(const u32x4*)(base + ((long)ty.i1 * Wi + tx.i0) * C);
-    u32x4 v11 = *(const u32x4*)(base + ((long)ty.i1 * Wi + tx.i1) * C);
+    const T* r0 = base + (long)ty.i0 * Wi * C;
+    const T* r1 = base + (long)ty.i1 * Wi * C;
+    u32x4 v00 = *(const u32x4*)(r0 + tx.i0 * C);
+    u32x4 v01 = *(const u32x4*)(r0 + tx.i1 * C);
+    u32x4 v10 = *(const u32x4*)(r1 + tx.i0 * C);
+    u32x4 v11 = *(const u32x4*)(r1 + tx.i1 * C);
     const T *p00 = (const T*)&v00, *p01 = (const T*)&v01, *p10 = (const T*)&v10, *p11 = (const T*)&v11;
+    const long po = (((long)b * Ho + oy) * Wo + ox) * C + c;
     u32x4 r, av = {0u, 0u, 0u, 0u};
-    if (addend) av = *(const u32x4*)(addend + pix * C + c);
+    if (addend) av = *(const u32x4*)(addend + po);
     const T* pa = (const T*)&av;
     T* o = (T*)&r;
 #pragma unroll
     for (int k = 0; k < CE; ++k) {
-        float top = tx.w0 * tof(p00[k]) + tx.w1 * tof(p01[k]);
-        float bot = tx.w0 * tof(p10[k]) + tx.w1 * tof(p11[k]);
-        o[k] = cvt<T>(ty.w0 * top + ty.w1 * bot + tof(pa[k]));
+        o[k] = cvt<T>(bilerp1(tx, ty, tof(p00[k]), tof(p01[k]), tof(p10[k]), tof(p11[k])) + tof(pa[k]));
     }
-    *(u32x4*)(out + pix * C + c) = r;
+    *(u32x4*)(out + po) = r;
 }
 
 template <typename T>
@@ -219,8 +221,8 @@ int launch_bilinear_nhwc(int prec, const void* in, void* out, int B, int Hi, int
     float sy = linear_scale(Hi, Ho, true), sx = linear_scale(Wi, Wo, true);
     const int ce = prec == D2S_PREC_BF16 ? 8 : 4;
     if (C % ce) { set_error("bilinear_nhwc: channels must be a multiple of the 16-byte chunk"); return D2S_E_INVALID; }
-    long total = (long)B * Ho * Wo * (C / ce);
-    dim3 grid(cdiv(total, 256)), block(256);
+    if (Ho > 65535 || B > 65535) { set_error("bilinear_nhwc: more than 65535 output rows / frames"); return D2S_E_UNSUPPORTED; }
+    dim3 grid(cdiv((long)Wo * (C / ce), 256), Ho, B), block(256);
     DISPATCH_T(prec, hipLaunchKernelGGL(bilinear_nhwc_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)in, (bf16_t*)out, B, Hi, Wi, Ho, Wo, C, sy, sx, (const bf16_t*)addend),
                      hipLaunchKernelGGL(bilinear_nhwc_kernel<float>, grid, block, 0, st, (const float*)in, (float*)out, B, Hi, Wi, Ho, Wo, C, sy, sx, (const float*)addend));
     D2S_CHECK_LAUNCH();
