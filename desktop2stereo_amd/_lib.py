@@ -57,6 +57,7 @@ SYMBOLS = {
     "d2s_last_error": (C.c_char_p, []),
     "d2s_version": (C.c_int, []),
     "d2s_debug_reload_env": (C.c_int, []),
+    "d2s_debug_lds_poison": (C.c_int, []),
     "d2s_engine_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_P)]),
     "d2s_engine_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),
     "d2s_engine_finalize": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),

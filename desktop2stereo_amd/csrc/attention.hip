@@ -161,6 +161,7 @@ attention_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, OT* __rest
     constexpr int BQ = NW * QF * 16;
     constexpr int PD = NS - 1;                         // NS LDS ring stages, prefetch distance PD
     __shared__ __attribute__((aligned(16))) u32x4 lds_all[KS * NS * 2 * TILE_CHUNKS];   // [group][stage][K | V^T]
+    D2S_POISON_LDS(lds_all, KS * NS * 2 * TILE_CHUNKS)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid_all = tid >> 6, grp = KS == 1 ? 0 : wid_all / NW, wid = KS == 1 ? wid_all : wid_all % NW;
@@ -438,6 +439,7 @@ attention32_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt
     constexpr int BQ = NW * 32;
     constexpr int IPW = 8 / NW;                        // LDS-DMA instructions per wave per operand tile (8 rows each)
     __shared__ __attribute__((aligned(16))) u32x4 lds[NS * 2 * TILE];
+    D2S_POISON_LDS(lds, NS * 2 * TILE)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);

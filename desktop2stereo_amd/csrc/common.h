@@ -11,6 +11,22 @@ namespace d2s {
 void set_error(const std::string& msg);
 int hip_fail(hipError_t err, const char* what, const char* file, int line);
 
+// Debug build (D2S_HIPCC_DEFS=-DD2S_LDS_POISON, `python -m desktop2stereo_amd.build --force`): every kernel that streams operands
+// through an LDS ring fills its whole LDS allocation with NaN patterns (bf16 and fp32 alike) before it starts, so a fragment read
+// that runs ahead of the LDS-DMA / staging write it depends on -- a slip in a hand-counted vmcnt or a missing barrier -- poisons
+// the output instead of quietly reading the previous block's data.  The GPU parity suite is then the detector
+// (tests/test_gpu_soak.py::test_lds_poison_build describes the procedure).  Persistent kernels are covered for their first tile.
+#ifdef D2S_LDS_POISON
+#define D2S_POISON_LDS(PTR, N16)                                                                                  \
+    {                                                                                                             \
+        for (int i_ = threadIdx.x; i_ < (int)(N16); i_ += blockDim.x)                                             \
+            ((uint4*)(PTR))[i_] = make_uint4(0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u);                 \
+        __syncthreads();                                                                                          \
+    }
+#else
+#define D2S_POISON_LDS(PTR, N16) {}
+#endif
+
 // Integer switch from the environment (kernel selection for A/B runs and tests): cached, re-read after
 // d2s_debug_reload_env() so that one process can run both sides.  Usage:  static EnvInt f{"D2S_NO_X", 0};  if (f.get()) ...
 int env_generation();

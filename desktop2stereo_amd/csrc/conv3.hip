@@ -52,6 +52,7 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
     constexpr int PD = NS - 1;
     static_assert(BI >= 1 && BN % (8 * NW) == 0 && TH % WM == 0 && BN % (16 * WN) == 0, "bad tile split");
     __shared__ __attribute__((aligned(16))) u32x4 lds[NS * WST + HPX * PST];
+    D2S_POISON_LDS(lds, NS * WST + HPX * PST)
     u32x4* const halo = lds + NS * WST;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -226,6 +227,7 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
     constexpr int NCH = HPX * CPP, NLD = (NCH + 511) / 512;       // halo chunks, loads per thread (6)
     constexpr int SR = 13, SCH = SR * SR * CPP, NSL = (SCH + 511) / 512;   // UPS: source window (pixels per side), its chunks, loads per thread (3)
     __shared__ __attribute__((aligned(16))) u32x4 lds[2 * HALO + (UPS ? 2 * SCH : 0)];
+    D2S_POISON_LDS(lds, 2 * HALO + (UPS ? 2 * SCH : 0))
     f32x4* const stg = (f32x4*)(lds + 2 * HALO);            // UPS: the source window as floats (unpacked once, tapped ~8 times): [pixel][64]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -454,6 +456,7 @@ conv3_wide_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
     constexpr int HKT = 28;                                   // K tile whose issue slot also requests the next halo (see below)
     static_assert(TH * TW == 256 && TW % 16 == 0, "256-pixel tiles of 16-pixel fragments");
     __shared__ __attribute__((aligned(16))) u32x4 lds[NS * WST + HALO];
+    D2S_POISON_LDS(lds, NS * WST + HALO)
     u32x4* const halo = lds + NS * WST;
 
     const int tid = threadIdx.x, lane = tid & 63;

@@ -27,6 +27,13 @@ int EnvInt::get() {
 
 }  // namespace d2s
 
+extern "C" int d2s_debug_lds_poison(void) {
+#ifdef D2S_LDS_POISON
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" int d2s_debug_reload_env(void) { return d2s::g_env_gen.fetch_add(1) + 1; }
 extern "C" const char* d2s_last_error(void) { return d2s::g_err.c_str(); }
 extern "C" int d2s_version(void) { return 100; }

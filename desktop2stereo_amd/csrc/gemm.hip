@@ -98,6 +98,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     constexpr int PD = NS - 1;
     constexpr int STAGE = (BM + BN) * CPR;          // chunks per stage
     __shared__ __attribute__((aligned(16))) u32x4 lds[NS * STAGE];
+    D2S_POISON_LDS(lds, NS * STAGE)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -505,6 +506,7 @@ conv3_halo_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpa
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     constexpr int STAGE = BN * CPR;
     __shared__ __attribute__((aligned(16))) u32x4 lds[NS * STAGE + HPX * HCPP];
+    D2S_POISON_LDS(lds, NS * STAGE + HPX * HCPP)
     u32x4* const halo = lds + NS * STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63;

@@ -343,6 +343,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     constexpr bool DEQ = ES == 1;                                   // e4m3 operands: the accumulator is de-quantised per column
     // 128 KiB of stages + 8 wave-private 4 KiB epilogue patches = the CU's 160 KiB: the ONLY __shared__ object (see gemm.hip)
     __shared__ __attribute__((aligned(16))) u32x4 lds[2 * PP_STAGE + 8 * 256];
+    D2S_POISON_LDS(lds, 2 * PP_STAGE + 8 * 256)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);

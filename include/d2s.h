@@ -140,6 +140,8 @@ int d2s_version(void);
 /* Kernel-selection switches (D2S_NO_HALO2, D2S_NO_WIDE, ... -- tuning aids) are read from the environment once and
  * cached; this makes the library read them again (tests run both sides of a switch in one process).  Returns the new generation. */
 int d2s_debug_reload_env(void);
+/* 1 if the library was built with -DD2S_LDS_POISON (LDS rings pre-filled with NaN patterns: a debug build for the parity suite). */
+int d2s_debug_lds_poison(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Engine life cycle -- replaces DepthModelWrapper construction + lazy engine build

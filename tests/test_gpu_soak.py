@@ -100,3 +100,18 @@ def test_soak_batched_engine_bit_identical_under_load(dev):
         eng.close()
         del frames, first
     torch.cuda.synchronize()
+
+
+def test_lds_poison_build():
+    """Race screen by construction: `D2S_HIPCC_DEFS=-DD2S_LDS_POISON python -m desktop2stereo_amd.build --force` builds a library whose
+    ring kernels (gemm_glds, gemm_pp, conv3_*, attention*) fill their LDS with NaN patterns before they start; a fragment read that
+    runs ahead of the LDS-DMA / staging write it depends on then poisons the output and the parity tests fail.  Procedure:
+        D2S_HIPCC_DEFS=-DD2S_LDS_POISON python -m desktop2stereo_amd.build --force
+        D2S_EXPECT_POISON=1 python -m pytest tests -m gpu -q
+        python -m desktop2stereo_amd.build --force
+    (round 3: 71 passed, 1 skipped with the poisoned build).  This test only makes such a run self-describing: with D2S_EXPECT_POISON=1 the
+    loaded library must be the poisoned one; in a normal run it must not be."""
+    import os
+    from desktop2stereo_amd import _lib
+    poisoned = int(_lib.load().d2s_debug_lds_poison())
+    assert poisoned == (1 if os.environ.get("D2S_EXPECT_POISON") == "1" else 0)
