@@ -85,7 +85,8 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
 
     // ---- the input halo, once: 10 x 18 pixels x C channels, zero outside the image, ReLU-on-load (pre-activation units)
     {
-        const bf16_t* img = (const bf16_t*)a.ptr + (long)b * a.Hi * a.Wi * a.C;
+        // (a.ups: the align_corners up-sample in front of this convolution happens here, gemm_epi.h ups_chunk)
+        const bf16_t* img = (const bf16_t*)a.ptr + (long)b * (a.ups ? (long)a.Hs * a.Ws : (long)a.Hi * a.Wi) * a.C;
         const short floor_ = a.relu ? (short)0 : (short)0x8000;      // max as int16: 0 = ReLU, most negative = identity
         typedef short s16x8_ __attribute__((ext_vector_type(8)));
         for (int idx = tid; idx < HPX * CPP; idx += 64 * NW) {
@@ -93,7 +94,10 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
             const int hy = p / HWD, hx = p - hy * HWD;
             const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) v = *(const u32x4*)(img + ((long)iy * a.Wi + ix) * a.C + c * 8);
+            if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+                if (a.ups) v = ups_chunk<bf16_t>(img, a, iy, ix, c * 8);
+                else v = *(const u32x4*)(img + ((long)iy * a.Wi + ix) * a.C + c * 8);
+            }
             s16x8_ x = __builtin_bit_cast(s16x8_, v);
             x = __builtin_elementwise_max(x, (s16x8_){floor_, floor_, floor_, floor_, floor_, floor_, floor_, floor_});
             halo[p * PST + c3_chunk_slot<PST>(c)] = __builtin_bit_cast(u32x4, x);
@@ -665,18 +669,7 @@ conv3_wide_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
 
 // Eligible: bf16, stride 1, same-size output, C = 64 | 128, K = 9 C, plain row mapping or the fused head, enough tiles to fill the
 // chip.  D2S_NO_HALO2=1 keeps the first-generation kernels (the parity tests run both).
-// Same conditions as the persistent-head branch of launch_conv3_halo2 below, plus the up-sample's: scales <= 0.6 (13 x 13 source window)
-bool conv3_head_upsample_ok(int precision, const GemmA& a, int M, int N, int K, const GemmEpi& e) {
-    static EnvInt off{"D2S_NO_HALO2", 0}, no_persist{"D2S_NO_HEADP", 0}, no_ups{"D2S_NO_HEADUPS", 0};
-    if (off.get() || no_persist.get() || no_ups.get() || precision != D2S_PREC_BF16) return false;
-    if (a.mode != A_CONV3 || a.stride != 1 || a.Hi != a.Ho || a.Wi != a.Wo || a.C != 64 || K != 9 * a.C || a.relu) return false;
-    if (e.map != MAP_HEAD || N > 32 || e.rows_per_img || e.ln_stats || e.stats_out || e.deq || e.ksplit > 1) return false;
-    const int nimg = M / (a.Ho * a.Wo);
-    if ((long)nimg * a.Ho * a.Wo != M || (long)nimg * cdiv(a.Ho, 16) * cdiv(a.Wo, 16) < 256) return false;
-    return a.Hs >= 2 && a.Ws >= 2 && a.usy > 0.f && a.usy <= 0.6f && a.usx > 0.f && a.usx <= 0.6f;
-}
-
-bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
+bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st, bool dry) {
     static EnvInt off{"D2S_NO_HALO2", 0};
     if (off.get()) return false;
     if (a.mode != A_CONV3 || a.stride != 1 || a.Hi != a.Ho || a.Wi != a.Wo || (a.C != 64 && a.C != 128) || K != 9 * a.C) return false;
@@ -689,13 +682,16 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
     if (!no_persist.get() && e.map == MAP_HEAD && a.C == 64 && N <= 32 && (long)nimg * cdiv(a.Ho, 16) * cdiv(a.Wo, 16) >= 256) {
         static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
         const int ntiles = nimg * cdiv(a.Ho, 16) * cdiv(a.Wo, 16);
+        static EnvInt no_headups{"D2S_NO_HEADUPS", 0};
+        // (the staged 13 x 13 source window holds scales <= 0.6; ReLU-on-load is not part of the interpolating loader)
+        if (a.ups && (no_headups.get() || a.usy > 0.6f || a.usx > 0.6f || a.relu)) return false;
+        if (dry) return true;
         if (a.ups) hipLaunchKernelGGL((conv3_head_kernel<1>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         else hipLaunchKernelGGL((conv3_head_kernel<0>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         return true;
     }
-    if (a.ups) return false;                                      // (only the persistent head kernel folds the up-sample; the caller asked first)
     static EnvInt no_wide{"D2S_NO_WIDE", 0};
-    if (!no_wide.get() && e.map == MAP_ROWS && a.C == 128 && N == 128 && (long)gemm_npad(N) * Kpad * 2 < (1L << 31) &&
+    if (!no_wide.get() && !a.ups && e.map == MAP_ROWS && a.C == 128 && N == 128 && (long)gemm_npad(N) * Kpad * 2 < (1L << 31) &&
         (e.out_type == OUT_T || e.out_type == OUT_BF16) && !e.scale && !e.res2 && !e.res1_mod && (e.act == ACT_NONE || e.act == ACT_RELU)) {
         static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
         static EnvInt wide_min{"D2S_WIDE_MIN", 384};                                                       // tiles (1.5 rounds of the CUs)
@@ -703,6 +699,7 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
         const long ntl = nimg * std::min(pad_a, pad_b);
         const int grid_w = ncu & ~7;
         if (ntl >= wide_min.get() && ntl < (1L << 30) && grid_w >= 8) {
+            if (dry) return true;
             GemmEpi e1 = e; e1.ksplit = 1;
             if (pad_a <= pad_b) hipLaunchKernelGGL((conv3_wide_kernel<8, 32>), dim3(grid_w), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e1, (int)ntl);
             else hipLaunchKernelGGL((conv3_wide_kernel<16, 16>), dim3(grid_w), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e1, (int)ntl);
@@ -713,6 +710,7 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
     const int bn = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
     if (tiles_m * cdiv(N, bn) < 512) return false;                // small maps: latency-bound, the small-tile kernels do better
     if ((long)gemm_npad(N) * Kpad * 2 >= (1L << 31)) return false;
+    if (dry) return true;
     static const int pst16 = getenv("D2S_HALO2_PST") ? atoi(getenv("D2S_HALO2_PST")) : 17;      // tuning aid: 17 (2 blocks / CU) | 18 (conflict-free)
     GemmEpi e1 = e; e1.ksplit = 1;
     unsigned grid = 0;

@@ -537,6 +537,8 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     // formed where fused(idx-1) is produced (up-sample / temporal-module epilogue), from the r1[] maps of the neck branches.
     void *X = e->scr[0], *Y = e->scr[1], *Z = e->scr[2];
     void* fused = nullptr;
+    bool fold1 = false;
+    GemmA c1a = {};
     int Hc = 0, Wc = 0;
     for (int idx = 0; idx < 4; ++idx) {
         int mi = 3 - idx;
@@ -558,29 +560,45 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
             RC(run_temporal(e, 2 + idx, pout, alt, st, next_r1));
             pout = alt;
         } else {
-            PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, X, pout, B, Hc, Wc, Ho, Wo, F, st, next_r1));
+            if (idx == 3) {
+                // the last stage's up-sample feeds the head's conv1 only: folded into its halo loader where an LDS-resident-input
+                // kernel runs it (gemm.h conv3_upsample_ok); conv1 then reads X (the projected map) and writes Y
+                c1a = convA(X, Ho, Wo, F, Ho, Wo, 1, 0);
+                c1a.ups = 1; c1a.Hs = Hc; c1a.Ws = Wc; c1a.usy = linear_scale(Hc, Ho, true); c1a.usx = linear_scale(Wc, Wo, true);
+                GemmEpi ep1 = rowsE(Y, OUT_T, e->head1.N, e->head1.bias);
+                fold1 = conv3_upsample_ok(e->wprec, 0, c1a, B * Ho * Wo, e->head1.N, e->head1.K, e->head1.Kpad, ep1);
+            }
+            if (!fold1) PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, X, pout, B, Hc, Wc, Ho, Wo, F, st, next_r1));
         }
         fused = pout; Hc = Ho; Wc = Wo;
     }
     // ---- head (HF DepthAnythingDepthEstimationHead)
-    RC(conv3(e, fused, B, Hc, Wc, F, 1, 0, e->head1, X, ACT_NONE, nullptr, nullptr, st));
+    void* c1out = X;                                     // conv1 output; the (optional) up-sample between conv1 and conv2 goes c1out -> up2
+    void* up2 = Y;
+    if (fold1) {
+        c1out = Y; up2 = X;
+        GemmEpi ep1 = rowsE(c1out, OUT_T, e->head1.N, e->head1.bias);
+        PROF(PC_CONV, 2.0 * B * Hc * Wc * e->head1.N * e->head1.K, 0, launch_gemm(e->wprec, 0, c1a, e->head1.w, B * Hc * Wc, e->head1.N, e->head1.K, e->head1.Kpad, ep1, st));
+    } else {
+        RC(conv3(e, fused, B, Hc, Wc, F, 1, 0, e->head1, c1out, ACT_NONE, nullptr, nullptr, st));
+    }
     {
         const int Mh = B * e->h * e->w, Nh = d.head_hidden;
         const int bn = Nh <= 32 ? 32 : 64;
         const bool fused_tail = Nh <= 64 && (long)cdiv(Mh, 256) * cdiv(Nh, bn) >= 224;
-        GemmA a = convA(Y, e->h, e->w, F / 2, e->h, e->w, 1, 0);
+        GemmA a = convA(up2, e->h, e->w, F / 2, e->h, e->w, 1, 0);
         GemmEpi ep = rowsE(depth, OUT_F32, 1, e->head2.bias);
         ep.map = MAP_HEAD; ep.scale = e->w3; ep.head_b3 = e->b3; ep.head_max_depth = d.max_depth;
         // the interpolate between conv1 and conv2 folded into conv2's halo loader where the persistent head kernel runs (conv3.hip)
         GemmA au = a;
-        au.ptr = X; au.ups = 1; au.Hs = Hc; au.Ws = Wc; au.usy = linear_scale(Hc, e->h, true); au.usx = linear_scale(Wc, e->w, true);
-        const bool ups = fused_tail && conv3_head_upsample_ok(e->wprec, au, Mh, Nh, e->head2.K, ep);
-        if (!ups) PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, X, Y, B, Hc, Wc, e->h, e->w, F / 2, st));
+        au.ptr = c1out; au.ups = 1; au.Hs = Hc; au.Ws = Wc; au.usy = linear_scale(Hc, e->h, true); au.usx = linear_scale(Wc, e->w, true);
+        const bool ups = fused_tail && conv3_upsample_ok(e->wprec, head_tile(bn), au, Mh, Nh, e->head2.K, e->head2.Kpad, ep);
+        if (!ups) PROF(PC_ELT, 0, 0, launch_bilinear_nhwc(prec, c1out, up2, B, Hc, Wc, e->h, e->w, F / 2, st));
         if (fused_tail) {
             // conv2 + ReLU + conv3 (1x1 -> 1 channel) + ReLU | sigmoid in one launch (MAP_HEAD, WN == 1 tiles)
             PROF(PC_CONV, 2.0 * Mh * Nh * e->head2.K, 0, launch_gemm(e->wprec, head_tile(bn), ups ? au : a, e->head2.w, Mh, Nh, e->head2.K, e->head2.Kpad, ep, st));
         } else {
-            RC(conv3(e, Y, B, e->h, e->w, F / 2, 1, 0, e->head2, Z, ACT_RELU, nullptr, nullptr, st));
+            RC(conv3(e, up2, B, e->h, e->w, F / 2, 1, 0, e->head2, Z, ACT_RELU, nullptr, nullptr, st));
             PROF(PC_ELT, 0, 0, launch_head_final(prec, Z, e->w3, e->b3, d.max_depth, depth, (long)B * e->h * e->w, d.head_hidden, st));
         }
     }

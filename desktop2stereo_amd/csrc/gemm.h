@@ -25,8 +25,8 @@ struct GemmA {
     int relu;             // max(x,0) on load (pre-activation)
     int buf;              // set by the launcher (plain linears with whole K tiles, < 2 GiB operands): LDS-DMA through buffer descriptors
     int bx3;              // D2S_PREC_BF16X3 launches: A is ALREADY in the split unit format (plain rows): LDS-DMA tiles; 0: fp32, split when staged
-    // A_CONV3 with the align_corners bilinear up-sample in front of it folded into the halo loader (conv3_head_kernel only; the
-    // caller asks conv3_head_upsample_ok first): ptr = the SOURCE map [B, Hs, Ws, C], (Hi, Wi) = the up-sampled size the conv sees
+    // A_CONV3 with the align_corners bilinear up-sample in front of it folded into the halo loader (the LDS-resident-input kernels; the
+    // caller asks conv3_upsample_ok first): ptr = the SOURCE map [B, Hs, Ws, C], (Hi, Wi) = the up-sampled size the conv sees
     int ups, Hs, Ws;
     float usy, usx;       // linear_scale(Hs, Hi, true), linear_scale(Ws, Wi, true)
 };
@@ -74,10 +74,10 @@ int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, i
                 const GemmEpi& e, hipStream_t st);
 
 // stride-1 3x3 convolutions with the input tile resident in LDS, second generation (conv3.hip): false = not eligible, nothing launched
-bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st);
+bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st, bool dry = false);   // dry: eligibility only
 
-// would launch_conv3_halo2 run the persistent head kernel with the up-sample folded in for this launch? (engine: skip the bilinear launch)
-bool conv3_head_upsample_ok(int precision, const GemmA& a, int M, int N, int K, const GemmEpi& e);
+// would launch_gemm fold the up-sample a.ups describes into this convolution's halo loader? (engine: skip the bilinear launch)
+bool conv3_upsample_ok(int precision, int tile, const GemmA& a, int M, int N, int K, int Kpad, const GemmEpi& e);
 
 // 256 x 256 ping-pong kernel (gemm_pp.hip): batched plain linears
 bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, const GemmEpi& e);

@@ -522,13 +522,17 @@ conv3_halo_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpa
 
     // ---- the input halo, once
     {
-        const T* img = (const T*)a.ptr + (long)b * a.Hi * a.Wi * a.C;
+        // (a.ups: the align_corners up-sample in front of this convolution happens here, gemm_epi.h ups_chunk)
+        const T* img = (const T*)a.ptr + (long)b * (a.ups ? (long)a.Hs * a.Ws : (long)a.Hi * a.Wi) * a.C;
         for (int idx = tid; idx < HPX * cpp; idx += 64 * NW) {
             const int p = idx / cpp, c = idx - p * cpp;
             const int hy = p / HWD, hx = p - hy * HWD;
             const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) v = *(const u32x4*)(img + ((long)iy * a.Wi + ix) * a.C + c * CE);
+            if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+                if (a.ups) v = ups_chunk<T>(img, a, iy, ix, c * CE);
+                else v = *(const u32x4*)(img + ((long)iy * a.Wi + ix) * a.C + c * CE);
+            }
             if (a.relu) v = relu_frag(v, 0, T());
             halo[p * cpp + (c ^ (p & smask))] = v;
         }
@@ -653,7 +657,7 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
 // stride-1 3x3 convs on the large maps go to conv3_halo_kernel (input tile resident in LDS); D2S_NO_HALO=1 keeps the
 // implicit-GEMM loader (the parity tests run both)
 template <typename T>
-static bool launch_conv_halo(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
+static bool launch_conv_halo(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st, bool dry = false) {
     static EnvInt off{"D2S_NO_HALO", 0};
     if (off.get()) return false;
     if constexpr (std::is_same<T, fp8_t>::value) return false;
@@ -664,6 +668,7 @@ static bool launch_conv_halo(const GemmA& a, const void* W, int M, int N, int K,
     const int nimg = M / (a.Ho * a.Wo);
     const long tiles_m = (long)nimg * cdiv(a.Ho, 8) * cdiv(a.Wo, 16);
     if (tiles_m * cdiv(N, 128) < 200 || (long)nimg * a.Ho * a.Wo != M) return false;      // small maps: too few tiles, latency-bound anyway
+    if (dry) return true;
     GemmEpi e1 = e; e1.ksplit = 1;
     unsigned grid = 0;
 #define D2S_HALO(BN_, WM_, WN_)                                                                                       \
@@ -823,6 +828,15 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     return D2S_OK;
 }
 
+// Would launch_gemm fold the up-sample described by a.ups / Hs / Ws / usy / usx into this convolution's loader?  (The engine asks
+// before it skips the stand-alone up-sample launch.)  Same order of kernels as launch_gemm below.
+bool conv3_upsample_ok(int precision, int tile, const GemmA& a, int M, int N, int K, int Kpad, const GemmEpi& e) {
+    static EnvInt no_ups{"D2S_NO_UPSFOLD", 0};
+    if (no_ups.get() || precision != D2S_PREC_BF16 || a.mode != A_CONV3 || !a.ups || a.Hs < 2 || a.Ws < 2 || a.usy <= 0.f || a.usx <= 0.f) return false;
+    if ((tile == 0 || e.map == MAP_HEAD) && launch_conv3_halo2(a, nullptr, M, N, K, Kpad, e, nullptr, true)) return true;
+    return tile == 0 && launch_conv_halo<bf16_t>(a, nullptr, M, N, K, Kpad, e, nullptr, true);
+}
+
 int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad,
                 const GemmEpi& e, hipStream_t st) {
     const int ce = 16 / (int)elem_size(precision);
@@ -841,7 +855,11 @@ int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, i
         D2S_CHECK_LAUNCH();
         return D2S_OK;
     }
-    if (a.ups) { set_error("launch_gemm: this launch cannot fold the up-sample into its loader (conv3_head_upsample_ok says when)"); return D2S_E_UNSUPPORTED; }
+    if (a.ups) {        // only the LDS-resident-input kernels fold the up-sample (conv3_upsample_ok says when)
+        if (precision == D2S_PREC_BF16 && tile == 0 && launch_conv_halo<bf16_t>(a, W, M, N, K, Kpad, e, st)) { D2S_CHECK_LAUNCH(); return D2S_OK; }
+        set_error("launch_gemm: this launch cannot fold the up-sample into its loader (conv3_upsample_ok says when)");
+        return D2S_E_UNSUPPORTED;
+    }
     if (precision == D2S_PREC_BF16) return launch_t<bf16_t>(tile, a, W, M, N, K, Kpad, e, st);
     if (precision == D2S_PREC_FP8_OPERANDS) {
         if (a.mode != A_PLAIN || a.relu) { set_error("launch_gemm: e4m3 operands are for plain linears"); return D2S_E_UNSUPPORTED; }

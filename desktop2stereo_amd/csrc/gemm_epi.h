@@ -91,6 +91,41 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
     f32x2_t v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+// One 16-byte chunk of an align_corners bilinear sample from its four tap chunks: bilerp1 (common.h) on every element, two at a
+// time as v_pk_fma_f32; 8 bf16 (rounded like the stand-alone up-sample kernel's output) or 4 floats.
+__device__ __forceinline__ u32x4 lerp_chunk(const u32x4& v00, const u32x4& v01, const u32x4& v10, const u32x4& v11, const Tap& tx, const Tap& ty, bf16_t) {
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    const f2_ w0x = {tx.w0, tx.w0}, w1x = {tx.w1, tx.w1}, w0y = {ty.w0, ty.w0}, w1y = {ty.w1, ty.w1};
+    u32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f2_ a00 = {__uint_as_float(v00[q] << 16), __uint_as_float(v00[q] & 0xffff0000u)}, a01 = {__uint_as_float(v01[q] << 16), __uint_as_float(v01[q] & 0xffff0000u)};
+        const f2_ a10 = {__uint_as_float(v10[q] << 16), __uint_as_float(v10[q] & 0xffff0000u)}, a11 = {__uint_as_float(v11[q] << 16), __uint_as_float(v11[q] & 0xffff0000u)};
+        const f2_ top = __builtin_elementwise_fma(w1x, a01, w0x * a00);
+        const f2_ bot = __builtin_elementwise_fma(w1x, a11, w0x * a10);
+        const f2_ o = __builtin_elementwise_fma(w1y, bot, w0y * top);
+        r[q] = pk_bf16(o[0], o[1]);
+    }
+    return r;
+}
+__device__ __forceinline__ u32x4 lerp_chunk(const u32x4& v00, const u32x4& v01, const u32x4& v10, const u32x4& v11, const Tap& tx, const Tap& ty, float) {
+    u32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        r[q] = __float_as_uint(bilerp1(tx, ty, __uint_as_float(v00[q]), __uint_as_float(v01[q]), __uint_as_float(v10[q]), __uint_as_float(v11[q])));
+    return r;
+}
+// the chunk (channels c .. of pixel (iy, ix) of the UP-SAMPLED map) a convolution's halo loader fetches when GemmA.ups is set
+template <typename T>
+__device__ __forceinline__ u32x4 ups_chunk(const T* src_img /* [Hs, Ws, C] of this frame */, const GemmA& a, int iy, int ix, int c_elem) {
+    const Tap ty = linear_tap(iy, a.usy, a.Hs, true), tx = linear_tap(ix, a.usx, a.Ws, true);
+    const T* r0 = src_img + (long)ty.i0 * a.Ws * a.C + c_elem;
+    const T* r1 = src_img + (long)ty.i1 * a.Ws * a.C + c_elem;
+    const u32x4 v00 = *(const u32x4*)(r0 + tx.i0 * a.C), v01 = *(const u32x4*)(r0 + tx.i1 * a.C);
+    const u32x4 v10 = *(const u32x4*)(r1 + tx.i0 * a.C), v11 = *(const u32x4*)(r1 + tx.i1 * a.C);
+    return lerp_chunk(v00, v01, v10, v11, tx, ty, T());
+}
+
 __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
     uint2 t;
     t.x = pk_bf16(v[0], v[1]);

@@ -485,7 +485,7 @@ def test_conv_kernel_generations_agree(dev, monkeypatch):
     """The 3x3 convolutions of the DPT neck / head have three generations of kernels behind one dispatcher (conv3.hip): the
     implicit-GEMM loader, the one-shot halo blocks (conv3_halo / conv3_halo2 / conv3_head) and, from ~7 frames per launch, the
     persistent conv3_wide blocks; the head's conv2 also takes the bilinear up-sample in front of it into its halo loader
-    (D2S_NO_HEADUPS=1: the stand-alone up-sample kernel).  Same fragments, same K order, fp32 accumulation: the engine output must not depend on which
+    (D2S_NO_HEADUPS=1: the stand-alone up-sample kernel), and conv1 the one in front of it (D2S_NO_UPSFOLD=1: neither).  Same fragments, same K order, fp32 accumulation: the engine output must not depend on which
     one ran (bit-identical between the halo generations; the implicit-GEMM loader sums in another K order -> bf16 rounding)."""
     from desktop2stereo_amd import ops, synth
     from desktop2stereo_amd.config import MODELS, engine_shape
@@ -497,10 +497,10 @@ def test_conv_kernel_generations_agree(dev, monkeypatch):
     x = ops.preprocess(torch.stack([_t(synth.structured_frame(1080, 1920, 40 + s), dev) for s in range(B)]), 518)
     outs = {}
     try:
-        for name, env in (("default", {}), ("no_headups", {"D2S_NO_HEADUPS": "1"}), ("no_wide", {"D2S_NO_WIDE": "1"}),
+        for name, env in (("default", {}), ("no_headups", {"D2S_NO_HEADUPS": "1"}), ("no_upsfold", {"D2S_NO_UPSFOLD": "1"}), ("no_wide", {"D2S_NO_WIDE": "1"}),
                           ("no_halo2", {"D2S_NO_WIDE": "1", "D2S_NO_HALO2": "1"}),
                           ("implicit", {"D2S_NO_WIDE": "1", "D2S_NO_HALO2": "1", "D2S_NO_HALO": "1"})):
-            for k in ("D2S_NO_WIDE", "D2S_NO_HALO2", "D2S_NO_HALO", "D2S_NO_HEADUPS"):
+            for k in ("D2S_NO_WIDE", "D2S_NO_HALO2", "D2S_NO_HALO", "D2S_NO_HEADUPS", "D2S_NO_UPSFOLD"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -510,14 +510,15 @@ def test_conv_kernel_generations_agree(dev, monkeypatch):
             assert np.array_equal(outs[name], eng(x).cpu().numpy()), name            # run-to-run identical
             eng.close()
     finally:
-        for k in ("D2S_NO_WIDE", "D2S_NO_HALO2", "D2S_NO_HALO", "D2S_NO_HEADUPS"):
+        for k in ("D2S_NO_WIDE", "D2S_NO_HALO2", "D2S_NO_HALO", "D2S_NO_HEADUPS", "D2S_NO_UPSFOLD"):
             monkeypatch.delenv(k, raising=False)
         ops.reload_env()
     scale = float(np.abs(outs["implicit"]).max())
-    for name in ("default", "no_headups", "no_wide", "no_halo2"):
+    for name in ("default", "no_headups", "no_upsfold", "no_wide", "no_halo2"):
         d = np.abs(outs[name] - outs["implicit"])
         print(f"[conv kernels] {name} vs implicit GEMM: max {d.max() / scale:.5f} mean {d.mean() / scale:.6f} of the depth range")
     assert np.array_equal(outs["default"], outs["no_headups"])     # up-sample folded into the head conv's loader: the same bilerp1
+    assert np.array_equal(outs["default"], outs["no_upsfold"])     # neither up-sample of the head folded (conv1's, conv2's)
     assert np.array_equal(outs["default"], outs["no_wide"])
     # (the head's conv2 + conv3 tail sums its 32 channels in another order in the persistent head kernel: fp32 rounding only)
     assert np.allclose(outs["no_wide"], outs["no_halo2"], rtol=0, atol=2e-6 * scale)
