@@ -451,12 +451,12 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     // LayerNorm-ed operands -> folded up to 8 frames
     static const int lnf_maxb = getenv("D2S_LNF_MAXB") ? atoi(getenv("D2S_LNF_MAXB")) : 8;       // tuning aid
     static const bool no_lnf = getenv("D2S_NO_LNFUSE") && atoi(getenv("D2S_NO_LNFUSE")) != 0;
-    const bool lnf = ((e->lnf && !e->fp8) || (f8 && !no_lnf)) && !e->calib && prec == D2S_PREC_BF16 && B <= lnf_maxb;
+    const bool lnf = ((e->lnf && !e->fp8) || (f8 && !no_lnf)) && !e->calib && (prec == D2S_PREC_BF16 || x3) && B <= lnf_maxb;
     int ln_slots = 0;
     // batch 1, bf16: the four tap LayerNorms fold into the reassemble projections the same way (the statistics and the raw
     // residual of a tap layer are still in lnbuf / lnstats when its projection runs; the main stream waits for that launch
     // -- ev_ln -- before the next layer's projection GEMM overwrites them)
-    const bool tap_fold = lnf && !f8 && e->lnf && B == 1;
+    const bool tap_fold = lnf && !f8 && !x3 && e->lnf && B == 1;           // (bf16x3: the tap LayerNorms stay kernels)
     bool tap_folded[4] = {false, false, false, false};
     int pending_ln = -1;
     for (int l = 0; l < d.layers; ++l) {
@@ -482,7 +482,7 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
             if (pending_ln >= 0) { D2S_HIP(hipStreamWaitEvent(st, e->ev_ln[pending_ln], 0)); pending_ln = -1; }
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.proj.bias);
             ep.scale = ly.ls1; ep.res1 = e->resid;
-            if (lnf) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[4] : 0.f; }
+            if (lnf) { ep.out2 = e->lnbuf; ep.out2_bx3 = x3; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[4] : 0.f; }
             if (f8) { ep.deq = ly.deq[1]; RC(gemm8(e, plainA(e->attn, D), ly.w8[1], M, ep, st)); }
             else RC(gemm(e, splitA(e->attn, D, x3), ly.proj, M, ep, st));
         }
@@ -501,7 +501,7 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         {
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.fc2.bias);
             ep.scale = ly.ls2; ep.res1 = e->resid;
-            if (lnf && (l + 1 < d.layers || tap_fold)) { ep.out2 = e->lnbuf; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[5] : 0.f; }
+            if (lnf && (l + 1 < d.layers || tap_fold)) { ep.out2 = e->lnbuf; ep.out2_bx3 = x3; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[5] : 0.f; }
             if (f8) { ep.deq = ly.deq[3]; RC(gemm8(e, plainA(e->mlp, d.mlp), ly.w8[3], M, ep, st)); }
             else RC(gemm(e, splitA(e->mlp, d.mlp, x3), ly.fc2, M, ep, st));
         }
@@ -627,9 +627,9 @@ extern "C" int d2s_engine_create(const d2s_model_desc* desc, int device_id, d2s_
     d2s_engine* e = new d2s_engine();
     e->d = *desc; e->device = device_id;
     e->fp8 = desc->precision == D2S_PREC_FP8;
-    {   // LayerNorm fusion: bf16 engines only (fp32 is the parity class; the e4m3 path quantises the LN output itself)
+    {   // LayerNorm fusion: bf16 and bf16x3 engines (not the plain fp32 engine; the e4m3 path quantises the LN output itself)
         const char* no = getenv("D2S_NO_LNFUSE");
-        e->lnf = desc->precision == D2S_PREC_BF16 && !(no && atoi(no) != 0);
+        e->lnf = (desc->precision == D2S_PREC_BF16 || desc->precision == D2S_PREC_BF16X3) && !(no && atoi(no) != 0);
     }                  // bf16 engine whose encoder linears switch to e4m3 operands
     e->prec = e->fp8 ? D2S_PREC_BF16 : (desc->precision == D2S_PREC_BF16X3 ? D2S_PREC_FP32 : desc->precision);
     e->wprec = desc->precision == D2S_PREC_BF16X3 ? D2S_PREC_BF16X3 : e->prec;      // split-precision GEMM operands on the fp32 engine
@@ -710,7 +710,12 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
                 std::vector<float> b2(Nn), cs(Nn);
                 for (int n = 0; n < Nn; ++n) {
                     double sb = bias[n], sc = 0.0;
-                    for (int k = 0; k < D; ++k) { sb += (double)bt->data[k] * at(n, k); sc += bf2f(f2bf(g->data[k] * at(n, k))); }
+                    for (int k = 0; k < D; ++k) {
+                        sb += (double)bt->data[k] * at(n, k);
+                        const float v = g->data[k] * at(n, k);              // colsum over what the MFMAs sum: bf16(W'), or its hi + lo halves
+                        const float hi = bf2f(f2bf(v));
+                        sc += e->wprec == D2S_PREC_BF16X3 ? (double)hi + (double)bf2f(f2bf(v - hi)) : (double)hi;
+                    }
                     b2[n] = (float)sb; cs[n] = (float)sc;
                 }
                 int rc = pack_matrix(e, Nn, D, [&](int n, int k) { return g->data[k] * at(n, k); }, b2.data(), out);

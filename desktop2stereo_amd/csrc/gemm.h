@@ -63,6 +63,7 @@ struct GemmEpi {
     // launcher reports the number of column blocks through stats_slots (host int; the consumer takes at most 16).
     void* out2; float* stats_out; int* stats_slots;
     float out2_qscale;                            // 0: out2 is bf16; > 0: out2 is e4m3 of v * out2_qscale (the e4m3 encoder path)
+    int out2_bx3;                                 // bf16x3 engines: out2 is the pre-split unit format (A operand of the LN-folded consumer)
     // Consumer: A rows are the RAW bf16 residual and W is gamma-folded, so LN(x) W = rstd * (x W' - mean * colsum(W'));
     // the kernel applies v = rstd[m] * (acc - mean[m] * ln_csum[n]) before bias (bias already holds b + W beta).
     const float* ln_stats; int ln_slots; const float* ln_csum; float ln_eps; int ln_dim;

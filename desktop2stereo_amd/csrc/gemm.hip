@@ -846,7 +846,7 @@ int launch_gemm(int precision, int tile, const GemmA& a, const void* W, int M, i
     if (a.mode == A_PLAIN && (a.lda % ce)) { set_error("launch_gemm: lda not chunk aligned"); return D2S_E_INVALID; }
     if (a.mode == A_CONV3 && (a.C % ce)) { set_error("launch_gemm: conv channels not chunk aligned"); return D2S_E_INVALID; }
     if (precision == D2S_PREC_BF16X3) {
-        if (e.ln_stats || e.ln_csum || e.stats_out || e.out2 || e.deq) { set_error("launch_gemm: bf16x3 operands take plain epilogues"); return D2S_E_UNSUPPORTED; }
+        if (e.deq || (e.out2 && !e.out2_bx3)) { set_error("launch_gemm: bf16x3 operands: no de-quantisation, raw-residual copies in the unit format only"); return D2S_E_UNSUPPORTED; }
         return launch_bx3(tile, a, W, M, N, K, Kpad, e, st);
     }
     if (tile == 256256) return launch_gemm_pp(precision, a, W, M, N, K, Kpad, e, st);      // the ping-pong kernel, forced (tests / sweeps)

@@ -263,7 +263,8 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float
             if (e.out2_qscale > 0.f) {
                 float q[4] = {v[0] * e.out2_qscale, v[1] * e.out2_qscale, v[2] * e.out2_qscale, v[3] * e.out2_qscale};
                 store4((fp8_t*)e.out2 + off, q);
-            } else store4((bf16_t*)e.out2 + off, v);
+            } else if (e.out2_bx3) store4((bx3_t*)e.out2 + off, v);
+            else store4((bf16_t*)e.out2 + off, v);
         }
     }
 }
