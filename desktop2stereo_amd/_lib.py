@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libd2s_hip.so")
+LIB_PATH = os.environ.get("D2S_LIB") or os.path.join(HERE, "libd2s_hip.so")     # D2S_LIB: another build of the same library (A/B runs)
 
 OK = 0
 MODE = {"Half-SBS": 0, "Full-SBS": 1, "Half-TAB": 2, "Full-TAB": 3}

@@ -27,6 +27,29 @@ int hip_fail(hipError_t err, const char* what, const char* file, int line);
 #define D2S_POISON_LDS(PTR, N16) {}
 #endif
 
+// Kernel-argument warm-up for the latency-bound launches.  The kernarg segment is written by the host for every launch and read
+// cold from device memory; the compiler fetches it lazily -- an s_load where a field is first needed, behind the branches of the
+// tile map -- so a kernel with ~370 bytes of arguments pays three or four serialised ~0.5 us misses before its first operand
+// request (gemm_glds_kernel: first LDS-DMA at instruction 775).  KERNARG_WARM(ka) at the top of the kernel requests one dword of
+// each 64-byte line at once (six lines); KERNARG_WARM_END(ka) -- placed where the compiler has already waited for its own scalar
+// loads -- waits for them and releases the six scratch SGPRs (they must stay reserved until the loads have landed: the hardware
+// writes them when the data arrives).  The compiler's own s_loads then hit the scalar cache.
+struct KernargWarm { int d0, d1, d2, d3, d4, d5; };
+#ifdef D2S_NO_KERNARG_WARM                       // (A/B builds)
+#define KERNARG_WARM(ka) {}
+#define KERNARG_WARM_END(ka) {}
+#else
+#define KERNARG_WARM(ka)                                                                                              \
+    KernargWarm ka;                                                                                                   \
+    {                                                                                                                 \
+        auto p_ = __builtin_amdgcn_kernarg_segment_ptr();                                                             \
+        asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\t"          \
+                     "s_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140"           \
+                     : "=&s"(ka.d0), "=&s"(ka.d1), "=&s"(ka.d2), "=&s"(ka.d3), "=&s"(ka.d4), "=&s"(ka.d5) : "s"(p_));   \
+    }
+#define KERNARG_WARM_END(ka) asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(ka.d0), "s"(ka.d1), "s"(ka.d2), "s"(ka.d3), "s"(ka.d4), "s"(ka.d5) : "memory");
+#endif
+
 // Integer switch from the environment (kernel selection for A/B runs and tests): cached, re-read after
 // d2s_debug_reload_env() so that one process can run both sides.  Usage:  static EnvInt f{"D2S_NO_X", 0};  if (f.get()) ...
 int env_generation();

@@ -44,6 +44,8 @@ template <int PST> __device__ __forceinline__ int c3_chunk_slot(int c) {
 template <int CPP, int PST, int BN, int WM, int WN, int NS>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad, GemmEpi e, int xn) {
+    KERNARG_WARM(kaw_)                                   // all argument lines in one round trip (common.h)
+    KERNARG_WARM_END(kaw_)
     constexpr int TW = 16, TH = 8, HWD = TW + 2, HPX = (TH + 2) * HWD;
     constexpr int NW = WM * WN, FM = TH / WM, FN = BN / WN / 16;
     constexpr int KPT = CPP / 8, NKT = 9 * KPT;             // K tiles (64 channels of one tap) per tap / in all
@@ -227,6 +229,8 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
 template <int UPS>
 __global__ void __launch_bounds__(512)
 conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEpi e, int ntiles) {
+    KERNARG_WARM(kaw_)                                   // all argument lines in one round trip (common.h)
+    KERNARG_WARM_END(kaw_)
     constexpr int CPP = 8, PST = 10, TH = 16, TW = 16, HWD = TW + 2, HPX = (TH + 2) * HWD, HALO = HPX * PST;
     constexpr int NCH = HPX * CPP, NLD = (NCH + 511) / 512;       // halo chunks, loads per thread (6)
     constexpr int SR = 13, SCH = SR * SR * CPP, NSL = (SCH + 511) / 512;   // UPS: source window (pixels per side), its chunks, loads per thread (3)
@@ -453,6 +457,8 @@ __device__ unsigned long long c3_timing[256 * 8];
 template <int TH, int TW>
 __global__ void __launch_bounds__(512)
 conv3_wide_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEpi e, int ntiles) {
+    KERNARG_WARM(kaw_)                                   // all argument lines in one round trip (common.h)
+    KERNARG_WARM_END(kaw_)
     constexpr int CPP = 16, PST = 17, HWD = TW + 2, HPX = (TH + 2) * HWD, HALO = HPX * PST;
     constexpr int NCH = HPX * CPP, NLD = (NCH + 511) / 512;
     constexpr int NW = 8, WN = 2, FM = 4, FN = 4, FPR = TW / 16;

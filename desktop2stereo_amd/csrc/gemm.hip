@@ -98,6 +98,8 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     constexpr int PD = NS - 1;
     constexpr int STAGE = (BM + BN) * CPR;          // chunks per stage
     __shared__ __attribute__((aligned(16))) u32x4 lds[NS * STAGE];
+    KERNARG_WARM(kaw_)                               // every 64-byte line of the ~370 argument bytes in one round trip (common.h)
+    KERNARG_WARM_END(kaw_)
     D2S_POISON_LDS(lds, NS * STAGE)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -497,6 +499,8 @@ splitk_reduce_kernel(GemmEpi e, int M, int N) {
 template <typename T, int BN, int WM, int WN>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv3_halo_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
+    KERNARG_WARM(kaw_)                                   // all argument lines in one round trip (common.h)
+    KERNARG_WARM_END(kaw_)
     constexpr int CE = Prec<T>::CE, CPR = 8, BK = CPR * CE, NS = 2;
     constexpr int TW = 16, TH = 8, BM = TH * TW, HWD = TW + 2, HPX = (TH + 2) * HWD;
     constexpr int HCPP = 16;                            // capacity: 16-byte chunks per input pixel
