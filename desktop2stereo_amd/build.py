@@ -17,7 +17,11 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libd2s_hip.so")
 SOURCES = ["core.cpp", "present.cpp", "ingest.hip", "frame_ops.hip", "dibr.hip", "jpeg.hip", "post.hip", "gemm.hip", "conv3.hip", "gemm_pp.hip", "vit_ops.hip", "attention.hip", "temporal.hip", "engine.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         # kernarg preload (gfx950): the first 16 argument dwords of a kernel arrive in SGPRs with the wave instead of through a cold
+         # s_load -- scalar / pointer arguments up to the first by-value struct.  gemm_glds_kernel's argument order is built around it
+         # (gemm.hip); the small kernels (attention, LayerNorm, up-sample, post-process) get all their arguments that way.
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 FLAGS += os.environ.get("D2S_HIPCC_DEFS", "").split()          # tuning aids only (e.g. -DD2S_PP_TIMING); rebuild with --force
 # no FMA contraction in the frame-side / post-process kernels: keeps their float32 op sequence
 # comparable with the oracle's (the matrix kernels keep the default fast contraction)

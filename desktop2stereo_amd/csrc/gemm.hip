@@ -80,7 +80,11 @@ template <int CPR> __device__ __forceinline__ int swz_row(int r) { return CPR ==
 // (~10 TB/s aggregate), not latency-bound; it won 9 % on FC2 in isolation and lost 2 % in the pipeline.  Removed.)
 template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, int STG = 0>
 __global__ void __launch_bounds__(64 * WM * WN)
-gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
+gemm_glds_kernel(const T* __restrict__ W, const void* a_ptr, long a_lda, int M, int N, int K, int Kpad, int xn, GemmA a, GemmEpi e) {
+    // Argument order: what the tile map and the first operand requests need -- 11 dwords -- comes first, so that the hardware's kernarg
+    // PRELOAD (gfx950: the first 16 dwords arrive in SGPRs with the wave; -mllvm -amdgpu-kernarg-preload-count=16, build.py) covers
+    // it: the lean (latency-regime) instantiations request their first K tiles before any kernarg load has returned.  a_ptr / a_lda
+    // repeat a.ptr / a.lda for that purpose.
     // STG: 0 = LDS-DMA ring, every loader; 1 = register-staged, two LDS stages; 2 = "lean" LDS-DMA ring: descriptor-addressed plain
     // linears only (a.buf guaranteed by the launcher) -- the pointer / implicit-conv loaders and their per-row set-up are compiled out
     static_assert(STG == 0 || STG == 2 || (STG == 1 && NS == 2), "the register-staged variant uses two LDS stages");
@@ -98,8 +102,8 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     constexpr int PD = NS - 1;
     constexpr int STAGE = (BM + BN) * CPR;          // chunks per stage
     __shared__ __attribute__((aligned(16))) u32x4 lds[NS * STAGE];
-    KERNARG_WARM(kaw_)                               // every 64-byte line of the ~370 argument bytes in one round trip (common.h)
-    KERNARG_WARM_END(kaw_)
+    KERNARG_WARM(kaw_)                               // every 64-byte line of the ~390 argument bytes in one round trip (common.h)
+    if constexpr (STG != 2) { KERNARG_WARM_END(kaw_) }   // (lean: waited for behind the first operand requests)
     D2S_POISON_LDS(lds, NS * STAGE)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -142,7 +146,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     // every descriptor's range: the hardware returns zeros for them.
     constexpr int ES = (int)sizeof(T);
     // (descriptors are built unconditionally -- a few scalar instructions; the offsets only where the path is taken)
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.ptr), 0, (unsigned)((long)M * a.lda * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a_ptr), 0, (unsigned)((long)M * a_lda * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(W), 0, (unsigned)((long)((N + 255) / 256 * 256) * Kpad * ES), 0x00020000);
     unsigned voA[AI], voW[BI];
     if constexpr (STG != 1) {
@@ -150,7 +154,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 const int m = bm0 + i * NW * RPI + lrow;
-                voA[i] = m < M ? (unsigned)((long)m * a.lda * ES) + (unsigned)(src_chunk * 16) : 0x80000000u;
+                voA[i] = m < M ? (unsigned)((long)m * a_lda * ES) + (unsigned)(src_chunk * 16) : 0x80000000u;
             }
 #pragma unroll
             for (int i = 0; i < BI; ++i) voW[i] = (unsigned)((long)(bn0 + lrow + RPI * NW * i) * Kpad * ES) + (unsigned)(src_chunk * 16);
@@ -162,6 +166,17 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
         const int so_ = ((KT) + kt0) * (BK * ES);                                                                \
         _Pragma("unroll") for (int i = 0; i < AI; ++i) lds_dma16(rsA, st_ + (i * NW + wid) * 64, voA[i], so_);    \
         _Pragma("unroll") for (int i = 0; i < BI; ++i) lds_dma16(rsW, st_ + BM * CPR + (i * NW + wid) * 64, voW[i], so_); \
+    }
+
+    // lean instantiations (one K range per block: the launcher never splits K for them): the ring is primed HERE, from preloaded
+    // arguments only; everything that reads the rest of the kernarg segment (LayerNorm statistics, epilogue set-up) comes after
+    if constexpr (LEAN) {
+        constexpr int kt0 = 0;
+        const int nkt_ = (K + BK - 1) / BK;
+#pragma unroll
+        for (int t = 0; t < PD; ++t)
+            if (t < nkt_) D2S_ISSUE_BUF(t)
+        KERNARG_WARM_END(kaw_)
     }
 
     // D2S_MOVE(slot index, source, LDS destination): LDS-DMA straight into the ring, or a load into staging registers
@@ -227,7 +242,7 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
 
     // split-K (e.ksplit > 1): blockIdx.y owns a contiguous range of K tiles and writes raw fp32 partials
     const int nkt_all = (K + BK - 1) / BK;
-    const int ksplit = e.ksplit > 1 ? e.ksplit : 1;
+    const int ksplit = LEAN ? 1 : (e.ksplit > 1 ? e.ksplit : 1);
     const int kt0 = (int)(((long)nkt_all * blockIdx.y) / ksplit);
     const int nkt = (int)(((long)nkt_all * (blockIdx.y + 1)) / ksplit) - kt0;
     const int fr = lane & 15, fg = lane >> 4;
@@ -305,9 +320,11 @@ gemm_glds_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad
     bool done_buf = false;
     if constexpr (STG != 1) {
         if (LEAN || a.buf) {                         // plain linear, descriptor-addressed ring (same ring, same waits)
+            if constexpr (!LEAN) {
 #pragma unroll
-            for (int t = 0; t < PD; ++t)
-                if (t < nkt) D2S_ISSUE_BUF(t)
+                for (int t = 0; t < PD; ++t)
+                    if (t < nkt) D2S_ISSUE_BUF(t)
+            }
             GL_STAMP(1)
             for (int kt = 0; kt < nkt; ++kt) {
                 if (kt + PD - 1 < nkt) wait_vmcnt<(PD - 1) * LPT>();
@@ -626,6 +643,14 @@ static inline bool buf_eligible(const GemmA& a, int M, int N, int K, int Kpad, i
     return a.mode == A_PLAIN && !a.relu && K % bk == 0 && (long)M * a.lda * (long)es < (1L << 31) && (long)gemm_npad(N) * Kpad * (long)es < (1L << 31);
 }
 
+// would launch_glds split K for this launch (tiny grid, long K loop, caller-provided workspace)?  The lean instantiations take one K
+// range per block (their ring is primed from preloaded arguments before e.ksplit could be read): the dispatchers send such
+// launches to the general instantiations.
+static inline bool splitk_wanted(const GemmEpi& e, long tiles, int K, int bk) {
+    static const int sk_grid = getenv("D2S_SPLITK_GRID") ? atoi(getenv("D2S_SPLITK_GRID")) : 128;
+    return e.part && e.part_elems > 0 && tiles < sk_grid && cdiv(K, bk) >= 24;
+}
+
 // tile codes: 64 (64x64), 128 (128x128), 256128 / 256256 (8 waves), 25664 / 25632 (256 x 64|32, 4 waves); 0 = auto
 template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR = 8, int STG = 0>
 static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
@@ -637,13 +662,13 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
     int ks = 1;
     static const int sk_grid = getenv("D2S_SPLITK_GRID") ? atoi(getenv("D2S_SPLITK_GRID")) : 128;       // tuning aids
     static const int sk_div = getenv("D2S_SPLITK_DIV") ? atoi(getenv("D2S_SPLITK_DIV")) : 6;
-    if (e.part && e.part_elems > 0 && (int)grid < sk_grid && nkt >= 24) {
+    if (STG != 2 && e.part && e.part_elems > 0 && (int)grid < sk_grid && nkt >= 24) {
         ks = nkt / sk_div; if (ks > 16) ks = 16;
         while (ks > 1 && (size_t)ks * M * N > e.part_elems) --ks;
     }
     if (ks > 1) {
         GemmEpi e2 = e; e2.ksplit = ks;
-        hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid, ks), dim3(64 * WM * WN), 0, st, a, (const T*)W, M, N, K, Kpad, e2, xn);
+        hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid, ks), dim3(64 * WM * WN), 0, st, (const T*)W, a.ptr, a.lda, M, N, K, Kpad, xn, a, e2);
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(cdiv((long)M * (N / 4), 256)), dim3(256), 0, st, e2, M, N);
         return;
     }
@@ -655,7 +680,7 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
         constexpr int bk = CPR * (16 / (int)sizeof(T));
         a1.buf = !nobuf && STG != 1 && buf_eligible(a, M, N, K, Kpad, bk, sizeof(T));
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid), dim3(64 * WM * WN), 0, st, a1, (const T*)W, M, N, K, Kpad, e1, xn);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid), dim3(64 * WM * WN), 0, st, (const T*)W, a1.ptr, a1.lda, M, N, K, Kpad, xn, a1, e1);
 }
 
 // stride-1 3x3 convs on the large maps go to conv3_halo_kernel (input tile resident in LDS); D2S_NO_HALO=1 keeps the
@@ -704,7 +729,8 @@ static int launch_bx3(int tile, const GemmA& a, const void* W, int M, int N, int
         }
         // (latency regime: the deep-ring lean instantiations, as in launch_t)
         static const int deep = getenv("D2S_GEMM_DEEP") ? atoi(getenv("D2S_GEMM_DEEP")) : 1;
-        const bool dp = deep && buf_eligible(a, M, N, K, Kpad, 32, 4);
+        const bool dp = deep && buf_eligible(a, M, N, K, Kpad, 32, 4) &&
+                        !splitk_wanted(e, (long)cdiv(M, t == 3264 ? 32 : 64) * cdiv(N, t == 641288 ? 128 : 64), K, 32);
         if (t == 3264 && dp && (long)cdiv(M, 32) * cdiv(N, 64) <= 512) launch_glds<T, 32, 64, 2, 2, 6, 8, 2>(a, W, M, N, K, Kpad, e, st);
         else if (t == 64648 && dp && (long)cdiv(M, 64) * cdiv(N, 64) <= 512) launch_glds<T, 64, 64, 4, 2, 4, 8, 2>(a, W, M, N, K, Kpad, e, st);
         else if (t == 641288 && dp && (long)cdiv(M, 64) * cdiv(N, 128) <= 512) launch_glds<T, 64, 128, 2, 4, 3, 8, 2>(a, W, M, N, K, Kpad, e, st);
@@ -792,7 +818,8 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     if constexpr (std::is_same<T, bf16_t>::value || std::is_same<T, fp8_t>::value) {
         static const int deep = getenv("D2S_GEMM_DEEP") ? atoi(getenv("D2S_GEMM_DEEP")) : 1;
         static const bool nobuf = getenv("D2S_GEMM_NOBUF") && atoi(getenv("D2S_GEMM_NOBUF")) != 0;
-        if (deep && !nobuf && !(e.part && e.ksplit > 1) && buf_eligible(a, M, N, K, Kpad, 128 / (int)sizeof(T), sizeof(T)) && e.map != MAP_HEAD) {
+        if (deep && !nobuf && !(e.part && e.ksplit > 1) && buf_eligible(a, M, N, K, Kpad, 128 / (int)sizeof(T), sizeof(T)) && e.map != MAP_HEAD &&
+            !splitk_wanted(e, (long)cdiv(M, tile == 3264 ? 32 : 64) * cdiv(N, tile == 641288 ? 128 : 64), K, 128 / (int)sizeof(T))) {
             bool done = true;
             if (tile == 3264 && (long)cdiv(M, 32) * cdiv(N, 64) <= 512) launch_glds<T, 32, 64, 2, 2, 6, 8, 2>(a, W, M, N, K, Kpad, e, st);            // 72 KiB: 2 blocks / CU
             else if (tile == 64648 && (long)cdiv(M, 64) * cdiv(N, 64) <= 512) launch_glds<T, 64, 64, 4, 2, 4, 8, 2>(a, W, M, N, K, Kpad, e, st);       // 64 KiB: 2 blocks / CU
