@@ -65,16 +65,24 @@ __device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& w, const u32x
     acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[1], al[1], acc, 0, 0, 0);
 }
 
-// exact-erf GELU (HF Dinov2MLP: nn.GELU()).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e. at
-// float32 round-off for this use) -- one rcp + one exp + 6 fma instead of the ~40-instruction libm erff,
-// which was ~25 % of the FC1 launch at batch 1.
-__device__ __forceinline__ float gelu_erf(float x) {
-    float z = fabsf(x) * 0.70710678118654752f;
-    float t = __frcp_rn(1.0f + 0.3275911f * z);
-    float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    float erf_abs = 1.0f - poly * __expf(-z * z);
-    float erf_x = x < 0.f ? -erf_abs : erf_abs;
-    return 0.5f * x * (1.0f + erf_x);
+// exact-erf GELU (HF Dinov2MLP: nn.GELU()).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e. at float32 round-off for this
+// use) instead of the ~40-instruction libm erff, on two values at once so that the
+// multiplies / fmas become v_pk_mul_f32 / v_pk_fma_f32 (one instruction per PAIR), rearranged to
+//     gelu(x) = x/2 (1 + erf(x / sqrt 2)) = max(x, 0) - (|x| P(t)/2) exp(-x^2 / 2),    t = 1 / (1 + p |x| / sqrt 2)
+// (x/2 + |x|/2 = max(x, 0); the sign of erf cancels against the sign of x): 14 vector + 4 transcendental instructions per
+// pair (max |err| 3.3e-7).  FC1's epilogue is 128 x 64 GELUs per wave with the matrix pipe idle in the ping-pong kernel -- about 6 us of a
+// 24 us tile at batch 32 -- and 16 per lane between the K loop and the stores in the latency-regime tiles; ONE expression for every
+// kernel, so that the engine's output does not depend on which kernel a batch size selects.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2v gelu_erf2(f32x2v x) {
+    const f32x2v ax = __builtin_elementwise_abs(x);
+    const f32x2v den = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
+    const f32x2v t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};       // v_rcp_f32 (1 ulp); __frcp_rn is a full division
+    const f32x2v hp = t * (t * (t * (t * (t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f)) + (0.5f * 1.421413741f)) + (0.5f * -0.284496736f)) + (0.5f * 0.254829592f));
+    const f32x2v arg = (ax * ax) * (-0.5f * 1.4426950408889634f);                           // exp(-x^2/2) = 2^arg
+    const f32x2v ex = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+    const f32x2v relu = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    return relu - (ax * hp) * ex;
 }
 
 __device__ __forceinline__ void load4(const float* p, float v[4]) { float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
@@ -230,7 +238,10 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float
         if (cols) { v[0] += cols->bias[0]; v[1] += cols->bias[1]; v[2] += cols->bias[2]; v[3] += cols->bias[3]; }
         else { float b[4]; load4(e.bias + n0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
     }
-    if (e.act == ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+    if (e.act == ACT_GELU) {
+        const f32x2v g0 = gelu_erf2((f32x2v){v[0], v[1]}), g1 = gelu_erf2((f32x2v){v[2], v[3]});
+        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+    }
     else if (e.act == ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
     if (e.scale) {
         if (cols) { v[0] *= cols->scale[0]; v[1] *= cols->scale[1]; v[2] *= cols->scale[2]; v[3] *= cols->scale[3]; }

@@ -128,22 +128,7 @@ __device__ int pp_timing_kind = -1;
 #define PP_WSTAMP(SLOT)
 #endif
 
-// exact-erf GELU on two values at once: the Abramowitz-Stegun 7.1.26 form of gelu_erf (gemm_epi.h) on 2-vectors, so that the
-// multiplies / fmas become v_pk_mul_f32 / v_pk_fma_f32 (one instruction per PAIR), rearranged to
-//     gelu(x) = x/2 (1 + erf(x / sqrt 2)) = max(x, 0) - (|x| P(t)/2) exp(-x^2 / 2),    t = 1 / (1 + p |x| / sqrt 2)
-// (x/2 + |x|/2 = max(x, 0); the sign of erf cancels against the sign of x): 14 vector + 4 transcendental instructions per
-// pair.  FC1's epilogue is 128 x 64 GELUs per wave with the matrix pipe idle -- about 6 us of a 24 us tile at batch 32.
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2v gelu_erf2(f32x2v x) {
-    const f32x2v ax = __builtin_elementwise_abs(x);
-    const f32x2v den = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
-    const f32x2v t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};       // v_rcp_f32 (1 ulp); __frcp_rn is a full division
-    const f32x2v hp = t * (t * (t * (t * (t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f)) + (0.5f * 1.421413741f)) + (0.5f * -0.284496736f)) + (0.5f * 0.254829592f));
-    const f32x2v arg = (ax * ax) * (-0.5f * 1.4426950408889634f);                           // exp(-x^2/2) = 2^arg
-    const f32x2v ex = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
-    const f32x2v relu = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
-    return relu - (ax * hp) * ex;
-}
+// (gelu_erf2: gemm_epi.h -- every kernel's GELU epilogue evaluates the same packed expression)
 
 // Epilogue modes.  Every mode issues at least PP_TAIL vector-memory instructions per wave after its hook (rows past M fall
 // outside the output buffer's num_records: the store is dropped but still issues), because the caller counts them in vmcnt.
