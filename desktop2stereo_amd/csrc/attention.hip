@@ -667,6 +667,11 @@ int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B
         else if (bq == 64 && ks == 4)
             hipLaunchKernelGGL((attention_kernel<bf16_t, 1, 4, 2, bf16_t, 4>), dim3(attn_grid(cdiv(N, 64), pairs)), dim3(1024), 0, st,
                                (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, N, Npad, heads, pairs, scale_log2e, 1.0f);
+        else if (bq == 64 && ks == 3)       // (D2S_ATTN_KS=3: three groups, three ring stages each = two key tiles in flight per group.
+                                            //  10.5 us against 10.6 / 10.8 with 4 / 2 groups at N = 778: the batch-1 launch is not waiting
+                                            //  for its key tiles -- 156 blocks keep 156 of 256 CUs at four waves per SIMD of softmax VALU work)
+            hipLaunchKernelGGL((attention_kernel<bf16_t, 1, 4, 3, bf16_t, 3>), dim3(attn_grid(cdiv(N, 64), pairs)), dim3(768), 0, st,
+                               (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, N, Npad, heads, pairs, scale_log2e, 1.0f);
         else if (bq == 128) D2S_ATT(bf16_t, 1, 8);
         else if (bq == 64) D2S_ATT(bf16_t, 1, 4);
         else D2S_ATT(bf16_t, 1, 2);
