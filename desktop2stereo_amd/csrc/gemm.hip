@@ -831,6 +831,8 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
             if (done) { D2S_CHECK_LAUNCH(); return D2S_OK; }
         }
     }
+    // (The same deeper rings for the implicit 3x3 convolutions of the small DPT maps at batch 1 -- general loaders, 32 x 64 x 6 / 64 x 64 x 4 /
+    //  64 x 128 x 3 stages when every block is resident: 866-873 frames/s with and without, ViT-S 1 200 vs 1 227.  Measured, removed.)
     // LDS-DMA ring (NS stages)
     if (tile == 256128) launch_glds<T, 256, 128, 4, 2, 3>(a, W, M, N, K, Kpad, e, st);
     else if (tile == 128) launch_glds<T, 128, 128, 2, 2, 4>(a, W, M, N, K, Kpad, e, st);
