@@ -85,27 +85,19 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
     for (int t = 0; t < PD; ++t)
         if (t < NKT) C3_ISSUE_W(t)
 
-    // ---- the input halo, once: 10 x 18 pixels x C channels, zero outside the image, ReLU-on-load (pre-activation units)
+    // ---- the input halo, once: 10 x 18 pixels x C channels, zero outside the image, ReLU-on-load (pre-activation units); a.ups: the
+    // align_corners up-sample in front of this convolution happens here (gemm_epi.h conv_halo_fill)
     {
-        // (a.ups: the align_corners up-sample in front of this convolution happens here, gemm_epi.h ups_chunk)
-        const bf16_t* img = (const bf16_t*)a.ptr + (long)b * (a.ups ? (long)a.Hs * a.Ws : (long)a.Hi * a.Wi) * a.C;
         const short floor_ = a.relu ? (short)0 : (short)0x8000;      // max as int16: 0 = ReLU, most negative = identity
         typedef short s16x8_ __attribute__((ext_vector_type(8)));
-        for (int idx = tid; idx < HPX * CPP; idx += 64 * NW) {
-            const int p = idx / CPP, c = idx - p * CPP;
-            const int hy = p / HWD, hx = p - hy * HWD;
-            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
-                if (a.ups) v = ups_chunk<bf16_t>(img, a, iy, ix, c * 8);
-                else v = *(const u32x4*)(img + ((long)iy * a.Wi + ix) * a.C + c * 8);
-            }
-            s16x8_ x = __builtin_bit_cast(s16x8_, v);
-            x = __builtin_elementwise_max(x, (s16x8_){floor_, floor_, floor_, floor_, floor_, floor_, floor_, floor_});
-            halo[p * PST + c3_chunk_slot<PST>(c)] = __builtin_bit_cast(u32x4, x);
-        }
+        conv_halo_fill<bf16_t, 64 * NW, 3>(a, b, ty0, tx0, HWD, HPX, CPP, tid, halo,
+            [&](int p, int c) { return p * PST + c3_chunk_slot<PST>(c); },
+            [&](u32x4 v) {
+                s16x8_ x = __builtin_bit_cast(s16x8_, v);
+                x = __builtin_elementwise_max(x, (s16x8_){floor_, floor_, floor_, floor_, floor_, floor_, floor_, floor_});
+                return __builtin_bit_cast(u32x4, x);
+            });
     }
-
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -714,7 +706,8 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
     }
     const long tiles_m = (long)nimg * cdiv(a.Ho, 8) * cdiv(a.Wo, 16);
     const int bn = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
-    if (tiles_m * cdiv(N, bn) < 512) return false;                // small maps: latency-bound, the small-tile kernels do better
+    static EnvInt halo2_min{"D2S_HALO2_MIN", 384};        // (head conv1 at batch 1: 399 tiles, 26.5 -> 21.8 us here; 110-tile maps lose)
+    if (tiles_m * cdiv(N, bn) < halo2_min.get()) return false;    // small maps: latency-bound, the small-tile kernels do better
     if ((long)gemm_npad(N) * Kpad * 2 >= (1L << 31)) return false;
     if (dry) return true;
     static const int pst16 = getenv("D2S_HALO2_PST") ? atoi(getenv("D2S_HALO2_PST")) : 17;      // tuning aid: 17 (2 blocks / CU) | 18 (conflict-free)

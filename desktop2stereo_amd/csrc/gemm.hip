@@ -513,12 +513,12 @@ splitk_reduce_kernel(GemmEpi e, int M, int N) {
 // 16 chunks per pixel (C <= 128 bf16 / 64 f32), MAP_ROWS without row remapping, N >= 64.  Measured at batch 16:
 // 84x148 RCU convs 118 -> 100 us (606 TFLOP/s), 42x74 45 -> 33 us, head conv1 271 -> 241 us.
 // ================================================================================================
-template <typename T, int BN, int WM, int WN>
+template <typename T, int BN, int WM, int WN, int NS = 2>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv3_halo_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn) {
     KERNARG_WARM(kaw_)                                   // all argument lines in one round trip (common.h)
     KERNARG_WARM_END(kaw_)
-    constexpr int CE = Prec<T>::CE, CPR = 8, BK = CPR * CE, NS = 2;
+    constexpr int CE = Prec<T>::CE, CPR = 8, BK = CPR * CE, PD = NS - 1;
     constexpr int TW = 16, TH = 8, BM = TH * TW, HWD = TW + 2, HPX = (TH + 2) * HWD;
     constexpr int HCPP = 16;                            // capacity: 16-byte chunks per input pixel
     constexpr int NW = WM * WN, RPI = 64 / CPR;
@@ -541,24 +541,8 @@ conv3_halo_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpa
     const int bn0 = tn_ * BN;
     const int cpp = a.C / CE, smask = cpp - 1;          // chunks per pixel: a power of two <= 16
 
-    // ---- the input halo, once
-    {
-        // (a.ups: the align_corners up-sample in front of this convolution happens here, gemm_epi.h ups_chunk)
-        const T* img = (const T*)a.ptr + (long)b * (a.ups ? (long)a.Hs * a.Ws : (long)a.Hi * a.Wi) * a.C;
-        for (int idx = tid; idx < HPX * cpp; idx += 64 * NW) {
-            const int p = idx / cpp, c = idx - p * cpp;
-            const int hy = p / HWD, hx = p - hy * HWD;
-            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
-                if (a.ups) v = ups_chunk<T>(img, a, iy, ix, c * CE);
-                else v = *(const u32x4*)(img + ((long)iy * a.Wi + ix) * a.C + c * CE);
-            }
-            if (a.relu) v = relu_frag(v, 0, T());
-            halo[p * cpp + (c ^ (p & smask))] = v;
-        }
-    }
-    // ---- weights: LDS-DMA ring, as in gemm_glds_kernel
+    // ---- weights: LDS-DMA ring, as in gemm_glds_kernel; the first NS - 1 K tiles are requested BEFORE the halo is fetched (they do not
+    // depend on it: their latency sits under the halo phase -- with the up-sample folded in, four tap loads and the interpolation per chunk)
     const int lrow = wid * RPI + lane / CPR;
     const int src_chunk = (lane % CPR) ^ swz_row<CPR>(lrow);
     const T* wrow = W + (long)(bn0 + lrow) * Kpad + src_chunk * CE;
@@ -569,19 +553,28 @@ conv3_halo_kernel(GemmA a, const T* __restrict__ W, int M, int N, int K, int Kpa
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow + (long)(RPI * NW * i) * Kpad + (KT) * BK), \
                                              (__attribute__((address_space(3))) void*)(st_ + (i * NW + wid) * 64), 16, 0, 0);              \
     }
+    const int nkt = K / BK;
+#pragma unroll
+    for (int t = 0; t < PD; ++t)
+        if (t < nkt) D2S_ISSUE_W(t)
+    // ---- the input halo, once (a.ups: the align_corners up-sample in front of this convolution happens here; gemm_epi.h)
+    conv_halo_fill<T, 64 * NW, 3>(a, b, ty0, tx0, HWD, HPX, cpp, tid, halo,
+        [&](int p, int c) { return p * cpp + (c ^ (p & smask)); },
+        [&](u32x4 v) { return a.relu ? relu_frag(v, 0, T()) : v; });
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nkt = K / BK, kpt = cpp / CPR;             // K tiles in all, K tiles per tap
+    const int kpt = cpp / CPR;                           // K tiles per tap
     const int fr = lane & 15, fg = lane >> 4;
-    D2S_ISSUE_W(0)
     int tap = 0, sub = 0;                                // kt = tap * kpt + sub
     for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // my W loads of tile kt (and, first time, my halo stores)
+        // my W loads of tile kt (tiles kt + 1 .. kt + PD - 1 may stay in flight) and, first time, my halo stores
+        if (kt + PD - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((PD - 1) * BI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nkt) D2S_ISSUE_W(kt + 1)
+        if (kt + PD < nkt) D2S_ISSUE_W(kt + PD)
         const int ky = tap / 3, kx = tap - ky * 3, cb = sub * CPR;
         const u32x4* B_l = lds + (kt % NS) * STAGE + (wave_n * (BN / WN)) * CPR;
 #pragma unroll
@@ -700,11 +693,12 @@ static bool launch_conv_halo(const GemmA& a, const void* W, int M, int N, int K,
     if (dry) return true;
     GemmEpi e1 = e; e1.ksplit = 1;
     unsigned grid = 0;
-#define D2S_HALO(BN_, WM_, WN_)                                                                                       \
+#define D2S_HALO(BN_, WM_, WN_, NS_)                                                                                  \
     { int xn = pick_xn((int)tiles_m, cdiv(N, BN_), BN_, Kpad, sizeof(T), grid);                                       \
-      hipLaunchKernelGGL((conv3_halo_kernel<T, BN_, WM_, WN_>), dim3(grid), dim3(64 * WM_ * WN_), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn); }
-    if (N <= 64) D2S_HALO(64, 4, 2)
-    else D2S_HALO(128, 2, 4)
+      hipLaunchKernelGGL((conv3_halo_kernel<T, BN_, WM_, WN_, NS_>), dim3(grid), dim3(64 * WM_ * WN_), 0, st, a, (const T*)W, M, N, K, Kpad, e1, xn); }
+    // (ring depth: what keeps two blocks per CU beside the 46 KB halo -- four 8 KB stages for 64 output channels, two 16 KB stages for 128)
+    if (N <= 64) D2S_HALO(64, 4, 2, 4)
+    else D2S_HALO(128, 2, 4, 2)
 #undef D2S_HALO
     return true;
     }

@@ -134,6 +134,53 @@ __device__ __forceinline__ u32x4 ups_chunk(const T* src_img /* [Hs, Ws, C] of th
     return lerp_chunk(v00, v01, v10, v11, tx, ty, T());
 }
 
+// Halo fill of the LDS-resident-input convolutions: the (TH + 2) x (TW + 2) x C input window of an output tile, zero outside the image,
+// optionally interpolated on the fly (a.ups).  GRP chunks per thread are REQUESTED before the first is used: written as a plain loop
+// (load, wait, store; run-time trip count) the ~6 chunks of a thread were six dependent L2 round trips at the head of every block.
+// slot(p, c): LDS index of chunk c of halo pixel p;  fin(v): the kernel's ReLU-on-load.
+template <typename T, int NT, int GRP, typename SlotF, typename FinF>
+__device__ __forceinline__ void conv_halo_fill(const GemmA& a, int b, int ty0, int tx0, int hwd, int npx, int cpp, int tid, u32x4* halo, SlotF slot, FinF fin) {
+    constexpr int CE = 16 / (int)sizeof(T);
+    const T* img = (const T*)a.ptr + (long)b * (a.ups ? (long)a.Hs * a.Ws : (long)a.Hi * a.Wi) * a.C;
+    const int total = npx * cpp;
+    for (int base = tid; base < total; base += NT * GRP) {
+        int pp[GRP], cc[GRP], iy[GRP], ix[GRP];
+        bool in[GRP], st[GRP];
+#pragma unroll
+        for (int g = 0; g < GRP; ++g) {
+            const int idx = base + g * NT;
+            st[g] = idx < total;
+            const int i2 = st[g] ? idx : 0;
+            pp[g] = i2 / cpp; cc[g] = i2 - pp[g] * cpp;
+            const int hy = pp[g] / hwd, hx = pp[g] - hy * hwd;
+            iy[g] = ty0 + hy - 1; ix[g] = tx0 + hx - 1;
+            in[g] = st[g] && iy[g] >= 0 && iy[g] < a.Hi && ix[g] >= 0 && ix[g] < a.Wi;
+            if (!in[g]) { iy[g] = 0; ix[g] = 0; }                 // (a valid address: the loads below are unconditional)
+        }
+        u32x4 r[GRP];
+        if (a.ups) {
+            Tap ty[GRP], tx[GRP];
+            u32x4 v[GRP][4];
+#pragma unroll
+            for (int g = 0; g < GRP; ++g) {
+                ty[g] = linear_tap(iy[g], a.usy, a.Hs, true); tx[g] = linear_tap(ix[g], a.usx, a.Ws, true);
+                const T* r0 = img + (long)ty[g].i0 * a.Ws * a.C + cc[g] * CE;
+                const T* r1 = img + (long)ty[g].i1 * a.Ws * a.C + cc[g] * CE;
+                v[g][0] = *(const u32x4*)(r0 + tx[g].i0 * a.C); v[g][1] = *(const u32x4*)(r0 + tx[g].i1 * a.C);
+                v[g][2] = *(const u32x4*)(r1 + tx[g].i0 * a.C); v[g][3] = *(const u32x4*)(r1 + tx[g].i1 * a.C);
+            }
+#pragma unroll
+            for (int g = 0; g < GRP; ++g) r[g] = lerp_chunk(v[g][0], v[g][1], v[g][2], v[g][3], tx[g], ty[g], T());
+        } else {
+#pragma unroll
+            for (int g = 0; g < GRP; ++g) r[g] = *(const u32x4*)(img + ((long)iy[g] * a.Wi + ix[g]) * a.C + cc[g] * CE);
+        }
+#pragma unroll
+        for (int g = 0; g < GRP; ++g)
+            if (st[g]) halo[slot(pp[g], cc[g])] = fin(in[g] ? r[g] : (u32x4){0u, 0u, 0u, 0u});
+    }
+}
+
 __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
     uint2 t;
     t.x = pk_bf16(v[0], v[1]);
