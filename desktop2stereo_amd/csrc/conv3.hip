@@ -677,7 +677,10 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
     const int nimg = M / (a.Ho * a.Wo);
     if ((long)nimg * a.Ho * a.Wo != M) return false;
     static EnvInt no_persist{"D2S_NO_HEADP", 0};
-    if (!no_persist.get() && e.map == MAP_HEAD && a.C == 64 && N <= 32 && (long)nimg * cdiv(a.Ho, 16) * cdiv(a.Wo, 16) >= 256) {
+    // (from ~8 tiles per CU: at batch 1-2 the 627 / 1 254 tiles are 2.4 / 4.9 rounds of 256 persistent blocks, and the one-shot blocks
+    //  below -- 1 221 per frame, many per CU -- finish sooner: 25.9 -> 20.3 us at batch 1, even at batch 4)
+    static EnvInt headp_min{"D2S_HEADP_MIN", 2048};
+    if (!no_persist.get() && e.map == MAP_HEAD && a.C == 64 && N <= 32 && (long)nimg * cdiv(a.Ho, 16) * cdiv(a.Wo, 16) >= headp_min.get()) {
         static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
         const int ntiles = nimg * cdiv(a.Ho, 16) * cdiv(a.Wo, 16);
         static EnvInt no_headups{"D2S_NO_HEADUPS", 0};
