@@ -774,6 +774,8 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     static const int force_tile = getenv("D2S_GEMM_TILE") ? atoi(getenv("D2S_GEMM_TILE")) : 0;
     if (tile == 0) tile = force_tile;
     if (tile == 0 && launch_conv_halo<T>(a, W, M, N, K, Kpad, e, st)) { D2S_CHECK_LAUNCH(); return D2S_OK; }
+    static EnvInt conv_tile{"D2S_CONV_TILE", 0};          // tuning aid: tile code for the implicit 3x3 convolutions
+    if (tile == 0 && a.mode == A_CONV3 && N > 64) tile = conv_tile.get();
     if constexpr (!std::is_same<T, float>::value) {
         // batched plain linears: the 256 x 256 ping-pong kernel (gemm_pp.hip) once the launch has enough tiles to fill the chip
         // measured (tools/pp_check.py, ViT-B shapes): from ~140 tiles of 256 x 256 the ping-pong kernel wins every encoder
