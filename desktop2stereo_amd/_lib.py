@@ -72,6 +72,7 @@ SYMBOLS = {
     "d2s_engine_calibrate": (C.c_int, [_P, _P, C.c_int, _P]),
     "d2s_post_process": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(PostParams), _P, C.c_uint64, _P]),
     "d2s_post_process_workspace": (C.c_uint64, [C.c_int, C.c_int, C.c_int]),
+    "d2s_post_process_to": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(PostParams), _P, C.c_uint64, _P]),
     "d2s_ema_update": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "d2s_upsample_depth": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
     "d2s_make_sbs": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -100,7 +100,7 @@ struct d2s_engine {
     float* tm_hs = nullptr;                        // [sites_max, C_max] fp32 residual of the temporal transformer
     void *tm_a = nullptr, *tm_kv = nullptr, *tm_u = nullptr, *tm_g = nullptr, *tm_out = nullptr;
     // pipeline buffers
-    float *pre_x = nullptr, *depth_small = nullptr;
+    float *pre_x = nullptr, *depth_small = nullptr, *depth_post = nullptr;    // model output; post-processed copy (d2s_pipeline)
     void* post_ws = nullptr;
     uint64_t post_ws_bytes = 0;
     float* ema_state = nullptr;
@@ -906,6 +906,7 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
     e->host.clear();
     RC(dev_alloc(e, (void**)&e->pre_x, (size_t)B * 3 * h * w * 4));
     RC(dev_alloc(e, (void**)&e->depth_small, (size_t)B * h * w * 4));
+    RC(dev_alloc(e, (void**)&e->depth_post, (size_t)B * h * w * 4));
     e->post_ws_bytes = d2s_post_process_workspace(B, h, w);
     RC(dev_alloc(e, &e->post_ws, e->post_ws_bytes));
     RC(dev_alloc(e, (void**)&e->ema_state, (size_t)h * w * 4));
@@ -1022,18 +1023,19 @@ extern "C" int d2s_pipeline(d2s_engine* e, const uint8_t* frames, int batch, int
     hipStream_t st = (hipStream_t)stream;
     PROF(PC_PRE, 0, (double)batch * ((double)H * W * 3 + (double)e->h * e->w * 12), d2s_preprocess(frames, D2S_FMT_U8_HWC, batch, H, W, e->pre_x, e->h, e->w, stride, pre, stream));
     RC(forward(e, e->pre_x, e->depth_small, batch, st));
-    PROF(PC_POST, 0, 0, d2s_post_process(e->depth_small, batch, e->h, e->w, pp, e->post_ws, e->post_ws_bytes, stream));
+    // post-process out of place (raw model output -> depth_post): few frames take the one-launch form (post.hip)
+    PROF(PC_POST, 0, 0, d2s_post_process_to(e->depth_small, e->depth_post, batch, e->h, e->w, pp, e->post_ws, e->post_ws_bytes, stream));
     if (use_ema) {
-        RC(ema_batch(e->depth_small, e->ema_state, e->ema_init, batch, e->h * e->w, pp->ema_alpha, st));
+        RC(ema_batch(e->depth_post, e->ema_state, e->ema_init, batch, e->h * e->w, pp->ema_alpha, st));
         e->ema_init = 1;
     }
-    if (depth_full) RC(d2s_upsample_depth(e->depth_small, batch, e->h, e->w, depth_full, H, W, stream));
+    if (depth_full) RC(d2s_upsample_depth(e->depth_post, batch, e->h, e->w, depth_full, H, W, stream));
     {
         int oh = 0, ow = 0;
         RC(d2s_sbs_shape(H, W, sp, &oh, &ow));
         double obytes = (double)oh * ow * 3 * (out_fmt == D2S_FMT_U8_HWC ? 1 : 4);
         PROF(PC_WARP, 0, batch * ((double)H * W * 3 + (double)e->h * e->w * 4 + obytes),
-             d2s_make_sbs(frames, D2S_FMT_U8_HWC, e->depth_small, e->h, e->w, batch, H, W, sp, out, out_fmt, stream));
+             d2s_make_sbs(frames, D2S_FMT_U8_HWC, e->depth_post, e->h, e->w, batch, H, W, sp, out, out_fmt, stream));
     }
     return D2S_OK;
 }

@@ -151,6 +151,22 @@ def post_process_depth(depth: torch.Tensor, p: PipelineParams) -> torch.Tensor:
     return d
 
 
+def post_process_depth_to(depth: torch.Tensor, p: PipelineParams) -> torch.Tensor:
+    """The same through d2s_post_process_to (out of place: with few frames the one-launch form runs); the input is left untouched."""
+    _need_cuda(depth, "depth")
+    d = depth.to(torch.float32).contiguous()
+    out = torch.empty_like(d)
+    B = d.shape[0] if d.dim() == 3 else 1
+    h, w = d.shape[-2:]
+    lib = _lib.load()
+    nbytes = lib.d2s_post_process_workspace(B, h, w)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=d.device)
+    pp = post_params(p)
+    with _on(d.device) as st:
+        check(lib.d2s_post_process_to(_ptr(d), _ptr(out), B, h, w, C.byref(pp), _ptr(ws), nbytes, st), "d2s_post_process_to")
+    return out
+
+
 def ema_update(depth: torch.Tensor, state: torch.Tensor, initialised: bool, alpha: float) -> torch.Tensor:
     """A12 (reference depth.py:1865-1887); depth [h,w] is overwritten with the returned value."""
     h, w = depth.shape

@@ -203,6 +203,10 @@ int d2s_engine_calibrate(d2s_engine* e, const float* x, int batch, void* stream)
 int d2s_post_process(float* depth, int batch, int h, int w, const d2s_post_params* p,
                      void* workspace, uint64_t workspace_bytes, void* stream);
 uint64_t d2s_post_process_workspace(int batch, int h, int w);
+/* The same, out of place (depth_out may equal depth_in): with distinct buffers and few frames the normalise / gamma / foreground
+ * step and both blur passes run as one launch. */
+int d2s_post_process_to(const float* depth_in, float* depth_out, int batch, int h, int w, const d2s_post_params* p,
+                        void* workspace, uint64_t workspace_bytes, void* stream);
 
 /* A12: DepthStabilizer.__call__ (reference depth.py:1865-1887).  state: float [h,w] owned by the
  * caller; *initialised == 0 -> state = depth (first frame), else state = lerp(state, depth, 1-alpha);

@@ -204,6 +204,9 @@ def test_post_process_property(dev):
         got = ops.post_process_depth(_t(raw, dev), pp).cpu().numpy().reshape(h, w)
         want = O.post_process_depth(raw, fg, aa, metric=metric).reshape(h, w)
         assert np.abs(got - want).max() <= 2e-5, (h, w, fg, aa, metric, dist, np.abs(got - want).max())
+        # the out-of-place entry point (one launch for normalise + both blur passes): the same bits
+        got2 = ops.post_process_depth_to(_t(raw, dev), pp).cpu().numpy().reshape(h, w)
+        assert np.array_equal(got, got2), (h, w, fg, aa, metric, dist, np.abs(got - got2).max())
 
     check()
 
