@@ -418,6 +418,7 @@ int neck_rest(d2s_engine* e, int i, int B, hipStream_t st) {
     return D2S_OK;
 }
 
+// x: the pre-processed frames [B,3,h,w], or null when d2s_pipeline has already written the patch rows (and cls rows) itself
 int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) {
     const d2s_model_desc& d = e->d;
     const int D = d.hidden, N = e->N, P = e->P, M = B * N, Mp = B * P, prec = e->prec;
@@ -428,7 +429,7 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         return D2S_E_STATE;
     }
     // ---- embeddings (HF Dinov2Embeddings)
-    PROF(PC_ELT, 0, 0, launch_patchify(prec, x, e->patchA, B, e->h, e->w, d.patch, e->patch.Kpad, e->cls, e->pos, e->resid, N, D, st));
+    if (x) PROF(PC_ELT, 0, 0, launch_patchify(prec, x, e->patchA, B, e->h, e->w, d.patch, e->patch.Kpad, e->cls, e->pos, e->resid, N, D, st));
     {
         GemmEpi ep = rowsE(e->resid, OUT_F32, D, e->patch.bias);
         ep.rows_per_img = P; ep.img_rows = N; ep.row_off = 1;
@@ -821,7 +822,7 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
     RC(dev_alloc(e, &e->vt, (size_t)B * D * e->Npad * es, true));     // zero beyond N, never written there
     RC(dev_alloc(e, &e->attn, M * D * es));
     RC(dev_alloc(e, &e->mlp, M * d.mlp * es));
-    RC(dev_alloc(e, &e->patchA, Mp * e->patch.Kpad * es));
+    RC(dev_alloc(e, &e->patchA, Mp * e->patch.Kpad * es, true));        // (zero: the padding columns are never written again)
     const int gh = e->gh, gw = e->gw;
     e->fH[0] = gh * 4; e->fW[0] = gw * 4; e->fH[1] = gh * 2; e->fW[1] = gw * 2; e->fH[2] = gh; e->fW[2] = gw;
     e->fH[3] = (gh - 1) / 2 + 1; e->fW[3] = (gw - 1) / 2 + 1;
@@ -1021,8 +1022,14 @@ extern "C" int d2s_pipeline(d2s_engine* e, const uint8_t* frames, int batch, int
     if (stride < 1) stride = 1;
     D2S_ON_DEVICE(e->device);
     hipStream_t st = (hipStream_t)stream;
-    PROF(PC_PRE, 0, (double)batch * ((double)H * W * 3 + (double)e->h * e->w * 12), d2s_preprocess(frames, D2S_FMT_U8_HWC, batch, H, W, e->pre_x, e->h, e->w, stride, pre, stream));
-    RC(forward(e, e->pre_x, e->depth_small, batch, st));
+    {   // pre-process straight into the patch rows where that form exists (bilinear branch), else planes + the engine's patchify
+        const bool fused = !e->taps && preprocess_patches_ok(e->prec, D2S_FMT_U8_HWC, pre, H, W, e->h, e->w, e->d.patch, e->patch.Kpad);
+        if (fused) PROF(PC_PRE, 0, (double)batch * ((double)H * W * 3 + (double)e->h * e->w * 6),
+                        launch_preprocess_patches(e->prec, frames, D2S_FMT_U8_HWC, batch, H, W, stride, pre, e->patchA, e->h, e->w, e->d.patch, e->patch.Kpad,
+                                                  e->cls, e->pos, e->resid, e->N, e->d.hidden, st));
+        if (!fused) PROF(PC_PRE, 0, (double)batch * ((double)H * W * 3 + (double)e->h * e->w * 12), d2s_preprocess(frames, D2S_FMT_U8_HWC, batch, H, W, e->pre_x, e->h, e->w, stride, pre, stream));
+        RC(forward(e, fused ? nullptr : e->pre_x, e->depth_small, batch, st));
+    }
     // post-process out of place (raw model output -> depth_post): few frames take the one-launch form (post.hip)
     PROF(PC_POST, 0, 0, d2s_post_process_to(e->depth_small, e->depth_post, batch, e->h, e->w, pp, e->post_ws, e->post_ws_bytes, stream));
     if (use_ema) {

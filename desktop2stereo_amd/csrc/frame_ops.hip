@@ -3,6 +3,7 @@
 //   upsample_depth  A13    (reference depth.py:1999-2004)
 //   stereo_warp     A14    (reference depth.py:2122-2184), with A13 fused when depth comes at model res
 #include "common.h"
+#include <algorithm>
 
 namespace d2s {
 
@@ -62,6 +63,47 @@ preprocess_kernel(const void* __restrict__ frames, int B, int H, int W, int stri
         float v = ty.w0 * top + ty.w1 * bot;
         v = v / 255.0f;
         o[ch * plane] = (v - mean[ch]) / istd[ch];
+    }
+}
+
+// The same values written straight into the patch-embedding GEMM's A matrix (Conv2d(3 -> D, k = s = p) as im2col rows:
+// A[(b, py, px)][c p^2 + i p + j] = x[b][c][py p + i][px p + j], HF Dinov2PatchEmbeddings) in the engine's operand type, plus the
+// cls-token rows of the residual stream: d2s_pipeline's pre-process and the engine's patchify in one launch (the [B,3,h,w] float
+// planes in between are never materialised).  Columns >= 3 p^2 of A are zero from allocation and never written.
+template <int FMT, typename T>
+__global__ void __launch_bounds__(256)
+preprocess_patch_kernel(const void* __restrict__ frames, int B, int H, int W, int stride, T* __restrict__ A, int h, int w, int p, int Kp,
+                        float sy, float sx, float m0, float m1, float m2, float is0, float is1, float is2,
+                        const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ resid, int N, int D) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cls && idx < (long)B * D) { int b = (int)(idx / D), d = (int)(idx % D); resid[(long)b * N * D + d] = cls[d] + pos[d]; }
+    long total = (long)B * h * w;
+    if (idx >= total) return;
+    int ox = (int)(idx % w);
+    int oy = (int)((idx / w) % h);
+    int b = (int)(idx / ((long)w * h));
+    int Hs = (H + stride - 1) / stride, Ws = (W + stride - 1) / stride;
+    Tap ty = linear_tap(oy, sy, Hs, false);
+    Tap tx = linear_tap(ox, sx, Ws, false);
+    long fo = (long)b * H * W;
+    float a[3], c[3], d[3], e[3];
+    load_px<FMT>(frames, fo, H, W, ty.i0 * stride, tx.i0 * stride, a[0], a[1], a[2]);
+    load_px<FMT>(frames, fo, H, W, ty.i0 * stride, tx.i1 * stride, c[0], c[1], c[2]);
+    load_px<FMT>(frames, fo, H, W, ty.i1 * stride, tx.i0 * stride, d[0], d[1], d[2]);
+    load_px<FMT>(frames, fo, H, W, ty.i1 * stride, tx.i1 * stride, e[0], e[1], e[2]);
+    const float mean[3] = {m0, m1, m2};
+    const float istd[3] = {is0, is1, is2};
+    const int gw = w / p, gh = h / p;
+    const int py = oy / p, px = ox / p;
+    T* o = A + ((long)(b * gh + py) * gw + px) * Kp + (oy - py * p) * p + (ox - px * p);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float top = tx.w0 * a[ch] + tx.w1 * c[ch];
+        float bot = tx.w0 * d[ch] + tx.w1 * e[ch];
+        float v = ty.w0 * top + ty.w1 * bot;
+        v = v / 255.0f;
+        v = (v - mean[ch]) / istd[ch];
+        if constexpr (sizeof(T) == 2) o[ch * p * p] = f2bf(v); else o[ch * p * p] = v;
     }
 }
 
@@ -862,6 +904,35 @@ stereo_warp_fast_halftab(const uint8_t* __restrict__ rgb, const float* __restric
 }  // namespace d2s
 
 using namespace d2s;
+
+// d2s_pipeline's pre-process + patchify in one launch (bilinear branch, uint8 HWC frames, bf16 / fp32 patch rows); D2S_E_UNSUPPORTED =
+// not this case, nothing launched (the caller runs d2s_preprocess + launch_patchify)
+namespace d2s {
+bool preprocess_patches_ok(int prec, int fmt, const d2s_pre_params* pre, int H, int W, int h, int w, int p, int Kp) {
+    static EnvInt off{"D2S_NO_PREPATCH", 0};
+    const int resample = pre ? pre->resample : D2S_RESAMPLE_BILINEAR;
+    return !off.get() && fmt == D2S_FMT_U8_HWC && resample == D2S_RESAMPLE_BILINEAR && !(h == H && w == W) && h % p == 0 && w % p == 0 && 3 * p * p <= Kp &&
+           (prec == D2S_PREC_BF16 || prec == D2S_PREC_FP32);
+}
+int launch_preprocess_patches(int prec, const void* frames, int fmt, int batch, int H, int W, int decim_stride, const d2s_pre_params* pre,
+                              void* A, int h, int w, int p, int Kp, const float* cls, const float* pos, float* resid, int N, int D, hipStream_t st) {
+    static const d2s_pre_params dflt = {{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}, D2S_RESAMPLE_BILINEAR};
+    if (!pre) pre = &dflt;
+    if (!preprocess_patches_ok(prec, fmt, pre, H, W, h, w, p, Kp)) return D2S_E_UNSUPPORTED;
+    const int Hs = (H + decim_stride - 1) / decim_stride, Ws = (W + decim_stride - 1) / decim_stride;
+    const float sy = linear_scale(Hs, h, false), sx = linear_scale(Ws, w, false);
+    const long total = std::max((long)batch * h * w, (long)batch * D);
+    const dim3 grid(cdiv(total, 256)), block(256);
+    if (prec == D2S_PREC_BF16)
+        hipLaunchKernelGGL((preprocess_patch_kernel<D2S_FMT_U8_HWC, bf16_t>), grid, block, 0, st, frames, batch, H, W, decim_stride, (bf16_t*)A, h, w, p, Kp,
+                           sy, sx, pre->mean[0], pre->mean[1], pre->mean[2], pre->std[0], pre->std[1], pre->std[2], cls, pos, resid, N, D);
+    else
+        hipLaunchKernelGGL((preprocess_patch_kernel<D2S_FMT_U8_HWC, float>), grid, block, 0, st, frames, batch, H, W, decim_stride, (float*)A, h, w, p, Kp,
+                           sy, sx, pre->mean[0], pre->mean[1], pre->mean[2], pre->std[0], pre->std[1], pre->std[2], cls, pos, resid, N, D);
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+}  // namespace d2s
 
 // ================================================================================================
 // C-ABI

@@ -6,6 +6,10 @@ namespace d2s {
 
 int launch_patchify(int prec, const float* x, void* A, int B, int h, int w, int p, int Kp,
                     const float* cls, const float* pos, float* resid, int N, int D, hipStream_t st);   // also writes the cls rows
+// d2s_pipeline: pre-process + patchify in one launch (frame_ops.hip); D2S_E_UNSUPPORTED = not eligible, nothing launched
+bool preprocess_patches_ok(int prec, int fmt, const d2s_pre_params* pre, int H, int W, int h, int w, int p, int Kp);
+int launch_preprocess_patches(int prec, const void* frames, int fmt, int batch, int H, int W, int decim_stride, const d2s_pre_params* pre,
+                              void* A, int h, int w, int p, int Kp, const float* cls, const float* pos, float* resid, int N, int D, hipStream_t st);
 int launch_cls_rows(const float* cls, const float* pos, float* resid, int B, int N, int D, hipStream_t st);
 int launch_layernorm(int prec, const float* x, const float* g, const float* b, void* out, int rows_out, int D, float eps,
                      int rows_per_img, int img_rows, int row_off, hipStream_t st, float fp8_qscale = 0.f,   // > 0: e4m3 output

@@ -651,3 +651,38 @@ def test_pipeline_end_to_end(dev):
         sbs_ref = orc.make_sbs(frames[b], depth[b], ipd_uv=0.064, depth_ratio=4.0, display_mode="Half-SBS", fill_16_9=True)
         assert np.abs(out[b].astype(int) - O.to_u8(sbs_ref).astype(int)).max() <= 1
     eng.close()
+
+
+def test_pipeline_fused_launches_equal_separate(dev, monkeypatch):
+    """d2s_pipeline folds launches where an equivalent one-launch form exists: pre-process + patchify (D2S_NO_PREPATCH=1 separates
+    them), normalise / gamma + both blur passes at batch 1-2 (D2S_POST_FUSE_MAXB=0).  Same arithmetic, same order: bit-identical
+    frames and depth, on the bf16 and the fp32 engine."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS, PipelineParams, engine_shape
+    from desktop2stereo_amd.weights import make_weights
+    cfg = MODELS["vits"]
+    wts = make_weights(cfg, 0)
+    H, W, res = 1080, 1920, 336
+    h, w, _ = engine_shape(H, W, res)
+    p = PipelineParams(depth_resolution=res)
+    sp = ops.sbs_params(0.064, 4.0, 0.0, "Full-SBS", False)
+    frames = _t(np.stack([synth.structured_frame(H, W, 5), synth.structured_frame(H, W, 6)]), dev)
+    try:
+        for prec in ("bf16", "fp32"):
+            res_ = {}
+            for name, env in (("fused", {}), ("separate", {"D2S_NO_PREPATCH": "1", "D2S_POST_FUSE_MAXB": "0"})):
+                for k in ("D2S_NO_PREPATCH", "D2S_POST_FUSE_MAXB"):
+                    monkeypatch.delenv(k, raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                ops.reload_env()
+                eng = ops.Engine(cfg, wts, h, w, 2, prec)
+                out, depth = eng.pipeline(frames, p, sp, use_ema=False, want_depth=True)
+                res_[name] = (out.cpu().numpy(), depth.cpu().numpy())
+                eng.close()
+            assert np.array_equal(res_["fused"][0], res_["separate"][0]), prec
+            assert np.array_equal(res_["fused"][1], res_["separate"][1]), prec
+    finally:
+        for k in ("D2S_NO_PREPATCH", "D2S_POST_FUSE_MAXB"):
+            monkeypatch.delenv(k, raising=False)
+        ops.reload_env()
