@@ -226,8 +226,9 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
     constexpr int CPP = 8, PST = 10, TH = 16, TW = 16, HWD = TW + 2, HPX = (TH + 2) * HWD, HALO = HPX * PST;
     constexpr int NCH = HPX * CPP, NLD = (NCH + 511) / 512;       // halo chunks, loads per thread (6)
     constexpr int SR = 13, SCH = SR * SR * CPP, NSL = (SCH + 511) / 512;   // UPS: source window (pixels per side), its chunks, loads per thread (3)
-    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * HALO + (UPS ? 2 * SCH : 0)];
-    D2S_POISON_LDS(lds, 2 * HALO + (UPS ? 2 * SCH : 0))
+    constexpr int SPS = 2 * CPP + 1;                         // UPS: staging stride of a source pixel in 16-byte units (odd: the taps of neighbouring pixels spread over the banks)
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * HALO + (UPS ? SR * SR * SPS : 0)];
+    D2S_POISON_LDS(lds, 2 * HALO + (UPS ? SR * SR * SPS : 0))
     f32x4* const stg = (f32x4*)(lds + 2 * HALO);            // UPS: the source window as floats (unpacked once, tapped ~8 times): [pixel][64]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -305,8 +306,8 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
                 const int idx = tid + k * 512;
                 if (idx < SCH) {
                     const u32x4 v = hr[k];
-                    stg[2 * idx] = (f32x4){__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
-                    stg[2 * idx + 1] = (f32x4){__uint_as_float(v[2] << 16), __uint_as_float(v[2] & 0xffff0000u), __uint_as_float(v[3] << 16), __uint_as_float(v[3] & 0xffff0000u)};
+                    stg[(idx >> 3) * SPS + 2 * (idx & 7)] = (f32x4){__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+                    stg[(idx >> 3) * SPS + 2 * (idx & 7) + 1] = (f32x4){__uint_as_float(v[2] << 16), __uint_as_float(v[2] & 0xffff0000u), __uint_as_float(v[3] << 16), __uint_as_float(v[3] & 0xffff0000u)};
                 }
             }
             __syncthreads();
@@ -324,8 +325,8 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
                     if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
                         const Tap ty = linear_tap(iy, a.usy, a.Hs, true), tx = linear_tap(ix, a.usx, a.Ws, true);
                         const int r0 = (ty.i0 - rs0) * SR, r1 = (ty.i1 - rs0) * SR, c0 = tx.i0 - cs0, c1 = tx.i1 - cs0;
-                        const f32x4* q00 = stg + ((r0 + c0) * CPP + c) * 2; const f32x4* q01 = stg + ((r0 + c1) * CPP + c) * 2;
-                        const f32x4* q10 = stg + ((r1 + c0) * CPP + c) * 2; const f32x4* q11 = stg + ((r1 + c1) * CPP + c) * 2;
+                        const f32x4* q00 = stg + (r0 + c0) * SPS + 2 * c; const f32x4* q01 = stg + (r0 + c1) * SPS + 2 * c;
+                        const f32x4* q10 = stg + (r1 + c0) * SPS + 2 * c; const f32x4* q11 = stg + (r1 + c1) * SPS + 2 * c;
                         typedef float f2_ __attribute__((ext_vector_type(2)));
                         const f2_ w0x = {tx.w0, tx.w0}, w1x = {tx.w1, tx.w1}, w0y = {ty.w0, ty.w0}, w1y = {ty.w1, ty.w1};
 #pragma unroll
