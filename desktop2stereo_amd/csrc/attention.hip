@@ -627,9 +627,10 @@ int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B
     // prescaled: the q columns already carry 64^-0.5 * log2(e) (folded into W_q / b_q, engine.hip): scores are log2-domain as they are
     const float scale_log2e = prescaled ? 1.0f : ATTN_SCALE_LOG2E;
     if (fp8_qscale > 0.f && prec != D2S_PREC_BF16) { set_error("attention: e4m3 output needs bf16 inputs"); return D2S_E_UNSUPPORTED; }
-    // batched bf16: the 32 x 32 kernel once its 128-row blocks fill the chip (D2S_ATTN32=0: the 16-row kernel everywhere)
+    static EnvInt attn32_min{"D2S_ATTN32_MIN", 168};        // (from batch 2 at N = 778: +0.3 % at 2, +1.5 % at 4, +4.5 % at 6; batch 1 -6 %)
+    // batched bf16: the 32 x 32 kernel from ~170 blocks of 128 rows (D2S_ATTN32=0: the 16-row kernel everywhere)
     // (read per call, only for launches in that regime: the parity test flips it inside one process)
-    if (prescaled && prec == D2S_PREC_BF16 && (long)cdiv(N, 128) * heads * B >= 512 && !(getenv("D2S_ATTN32") && atoi(getenv("D2S_ATTN32")) == 0)) {
+    if (prescaled && prec == D2S_PREC_BF16 && (long)cdiv(N, 128) * heads * B >= attn32_min.get() && !(getenv("D2S_ATTN32") && atoi(getenv("D2S_ATTN32")) == 0)) {
         if ((long)N * 3 * heads * 64 * 2 >= (1L << 31)) { set_error("attention: frame too large for 32-bit buffer offsets"); return D2S_E_UNSUPPORTED; }
         const dim3 grid(attn_grid(cdiv(N, 128), heads * B));
         if (fp8_qscale > 0.f)
