@@ -450,9 +450,12 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     // (the LN kernels' launch floor is amortised there and the wider epilogues are not); from ~9 frames the encoder linears
     // switch to the 256 x 256 ping-pong kernel (gemm_pp.hip: +12 % frames/s at 16, +13 % at 32), which takes plain
     // LayerNorm-ed operands -> folded up to 8 frames
-    static const int lnf_maxb = getenv("D2S_LNF_MAXB") ? atoi(getenv("D2S_LNF_MAXB")) : 8;       // tuning aid
+    // Re-measured at the end of round 3 (the ping-pong kernel now takes launches from 100 tiles, i.e. QKV / FC1 from 4 frames): folding
+    // keeps those linears on the small-tile kernels, and from 4 frames that costs more than the LayerNorm launches:
+    // 1 670 -> 1 758 frames/s at batch 4, 1 815 -> 2 000 at 5, 2 052 -> 2 275 at 8 with the limit at 3 (same box).
+    static const int lnf_maxb = getenv("D2S_LNF_MAXB") ? atoi(getenv("D2S_LNF_MAXB")) : 3;       // tuning aid
     static const bool no_lnf = getenv("D2S_NO_LNFUSE") && atoi(getenv("D2S_NO_LNFUSE")) != 0;
-    const bool lnf = ((e->lnf && !e->fp8) || (f8 && !no_lnf)) && !e->calib && (prec == D2S_PREC_BF16 || x3) && B <= lnf_maxb;
+    const bool lnf = ((e->lnf && !e->fp8) || (f8 && !no_lnf)) && !e->calib && (prec == D2S_PREC_BF16 || x3) && B <= (x3 ? 8 : lnf_maxb);   // (bf16x3: no ping-pong kernel to give way to)
     int ln_slots = 0;
     // batch 1, bf16: the four tap LayerNorms fold into the reassemble projections the same way (the statistics and the raw
     // residual of a tap layer are still in lnbuf / lnstats when its projection runs; the main stream waits for that launch

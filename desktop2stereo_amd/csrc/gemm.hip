@@ -780,7 +780,7 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
         // batched plain linears: the 256 x 256 ping-pong kernel (gemm_pp.hip) once the launch has enough tiles to fill the chip
         // measured (tools/pp_check.py, ViT-B shapes): from ~140 tiles of 256 x 256 the ping-pong kernel wins every encoder
         // linear (batch 16: +14..+30 %, batch 32: +9..+48 %); at 75 tiles (batch 8, N = 768) it loses.  D2S_GEMM_PP=0: off
-        static const int pp_min_tiles = getenv("D2S_GEMM_PP") ? atoi(getenv("D2S_GEMM_PP")) : 140;
+        static const int pp_min_tiles = getenv("D2S_GEMM_PP") ? atoi(getenv("D2S_GEMM_PP")) : 100;       // (100 vs 140: +5 % at batch 12, proj / FC2 there)
         const int prec = std::is_same<T, bf16_t>::value ? D2S_PREC_BF16 : D2S_PREC_FP8_OPERANDS;
         if (tile == 0 && pp_min_tiles > 0 && (long)cdiv(M, 256) * cdiv(N, 256) >= pp_min_tiles && pp_supported(prec, a, M, N, K, Kpad, e))
             return launch_gemm_pp(prec, a, W, M, N, K, Kpad, e, st);
