@@ -35,7 +35,7 @@ RESAMPLE = {"bilinear": 0, "bicubic_aa": 1}      # D2S_RESAMPLE_*: _resize_patch
 
 
 class PreParams(C.Structure):
-    _fields_ = [("mean", C.c_float * 3), ("std", C.c_float * 3), ("resample", C.c_int32)]
+    _fields_ = [("mean", C.c_float * 3), ("std", C.c_float * 3), ("resample", C.c_int32), ("square", C.c_int32)]
 
 
 class SbsParams(C.Structure):
@@ -67,6 +67,9 @@ SYMBOLS = {
                                  C.POINTER(PreParams), _P]),
     "d2s_process_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "d2s_process": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "d2s_process_rgb": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "d2s_process_area_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "d2s_process_area": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "d2s_overlay_text": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_char_p, _P]),
     "d2s_model_forward": (C.c_int, [_P, _P, _P, C.c_int, _P]),
     "d2s_engine_calibrate": (C.c_int, [_P, _P, C.c_int, _P]),

@@ -95,6 +95,14 @@ class PipelineParams:
     #                   the path BASELINE.json's parity bar names (default);
     #   "bicubic_aa" -- the IS_CUDA branch (depth.py:698-699; true on a ROCm device): bicubic + antialias from the full frame
     resample: str = "bilinear"
+    # reference CAPTURE_MODE (utils.py; settings "Capture Mode"): "Window" makes get_patch_size() return None (depth.py:531-538), so
+    # predict_depth takes the fixed-square branch -- plain bilinear of the full frame to depth_resolution x depth_resolution
+    # (depth.py:1937-1946) -- instead of the aspect-preserving patch-aligned resize ("Monitor")
+    capture_mode: str = "Monitor"
+
+    @property
+    def square_input(self) -> bool:
+        return self.capture_mode == "Window"
 
     def asdict(self):
         return asdict(self)
@@ -107,14 +115,21 @@ def nearest_multiple(x: int, p: int) -> int:
     return up if abs(up - x) <= abs(x - down) else down
 
 
-def engine_shape(h: int, w: int, target: int, patch: int = PATCH):
+def engine_shape(h: int, w: int, target: int, patch: int = PATCH, square: bool = False):
     """Model-input size and the CPU-branch decimation stride for an h x w frame.
+
+    square=True: the fixed-square branch of predict_depth (get_patch_size() is None, reference
+    depth.py:1937-1946): target x target from the full frame, no decimation.
 
     Restates the integer logic of ``_resize_patch_aligned_t`` (reference
     depth.py:676-706): longest side -> target, each dim to the nearest patch
     multiple (ties up); CPU branch pre-decimates by ``longest // (2*target)``.
     Returns (new_h, new_w, stride) with stride >= 1.
     """
+    if square:
+        if target % patch:
+            raise ValueError(f"fixed-square input: Depth Resolution {target} is not a multiple of the patch size {patch}")
+        return target, target, 1
     longest = max(h, w)
     scale = target / float(longest) if longest != target else 1.0
     sh = max(1, int(round(h * scale)))

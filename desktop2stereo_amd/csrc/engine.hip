@@ -1013,16 +1013,22 @@ extern "C" int d2s_pipeline(d2s_engine* e, const uint8_t* frames, int batch, int
     // model-input shape of this frame size must be the engine's (reference: fixed at first frame, depth.py:1951-1953)
     D2S_REQUIRE(H > 0 && W > 0 && depth_resolution > 0, "bad frame shape");
     int longest = H > W ? H : W;
-    {   // _resize_patch_aligned_t integer logic (reference depth.py:677-689); Python round() = half-to-even
+    int stride = 1;
+    if (pre && pre->square) {
+        // fixed-square branch (get_patch_size() is None: CAPTURE_MODE == "Window", reference depth.py:531-538, 1937-1946)
+        if (e->h != depth_resolution || e->w != depth_resolution) {
+            set_error("d2s_pipeline: the fixed-square branch needs a depth_resolution x depth_resolution engine"); return D2S_E_INVALID;
+        }
+    } else {   // _resize_patch_aligned_t integer logic (reference depth.py:677-689); Python round() = half-to-even
         double scale = longest != depth_resolution ? (double)depth_resolution / (double)longest : 1.0;
         int sh = std::max(1, (int)nearbyint(H * scale)), sw = std::max(1, (int)nearbyint(W * scale));
         auto nm = [&](int x) { int p = e->d.patch, down = (x / p) * p, up = down + p; return (std::abs(up - x) <= std::abs(x - down)) ? up : down; };
         if (std::max(1, nm(sh)) != e->h || std::max(1, nm(sw)) != e->w) {
             set_error("d2s_pipeline: frame maps to a model-input shape different from the engine's"); return D2S_E_INVALID;
         }
+        stride = longest / (depth_resolution * 2);
+        if (stride < 1) stride = 1;
     }
-    int stride = longest / (depth_resolution * 2);
-    if (stride < 1) stride = 1;
     D2S_ON_DEVICE(e->device);
     hipStream_t st = (hipStream_t)stream;
     {   // pre-process straight into the patch rows where that form exists (bilinear branch), else planes + the engine's patchify

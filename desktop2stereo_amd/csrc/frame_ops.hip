@@ -910,15 +910,16 @@ using namespace d2s;
 namespace d2s {
 bool preprocess_patches_ok(int prec, int fmt, const d2s_pre_params* pre, int H, int W, int h, int w, int p, int Kp) {
     static EnvInt off{"D2S_NO_PREPATCH", 0};
-    const int resample = pre ? pre->resample : D2S_RESAMPLE_BILINEAR;
+    const int resample = pre && !pre->square ? pre->resample : D2S_RESAMPLE_BILINEAR;     // (the fixed-square branch is always plain bilinear)
     return !off.get() && fmt == D2S_FMT_U8_HWC && resample == D2S_RESAMPLE_BILINEAR && !(h == H && w == W) && h % p == 0 && w % p == 0 && 3 * p * p <= Kp &&
            (prec == D2S_PREC_BF16 || prec == D2S_PREC_FP32);
 }
 int launch_preprocess_patches(int prec, const void* frames, int fmt, int batch, int H, int W, int decim_stride, const d2s_pre_params* pre,
                               void* A, int h, int w, int p, int Kp, const float* cls, const float* pos, float* resid, int N, int D, hipStream_t st) {
-    static const d2s_pre_params dflt = {{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}, D2S_RESAMPLE_BILINEAR};
+    static const d2s_pre_params dflt = {{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}, D2S_RESAMPLE_BILINEAR, 0};
     if (!pre) pre = &dflt;
     if (!preprocess_patches_ok(prec, fmt, pre, H, W, h, w, p, Kp)) return D2S_E_UNSUPPORTED;
+    if (pre->square) decim_stride = 1;
     const int Hs = (H + decim_stride - 1) / decim_stride, Ws = (W + decim_stride - 1) / decim_stride;
     const float sy = linear_scale(Hs, h, false), sx = linear_scale(Ws, w, false);
     const long total = std::max((long)batch * h * w, (long)batch * D);
@@ -940,8 +941,12 @@ int launch_preprocess_patches(int prec, const void* frames, int fmt, int batch, 
 extern "C" int d2s_preprocess(const void* frames, int fmt, int batch, int H, int W, float* out, int h, int w,
                               int decim_stride, const d2s_pre_params* pre, void* stream) {
     D2S_REQUIRE(frames && out, "null pointer");
-    static const d2s_pre_params dflt = {{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}, D2S_RESAMPLE_BILINEAR};   // depth.py:1798-1799
+    static const d2s_pre_params dflt = {{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}, D2S_RESAMPLE_BILINEAR, 0};   // depth.py:1798-1799
     if (!pre) pre = &dflt;
+    d2s_pre_params sq;
+    if (pre->square) {                                           // fixed-square branch (depth.py:1937-1946): plain bilinear of the full frame
+        sq = *pre; sq.resample = D2S_RESAMPLE_BILINEAR; pre = &sq; decim_stride = 1;
+    }
     const float* mean = pre->mean;
     const float* stdv = pre->std;
     D2S_REQUIRE(batch > 0 && H > 0 && W > 0 && h > 0 && w > 0 && decim_stride >= 1, "bad shape");

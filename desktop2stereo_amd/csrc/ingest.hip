@@ -7,6 +7,8 @@
 //        reference depth.py:641-658 (glyph table), 2061-2103
 #include "common.h"
 #include <string.h>
+#include <cmath>
+#include <cstdlib>
 
 namespace d2s {
 
@@ -62,6 +64,107 @@ process_kernel(const uint8_t* __restrict__ src, int nch, int H0, int W0, float* 
     }
     long o = (long)y * w + x;
     out[o] = r; out[plane + o] = g; out[2 * plane + o] = b;
+}
+
+// A1, the tensor branch of the NON-CUDA process() (reference depth.py:576-601): the capture tensor "is already RGB" -- first three
+// channels, no flip -- and the down-scale is plain bilinear (align_corners=False, antialias=False).  FMT: D2S_FMT_U8_HWC (nch
+// interleaved channels), D2S_FMT_U8_CHW / D2S_FMT_F32_CHW (planes).  One thread = one output pixel.  Same product order as ATen
+// (and preprocess_kernel): wy0*(wx0*a + wx1*b) + wy1*(wx0*c + wx1*d).
+template <int FMT>
+__global__ void __launch_bounds__(256)
+process_rgb_kernel(const void* __restrict__ src, int nch, int H0, int W0, float* __restrict__ out, int h, int w, float sy, float sx) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const Tap ty = linear_tap(y, sy, H0, false), tx = linear_tap(x, sx, W0, false);
+    const long plane = (long)h * w, splane = (long)H0 * W0;
+    auto px = [&](int yy, int xx, int c) -> float {
+        if constexpr (FMT == D2S_FMT_U8_HWC) return (float)((const uint8_t*)src)[((long)yy * W0 + xx) * nch + c];
+        else if constexpr (FMT == D2S_FMT_U8_CHW) return (float)((const uint8_t*)src)[c * splane + (long)yy * W0 + xx];
+        else return ((const float*)src)[c * splane + (long)yy * W0 + xx];
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float top = tx.w0 * px(ty.i0, tx.i0, c) + tx.w1 * px(ty.i0, tx.i1, c);
+        const float bot = tx.w0 * px(ty.i1, tx.i0, c) + tx.w1 * px(ty.i1, tx.i1, c);
+        out[c * plane + (long)y * w + x] = ty.w0 * top + ty.w1 * bot;
+    }
+}
+
+// A1, the numpy branch of the NON-CUDA process() (reference depth.py:603-629): cv2.cvtColor(BGR(A) -> RGB) +
+// cv2.resize(INTER_AREA) of a DOWN-scale, uint8 HWC in and out.  OpenCV's published algorithm (modules/imgproc/src/resize.cpp;
+// third party -- opencv-python 4.12.0.88, requirements.txt:4 -- and not installed in this image: parity unpinned, see oracle
+// resize_area_u8):  integer scale factors -> ResizeAreaFast (2 x 2: (a+b+c+d+2) >> 2; else saturate_cast<uchar>(int sum * (1.f / area)));
+// otherwise ResizeArea_<uchar, float>: per source row the horizontal cells of a destination pixel accumulate in table order
+// (buf += S * alpha, float), the rows then accumulate sum (+)= beta * buf, and saturate_cast<uchar>(sum) (round-half-even) ends the
+// pixel.  The tables (computeResizeAreaTab: first partial cell, whole cells, last partial cell; weights formed in double, stored as
+// float) are evaluated on the fly per thread -- one thread = one output pixel, all three channels.
+struct AreaCells { int s0, n; float a_first, a_mid, a_last; bool has_first, has_last; };
+__device__ __forceinline__ AreaCells area_cells(int d, double scale, int ssize) {
+    AreaCells c;
+    const double fsx1 = d * scale, fsx2 = fsx1 + scale;
+    const double cell = fmin(scale, (double)ssize - fsx1);
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+    sx1 = sx1 < sx2 ? sx1 : sx2;
+    c.has_first = (double)sx1 - fsx1 > 1e-3;
+    c.a_first = (float)(((double)sx1 - fsx1) / cell);
+    c.a_mid = (float)(1.0 / cell);
+    c.has_last = fsx2 - (double)sx2 > 1e-3;
+    c.a_last = (float)(fmin(fmin(fsx2 - (double)sx2, 1.0), cell) / cell);
+    c.s0 = sx1 - (c.has_first ? 1 : 0);
+    c.n = (sx2 - sx1) + (c.has_first ? 1 : 0) + (c.has_last ? 1 : 0);
+    return c;
+}
+__device__ __forceinline__ float area_alpha(const AreaCells& c, int k) {
+    if (k == 0 && c.has_first) return c.a_first;
+    if (k == c.n - 1 && c.has_last) return c.a_last;
+    return c.a_mid;
+}
+__device__ __forceinline__ uint8_t sat_u8_rne(float v) {                  // saturate_cast<uchar>(float): cvRound (half to even), saturate
+    float r = rintf(v);
+    return (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+}
+template <int FAST>     // 0: general tables; 1: integer factors; 2: 2 x 2
+__global__ void __launch_bounds__(256)
+process_area_kernel(const uint8_t* __restrict__ src, int nch, int H0, int W0, uint8_t* __restrict__ out, int h, int w,
+                    double sy, double sx, int iy, int ix) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    uint8_t* o = out + ((long)y * w + x) * 3;
+    if constexpr (FAST != 0) {
+        int sum[3] = {0, 0, 0};
+        for (int jy = 0; jy < iy; ++jy) {
+            const uint8_t* row = src + ((long)(y * iy + jy) * W0 + (long)x * ix) * nch;
+            for (int jx = 0; jx < ix; ++jx) { sum[0] += row[jx * nch + 2]; sum[1] += row[jx * nch + 1]; sum[2] += row[jx * nch + 0]; }   // BGR -> RGB
+        }
+        if constexpr (FAST == 2) { o[0] = (uint8_t)((sum[0] + 2) >> 2); o[1] = (uint8_t)((sum[1] + 2) >> 2); o[2] = (uint8_t)((sum[2] + 2) >> 2); }
+        else { const float sc = 1.f / (float)(ix * iy); o[0] = sat_u8_rne((float)sum[0] * sc); o[1] = sat_u8_rne((float)sum[1] * sc); o[2] = sat_u8_rne((float)sum[2] * sc); }
+    } else {
+        const AreaCells cy = area_cells(y, sy, H0), cx = area_cells(x, sx, W0);
+        float sum[3] = {0.f, 0.f, 0.f};
+        for (int jy = 0; jy < cy.n; ++jy) {
+            const uint8_t* row = src + ((long)(cy.s0 + jy) * W0 + cx.s0) * nch;
+            float buf[3] = {0.f, 0.f, 0.f};
+            for (int jx = 0; jx < cx.n; ++jx) {
+                const float a = area_alpha(cx, jx);
+                buf[0] = buf[0] + (float)row[jx * nch + 2] * a;
+                buf[1] = buf[1] + (float)row[jx * nch + 1] * a;
+                buf[2] = buf[2] + (float)row[jx * nch + 0] * a;
+            }
+            const float b = area_alpha(cy, jy);
+            if (jy == 0) { sum[0] = b * buf[0]; sum[1] = b * buf[1]; sum[2] = b * buf[2]; }
+            else { sum[0] += b * buf[0]; sum[1] += b * buf[1]; sum[2] += b * buf[2]; }
+        }
+        o[0] = sat_u8_rne(sum[0]); o[1] = sat_u8_rne(sum[1]); o[2] = sat_u8_rne(sum[2]);
+    }
+}
+// no resize: cv2.cvtColor only
+__global__ void __launch_bounds__(256)
+process_swizzle_u8_kernel(const uint8_t* __restrict__ src, int nch, long npix, uint8_t* __restrict__ out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const uint8_t* p = src + i * nch;
+    out[i * 3 + 0] = p[2]; out[i * 3 + 1] = p[1]; out[i * 3 + 2] = p[0];
 }
 
 constexpr int MAX_TEXT = 32;
@@ -124,6 +227,56 @@ extern "C" int d2s_process(const uint8_t* bgr, int channels, int H0, int W0, int
     else        // area_pixel_compute_scale(align_corners=False, no scale_factor): in / out
         hipLaunchKernelGGL(process_kernel<true>, grid, block, 0, st, bgr, channels, H0, W0, out, h, w,
                            (float)H0 / (float)h, (float)W0 / (float)w);
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+extern "C" int d2s_process_rgb(const void* rgb, int fmt, int channels, int H0, int W0, int target_height, float* out, void* stream) {
+    D2S_REQUIRE(rgb && out, "null pointer");
+    D2S_REQUIRE(channels >= 3 && channels <= 4, "process(): tensor frame must have 3 or 4 channels");
+    D2S_REQUIRE(fmt == D2S_FMT_U8_HWC || fmt == D2S_FMT_U8_CHW || fmt == D2S_FMT_F32_CHW, "process(): unsupported tensor layout");
+    int h, w;
+    int rc = d2s_process_shape(H0, W0, target_height, &h, &w);          // same even-size rule (depth.py:591-593)
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(cdiv(w, 256), h), block(256);
+    const float sy = linear_scale(H0, h, false), sx = linear_scale(W0, w, false);
+    if (fmt == D2S_FMT_U8_HWC) hipLaunchKernelGGL(process_rgb_kernel<D2S_FMT_U8_HWC>, grid, block, 0, st, rgb, channels, H0, W0, out, h, w, sy, sx);
+    else if (fmt == D2S_FMT_U8_CHW) hipLaunchKernelGGL(process_rgb_kernel<D2S_FMT_U8_CHW>, grid, block, 0, st, rgb, channels, H0, W0, out, h, w, sy, sx);
+    else hipLaunchKernelGGL(process_rgb_kernel<D2S_FMT_F32_CHW>, grid, block, 0, st, rgb, channels, H0, W0, out, h, w, sy, sx);
+    D2S_CHECK_LAUNCH();
+    return D2S_OK;
+}
+
+extern "C" int d2s_process_area_shape(int H0, int W0, int target_height, int* out_h, int* out_w) {
+    D2S_REQUIRE(out_h && out_w && H0 > 0 && W0 > 0 && target_height > 0, "bad argument");
+    if (target_height >= H0) { *out_h = H0; *out_w = W0; return D2S_OK; }           // depth.py:621-622
+    *out_h = target_height;                                                           // no even rounding on this branch
+    *out_w = (int)((double)W0 * (double)target_height / (double)H0);                  // depth.py:612
+    D2S_REQUIRE(*out_w > 0, "target height too small");
+    return D2S_OK;
+}
+
+extern "C" int d2s_process_area(const uint8_t* bgr, int channels, int H0, int W0, int target_height, uint8_t* out, void* stream) {
+    D2S_REQUIRE(bgr && out, "null pointer");
+    D2S_REQUIRE(channels == 3 || channels == 4, "process(): frame must be HWC with 3 (BGR) or 4 (BGRA) channels");
+    int h, w;
+    int rc = d2s_process_area_shape(H0, W0, target_height, &h, &w);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (target_height >= H0) {
+        const long npix = (long)H0 * W0;
+        hipLaunchKernelGGL(process_swizzle_u8_kernel, dim3((unsigned)cdiv(npix, 256L)), dim3(256), 0, st, bgr, channels, npix, out);
+        D2S_CHECK_LAUNCH();
+        return D2S_OK;
+    }
+    dim3 grid(cdiv(w, 256), h), block(256);
+    const double sx = (double)W0 / (double)w, sy = (double)H0 / (double)h;          // resize(): scale = 1 / inv_scale = ssize / dsize
+    const int ix = (int)nearbyint(sx), iy = (int)nearbyint(sy);                      // saturate_cast<int>(double)
+    const bool fast = std::abs(sx - ix) < 2.220446049250313e-16 && std::abs(sy - iy) < 2.220446049250313e-16;
+    if (fast && ix == 2 && iy == 2) hipLaunchKernelGGL(process_area_kernel<2>, grid, block, 0, st, bgr, channels, H0, W0, out, h, w, sy, sx, iy, ix);
+    else if (fast) hipLaunchKernelGGL(process_area_kernel<1>, grid, block, 0, st, bgr, channels, H0, W0, out, h, w, sy, sx, iy, ix);
+    else hipLaunchKernelGGL(process_area_kernel<0>, grid, block, 0, st, bgr, channels, H0, W0, out, h, w, sy, sx, iy, ix);
     D2S_CHECK_LAUNCH();
     return D2S_OK;
 }

@@ -17,8 +17,9 @@ plus ``predict`` / ``to_stereo`` (the names BASELINE.json's north_star uses) and
   * every computation is a HIP kernel behind the C-ABI; if the library or a GPU is missing the
     call raises -- there is no eager-PyTorch fallback (the reference degrades silently,
     depth.py:1597-1631);
-  * ``process`` implements the torch branch of the reference (the one a ROCm device takes,
-    depth.py:540-566), not the cv2/UMat branch of CPU-only hosts (depth.py:570-629).
+  * ``process`` has both definitions of the reference behind ``branch=``: the torch one a ROCm device takes
+    (depth.py:540-566, default) and the non-CUDA one (depth.py:570-629: tensor branch + cv2 INTER_AREA branch);
+    only the cv2.UMat container of the latter is not built.
 """
 from __future__ import annotations
 
@@ -124,7 +125,7 @@ def calibrate(frames) -> None:
         t = t.unsqueeze(0)
     t = t.to(device=_device())
     p = _state["params"]
-    x = ops.preprocess(t, p.depth_resolution, _state["cfg"].patch, p.mean, p.std, p.resample)
+    x = ops.preprocess(t, p.depth_resolution, _state["cfg"].patch, p.mean, p.std, p.resample, p.square_input)
     eng = _ensure_engine_built(int(x.shape[2]), int(x.shape[3]), x)
     eng.calibrate(x[: _state["max_batch"]])
 
@@ -134,15 +135,30 @@ def _fp8_first_inputs(frames_u8: torch.Tensor, key) -> Optional[torch.Tensor]:
     if _state["precision"] != "fp8" or (_state["engine"] is not None and _state["engine_key"] == key):
         return None
     p = _state["params"]
-    return ops.preprocess(frames_u8, p.depth_resolution, _state["cfg"].patch, p.mean, p.std, p.resample)
+    return ops.preprocess(frames_u8, p.depth_resolution, _state["cfg"].patch, p.mean, p.std, p.resample, p.square_input)
 
 
-def process(img_uint8, target_height: int) -> torch.Tensor:
-    """HWC uint8 BGR / BGRA capture frame (numpy or tensor) -> CHW float32 RGB 0..255 on the device, down-scaled to
-    `target_height` rows (even dims, bilinear + antialias) when the frame is taller: the branch of the reference's
-    process() a ROCm device takes (reference depth.py:540-566).  The result feeds predict_depth / make_sbs."""
-    t = torch.from_numpy(np.ascontiguousarray(img_uint8)) if isinstance(img_uint8, np.ndarray) else img_uint8
-    return ops.process(t.to(device=_device()), target_height)
+def process(img_uint8, target_height: int, branch: str = "cuda"):
+    """The reference defines process() twice and picks one at import time by IS_CUDA (depth.py:540-629):
+
+    branch="cuda" (default: what a CUDA *or ROCm* torch device runs, depth.py:540-566): HWC uint8 BGR / BGRA capture frame
+      (numpy or tensor) -> CHW float32 RGB 0..255 on the device, down-scaled to `target_height` rows (even dims, bilinear +
+      antialias) when the frame is taller.
+    branch="cpu" (the other definition, depth.py:570-629), by input type like the reference:
+      tensor -> its tensor branch (:576-601): already-RGB capture tensor [3|4,H,W] / [H,W,>=3], first three channels, plain
+      bilinear (no antialias) to even dims, or the frame as is when target_height >= H0 -> device tensor CHW;
+      numpy  -> its cv2 branch (:603-629): cvtColor BGR(A)->RGB + cv2.resize(INTER_AREA) to (int(W0*h/H0), h) -> uint8 HWC
+      numpy array, like the reference returns (the UMat variant of the same branch is an OpenCL container: not built).
+    The result feeds predict_depth / make_sbs."""
+    if branch not in ("cuda", "cpu"):
+        raise ValueError("process(): branch must be 'cuda' or 'cpu'")
+    if branch == "cuda":
+        t = torch.from_numpy(np.ascontiguousarray(img_uint8)) if isinstance(img_uint8, np.ndarray) else img_uint8
+        return ops.process(t.to(device=_device()), target_height)
+    if isinstance(img_uint8, torch.Tensor):
+        return ops.process_rgb(img_uint8.to(device=_device()), target_height)
+    t = torch.from_numpy(np.ascontiguousarray(img_uint8)).to(device=_device())
+    return ops.process_area(t, target_height).cpu().numpy()
 
 
 _FPS_MASK_CACHE = {"text": None, "frame": 0, "interval": 10}      # reference depth.py:2054-2059
@@ -199,7 +215,7 @@ def predict_depth(image_rgb, return_tuple=False, use_temporal_smooth: bool = Tru
         hwc = torch.from_numpy(np.ascontiguousarray(image_rgb)).to(device=_device(), non_blocking=True)
         rgb_tensor = hwc.permute(2, 0, 1)
         src = hwc
-    x = ops.preprocess(src, p.depth_resolution, _state["cfg"].patch if _state["cfg"] else 14, p.mean, p.std, p.resample)
+    x = ops.preprocess(src, p.depth_resolution, _state["cfg"].patch if _state["cfg"] else 14, p.mean, p.std, p.resample, p.square_input)
     eng = _ensure_engine_built(x.shape[2], x.shape[3], x)
     depth = eng(x)
     depth = ops.post_process_depth(depth, p)[0]
@@ -268,7 +284,7 @@ def pipeline(frames, display_mode=None, use_temporal_smooth=False, out_u8=True, 
     t = torch.from_numpy(np.ascontiguousarray(frames)) if isinstance(frames, np.ndarray) else frames
     t = t.to(device=_device())
     B, H, W, _ = t.shape
-    h, w, _s = engine_shape(H, W, p.depth_resolution, _state["cfg"].patch)
+    h, w, _s = engine_shape(H, W, p.depth_resolution, _state["cfg"].patch, p.square_input)
     if B > _state["max_batch"]:
         raise _lib.D2SError(f"batch {B} > configured max_batch {_state['max_batch']}")
     eng = _ensure_engine_built(h, w, _fp8_first_inputs(t, (h, w)))
@@ -286,7 +302,7 @@ def pipeline_mixed(frames_list, display_mode=None, out_u8=True):
     cfg = _state["cfg"]
     dev = _device()
     ts = [torch.from_numpy(np.ascontiguousarray(f)).to(dev) if isinstance(f, np.ndarray) else f.to(dev) for f in frames_list]
-    shapes = {engine_shape(t.shape[0], t.shape[1], p.depth_resolution, cfg.patch)[:2] for t in ts}
+    shapes = {engine_shape(t.shape[0], t.shape[1], p.depth_resolution, cfg.patch, p.square_input)[:2] for t in ts}
     if len(shapes) != 1:
         raise _lib.D2SError(f"pipeline_mixed: frames map to different model-input shapes {sorted(shapes)}")
     h, w = shapes.pop()
@@ -298,7 +314,7 @@ def pipeline_mixed(frames_list, display_mode=None, out_u8=True):
         groups.setdefault(tuple(t.shape[:2]), []).append(i)
     x = torch.empty((len(ts), 3, h, w), dtype=torch.float32, device=dev)
     for (H, W), idx in groups.items():
-        x[idx] = ops.preprocess(torch.stack([ts[i] for i in idx]), p.depth_resolution, cfg.patch, p.mean, p.std, p.resample)
+        x[idx] = ops.preprocess(torch.stack([ts[i] for i in idx]), p.depth_resolution, cfg.patch, p.mean, p.std, p.resample, p.square_input)
     depth = ops.post_process_depth(eng(x), p)
     sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, display_mode or p.display_mode, p.fill_16_9)
     out = [None] * len(ts)

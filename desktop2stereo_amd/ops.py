@@ -56,10 +56,10 @@ def post_params(p: PipelineParams) -> PostParams:
                       int(bool(p.metric)))
 
 
-def pre_params(mean=IMAGENET_MEAN, std=IMAGENET_STD, resample: str = "bilinear") -> PreParams:
+def pre_params(mean=IMAGENET_MEAN, std=IMAGENET_STD, resample: str = "bilinear", square: bool = False) -> PreParams:
     if resample not in _lib.RESAMPLE:
         raise ValueError(f"resample must be one of {list(_lib.RESAMPLE)}")
-    return PreParams((C.c_float * 3)(*mean), (C.c_float * 3)(*std), _lib.RESAMPLE[resample])
+    return PreParams((C.c_float * 3)(*mean), (C.c_float * 3)(*std), _lib.RESAMPLE[resample], int(bool(square)))
 
 
 def sbs_params(ipd_uv=0.064, depth_ratio=2.0, convergence=0.0, display_mode="Half-SBS", fill_16_9=False) -> SbsParams:
@@ -105,6 +105,53 @@ def process(img_bgr: torch.Tensor, target_height: int) -> torch.Tensor:
     return out
 
 
+def process_rgb(img: torch.Tensor, target_height: int) -> torch.Tensor:
+    """A1, tensor branch of the reference's non-CUDA process() (depth.py:576-601): RGB capture tensor [3|4,H,W] or [H,W,>=3]
+    (uint8 or float32) -> first three channels as CHW; target_height < H0: float32 bilinear (no antialias) down-scale to even
+    dims; else the frame itself (dtype unchanged, like the reference)."""
+    _need_cuda(img, "img")
+    if img.dim() != 3:
+        raise ValueError(f"Unsupported tensor image shape: {tuple(img.shape)}")
+    if img.shape[0] in (3, 4):
+        chw, ch, H0, W0 = True, img.shape[0], img.shape[1], img.shape[2]
+    elif img.shape[-1] >= 3:
+        chw, ch, H0, W0 = False, img.shape[2], img.shape[0], img.shape[1]
+    else:
+        raise ValueError(f"Unsupported tensor image shape: {tuple(img.shape)}")
+    if target_height >= H0:                                       # depth.py:586-587: returned as is (no resize, no cast)
+        return img[:3] if chw else img[..., :3].permute(2, 0, 1).contiguous()
+    if img.dtype not in (torch.uint8, torch.float32):
+        img = img.float()
+    if not chw and (img.dtype != torch.uint8 or ch > 4):
+        img, chw, ch = img[..., :3].permute(2, 0, 1), True, 3      # float HWC / wide HWC: plane view first
+    img = img.contiguous()
+    fmt = (FMT_U8_CHW if img.dtype == torch.uint8 else FMT_F32_CHW) if chw else FMT_U8_HWC
+    lib = _lib.load()
+    oh, ow = C.c_int(), C.c_int()
+    check(lib.d2s_process_shape(H0, W0, int(target_height), C.byref(oh), C.byref(ow)), "d2s_process_shape")
+    out = torch.empty((3, oh.value, ow.value), dtype=torch.float32, device=img.device)
+    with _on(img.device) as st:
+        check(lib.d2s_process_rgb(_ptr(img), fmt, ch, H0, W0, int(target_height), _ptr(out), st), "d2s_process_rgb")
+    return out
+
+
+def process_area(img_bgr: torch.Tensor, target_height: int) -> torch.Tensor:
+    """A1, numpy branch of the reference's non-CUDA process() (depth.py:603-629): uint8 HWC BGR(A) device tensor -> uint8 HWC RGB,
+    cv2.resize(INTER_AREA) to (int(W0*height/H0), height) when height < H0."""
+    _need_cuda(img_bgr, "img")
+    if img_bgr.dtype != torch.uint8 or img_bgr.dim() != 3 or img_bgr.shape[-1] not in (3, 4):
+        raise ValueError(f"process(): want uint8 [H,W,3|4] (BGR / BGRA), got {tuple(img_bgr.shape)} {img_bgr.dtype}")
+    img_bgr = img_bgr.contiguous()
+    H0, W0, ch = img_bgr.shape
+    lib = _lib.load()
+    oh, ow = C.c_int(), C.c_int()
+    check(lib.d2s_process_area_shape(H0, W0, int(target_height), C.byref(oh), C.byref(ow)), "d2s_process_area_shape")
+    out = torch.empty((oh.value, ow.value, 3), dtype=torch.uint8, device=img_bgr.device)
+    with _on(img_bgr.device) as st:
+        check(lib.d2s_process_area(_ptr(img_bgr), ch, H0, W0, int(target_height), _ptr(out), st), "d2s_process_area")
+    return out
+
+
 def overlay_text(frame: torch.Tensor, text: str) -> torch.Tensor:
     """A15 (reference depth.py:2061-2103): paint `text` in the reference's 5x3 font, green, IN PLACE on one frame."""
     _need_cuda(frame, "frame")
@@ -122,15 +169,17 @@ def overlay_text(frame: torch.Tensor, text: str) -> torch.Tensor:
 
 
 def preprocess(frames: torch.Tensor, target: int, patch: int = 14, mean=IMAGENET_MEAN, std=IMAGENET_STD,
-               resample: str = "bilinear") -> torch.Tensor:
+               resample: str = "bilinear", square: bool = False) -> torch.Tensor:
     """A2-A4 (reference depth.py:676-706, 1916-1948) -> float32 [B,3,h,w].  resample: "bilinear" = the CPU branch of
-    _resize_patch_aligned_t (decimation + bilinear), "bicubic_aa" = its IS_CUDA branch (depth.py:698-699)."""
+    _resize_patch_aligned_t (decimation + bilinear), "bicubic_aa" = its IS_CUDA branch (depth.py:698-699).
+    square=True: the fixed-square branch (get_patch_size() is None, CAPTURE_MODE "Window"; depth.py:1937-1946): plain bilinear
+    of the full frame to target x target."""
     _need_cuda(frames, "frames")
     frames = frames.contiguous()
     fmt, B, H, W = _frame_fmt(frames)
-    h, w, stride = engine_shape(H, W, target, patch)
+    h, w, stride = engine_shape(H, W, target, patch, square)
     out = torch.empty((B, 3, h, w), dtype=torch.float32, device=frames.device)
-    pre = pre_params(mean, std, resample)
+    pre = pre_params(mean, std, resample, square)
     with _on(frames.device) as st:
         check(_lib.load().d2s_preprocess(_ptr(frames), fmt, B, H, W, _ptr(out), h, w, stride, C.byref(pre), st), "d2s_preprocess")
     return out
@@ -410,7 +459,7 @@ class Engine:
             self._mine(out, "out")
         depth = torch.empty((B, H, W), dtype=torch.float32, device=frames.device) if want_depth else None
         pp = post_params(p)
-        pre = pre_params(p.mean, p.std, p.resample)
+        pre = pre_params(p.mean, p.std, p.resample, p.square_input)
         with _on(self.device) as st:
             check(self.lib.d2s_pipeline(self._h, _ptr(frames), B, H, W, p.depth_resolution, C.byref(pre), C.byref(pp), C.byref(sp),
                                         int(use_ema), _ptr(out), out_fmt, _ptr(depth) if want_depth else None, st), "d2s_pipeline")

@@ -102,6 +102,11 @@ typedef struct d2s_pre_params {
     float   mean[3];           /* (0.485, 0.456, 0.406); 0.5 for the dpt / zoedepth / depthpro ids (depth.py:1794-1799) */
     float   std[3];            /* (0.229, 0.224, 0.225) */
     int32_t resample;          /* D2S_RESAMPLE_* */
+    int32_t square;            /* 0: aspect-preserving patch-aligned input (get_patch_size() = 14, depth.py:531-538).
+                                  1: the fixed-square branch predict_depth takes when get_patch_size() is None -- CAPTURE_MODE ==
+                                  "Window" (depth.py:532-533, 1937-1946): F.interpolate(bilinear, align_corners=False, no antialias)
+                                  of the full frame to depth_resolution x depth_resolution on EVERY device (no decimation, `resample`
+                                  is not consulted); the engine is depth_resolution x depth_resolution */
 } d2s_pre_params;
 
 /* Stereo parameters of make_sbs_core (reference depth.py:2122-2129). */
@@ -172,6 +177,17 @@ int d2s_engine_memory(const d2s_engine* e, uint64_t* bytes);
 int d2s_process_shape(int H0, int W0, int target_height, int* out_h, int* out_w);
 int d2s_process(const uint8_t* bgr, int channels, int H0, int W0, int target_height, float* out, void* stream);
 
+/* A1, the branches of the reference's NON-CUDA process() (depth.py:570-629; what a host without a CUDA/ROCm torch device runs):
+ *  - tensor input (depth.py:576-601): the capture tensor is already RGB -- first three channels, no flip; target_height < H0:
+ *    F.interpolate(bilinear, align_corners=False, antialias=False) to the even sizes of d2s_process_shape; else the frame as is.
+ *    rgb: D2S_FMT_U8_HWC [H0,W0,channels] or D2S_FMT_U8_CHW / D2S_FMT_F32_CHW [channels,H0,W0]; out: float RGB CHW [3,h,w];
+ *  - numpy input (depth.py:603-629): cv2.cvtColor(BGR(A) -> RGB), then cv2.resize(INTER_AREA) to
+ *    (int(W0*target/H0), target) -- no even rounding; d2s_process_area_shape -- uint8 HWC in, uint8 RGB HWC out.  INTER_AREA is
+ *    OpenCV's published box filter (resize.cpp: exact 2x2 / integer-factor averages, fractional cell weights otherwise). */
+int d2s_process_rgb(const void* rgb, int fmt, int channels, int H0, int W0, int target_height, float* out, void* stream);
+int d2s_process_area_shape(int H0, int W0, int target_height, int* out_h, int* out_w);
+int d2s_process_area(const uint8_t* bgr, int channels, int H0, int W0, int target_height, uint8_t* out, void* stream);
+
 /* A15: overlay_fps  (reference depth.py:2061-2103, glyphs depth.py:641-658): paints `text` (the reference's
  * "FPS: %.1f"; characters outside its 16-glyph table render as blanks) in green (0,255,0) with the 5x3 font scaled
  * by max(1,min(8,H//60)) at margin 2*scale, IN PLACE on one frame in any D2S_FMT_* layout. */
@@ -180,7 +196,8 @@ int d2s_overlay_text(void* rgb, int fmt, int H, int W, const char* text, void* s
 /* A2-A4: ingest + _resize_patch_aligned_t + /255 + (x-mean)/std  (reference depth.py:676-706, 1916-1948).
  * pre->resample picks the branch of _resize_patch_aligned_t: D2S_RESAMPLE_BILINEAR = the CPU branch (strided decimation
  * by decim_stride = longest // (2*target), then bilinear align_corners=False), D2S_RESAMPLE_BICUBIC_AA = the IS_CUDA
- * branch (bicubic + antialias from the full frame; decim_stride is ignored).  pre == NULL: ImageNet mean / std, CPU branch.
+ * branch (bicubic + antialias from the full frame; decim_stride is ignored).  pre->square: the fixed-square branch (depth.py:1937-1946):
+ * plain bilinear of the full frame to (h, w), decim_stride and resample ignored.  pre == NULL: ImageNet mean / std, CPU branch.
  * frames: `batch` frames, format D2S_FMT_U8_HWC or D2S_FMT_U8_CHW or D2S_FMT_F32_CHW (0..255),
  * each H x W, contiguous.  out: float [batch,3,h,w] with (h,w) the engine shape. */
 int d2s_preprocess(const void* frames, int fmt, int batch, int H, int W,

@@ -160,6 +160,17 @@ def resize_patch_aligned(img_chw: np.ndarray, target: int, patch: int = 14, cuda
     return bilinear_resize(x.astype(F32), new_h, new_w, align_corners=False)
 
 
+def resize_fixed_square(img_chw: np.ndarray, target: int) -> np.ndarray:
+    """reference depth.py:1937-1946: the branch predict_depth takes when get_patch_size() is None (CAPTURE_MODE == "Window",
+    depth.py:531-538) -- F.interpolate(bilinear, align_corners=False, no antialias) of the full frame to target x target, on
+    every device; a frame that already is target x target passes through."""
+    _, h, w = img_chw.shape
+    x = np.asarray(img_chw).astype(F32)
+    if (h, w) == (target, target):
+        return x
+    return bilinear_resize(x, target, target, align_corners=False)
+
+
 def normalise(x: np.ndarray, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) -> np.ndarray:
     """reference depth.py:1931, 1946-1948: x/255 then (x-mean)/std."""
     m = np.asarray(mean, dtype=F32).reshape(3, 1, 1)
@@ -638,6 +649,97 @@ def process_frame(img_bgr: np.ndarray, target_height: int) -> np.ndarray:
     return separable_aa_resize(x, nh, nw, cubic=False)
 
 
+def process_tensor(img: np.ndarray, height: int) -> np.ndarray:
+    """reference depth.py:576-601: the tensor branch of the NON-CUDA process() ("tensor capture path is already RGB CHW"):
+    [3|4,H,W] -> first three planes, or [H,W,>=3] -> [..., :3] as CHW; NO channel flip; height >= H0 returns the frame as is;
+    else F.interpolate(bilinear, align_corners=False, antialias=False) to ((height//2)*2, (int(W0*height/H0)//2)*2)."""
+    img = np.asarray(img)
+    if img.ndim == 3 and img.shape[0] in (3, 4):
+        x = img[:3]
+    elif img.ndim == 3 and img.shape[-1] >= 3:
+        x = np.ascontiguousarray(img[..., :3].transpose(2, 0, 1))
+    else:
+        raise ValueError(f"Unsupported tensor image shape: {tuple(img.shape)}")
+    _, h0, w0 = x.shape
+    if height >= h0:
+        return x
+    width = (int(w0 * height / h0) // 2) * 2
+    height = (height // 2) * 2
+    return bilinear_resize(x.astype(F32), height, width, align_corners=False)
+
+
+def _area_tab(ssize: int, dsize: int):
+    """OpenCV computeResizeAreaTab (modules/imgproc/src/resize.cpp; opencv-python 4.12.0.88 is the reference's pin,
+    requirements.txt:4 -- third party, not under /root/reference, cv2 is not installed in this image): the source cells
+    [sx] and float32 weights each destination index dx accumulates when scale = ssize / dsize (double) is not an integer."""
+    scale = float(ssize) / float(dsize)
+    tab = []
+    for dx in range(dsize):
+        fsx1 = dx * scale
+        fsx2 = fsx1 + scale
+        cell = min(scale, ssize - fsx1)
+        sx1, sx2 = int(np.ceil(fsx1)), int(np.floor(fsx2))
+        sx2 = min(sx2, ssize - 1)
+        sx1 = min(sx1, sx2)
+        if sx1 - fsx1 > 1e-3:
+            tab.append((dx, sx1 - 1, F32((sx1 - fsx1) / cell)))
+        for sx in range(sx1, sx2):
+            tab.append((dx, sx, F32(1.0 / cell)))
+        if fsx2 - sx2 > 1e-3:
+            tab.append((dx, sx2, F32(min(min(fsx2 - sx2, 1.0), cell) / cell)))
+    return tab
+
+
+def resize_area_u8(img: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """cv2.resize(img, (dw, dh), interpolation=cv2.INTER_AREA) for a DOWN-scale of uint8 [H,W,C], restated from OpenCV's
+    published algorithm (resize.cpp): integer scale factors -> ResizeAreaFast (2x2: (a+b+c+d+2)>>2; else
+    saturate_cast<uchar>(sum * (1.f/area)), cvRound = round-half-even); otherwise ResizeArea_<uchar,float> -- per source row a
+    horizontal accumulation buf[dx] += S[sx]*alpha in table order, then sum[dx] (+)= beta*buf[dx] over the rows of a
+    destination row, saturate_cast<uchar> at its end.  PARITY UNPINNED against cv2 itself (not installed here): held to an
+    exact float64 area integral within 1 level in tests/test_oracle_golden.py."""
+    img = np.asarray(img)
+    H, W, C = img.shape
+    sx, sy = W / float(dw), H / float(dh)
+    ix, iy = int(round(sx)), int(round(sy))
+    if abs(sx - ix) < np.finfo(np.float64).eps and abs(sy - iy) < np.finfo(np.float64).eps:
+        blk = img[: dh * iy, : dw * ix].reshape(dh, iy, dw, ix, C).astype(np.int64).sum(axis=(1, 3))
+        if ix == 2 and iy == 2:
+            return ((blk + 2) >> 2).astype(np.uint8)
+        return np.clip(np.rint(blk.astype(F32) * F32(1.0 / (ix * iy))), 0, 255).astype(np.uint8)
+    xt, yt = _area_tab(W, dw), _area_tab(H, dh)
+    xd = np.array([t[0] for t in xt]); xs = np.array([t[1] for t in xt]); xa = np.array([t[2] for t in xt], F32)
+    src = img.astype(F32)
+    out = np.empty((dh, dw, C), np.uint8)
+    acc = None
+    prev = yt[0][0]
+    for dy, syi, beta in yt:
+        buf = np.zeros((dw, C), F32)
+        row = src[syi]
+        for k in range(len(xd)):                                 # table order (np.add.at would reorder nothing, but is slower)
+            buf[xd[k]] = buf[xd[k]] + row[xs[k]] * xa[k]
+        if dy != prev:
+            out[prev] = np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+            acc = beta * buf
+            prev = dy
+        elif acc is None:
+            acc = beta * buf
+        else:
+            acc = acc + beta * buf
+    out[prev] = np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+    return out
+
+
+def process_area(img_bgr: np.ndarray, height: int) -> np.ndarray:
+    """reference depth.py:603-629: the numpy branch of the NON-CUDA process(): cv2.cvtColor BGR(A) -> RGB, then, only if
+    height < H0, cv2.resize to (int(W0*height/H0), height) with INTER_AREA (no rounding to even sizes here); uint8 HWC."""
+    h0, w0 = img_bgr.shape[:2]
+    width = int(w0 * height / h0)
+    rgb = np.ascontiguousarray(img_bgr[..., :3][..., ::-1])
+    if height >= h0:
+        return rgb
+    return resize_area_u8(rgb, width, height)
+
+
 _FONT = {  # reference depth.py:641-658 (5x3 glyphs)
     "0": "111101101101111", "1": "010110010010111", "2": "111001111100111", "3": "111001111001111",
     "4": "101101111001001", "5": "111100111001111", "6": "111100111101111", "7": "111001010100100",
@@ -671,9 +773,10 @@ class PipelineOracle:
     """predict_depth + make_sbs of the reference, CPU branch, float32 (autocast disabled)."""
 
     def __init__(self, cfg, weights, depth_resolution=518, foreground_scale=0.05, aa_strength=4.0,
-                 ema_alpha=0.9, metric=False, max_depth=0.0, cuda_branch=False):
+                 ema_alpha=0.9, metric=False, max_depth=0.0, cuda_branch=False, square=False):
         self.model = DepthAnythingOracle(cfg, weights, max_depth)
         self.cuda_branch = cuda_branch              # _resize_patch_aligned_t's IS_CUDA branch (bicubic + antialias)
+        self.square = square                        # get_patch_size() is None (CAPTURE_MODE "Window"): fixed-square input
         self.metric = metric
         self.target = depth_resolution
         self.fg = foreground_scale
@@ -681,6 +784,8 @@ class PipelineOracle:
         self.stab = DepthStabilizer(ema_alpha)
 
     def model_input(self, img_hwc_u8: np.ndarray) -> np.ndarray:
+        if self.square:
+            return normalise(resize_fixed_square(np.ascontiguousarray(img_hwc_u8.transpose(2, 0, 1)), self.target))
         x = resize_patch_aligned(np.ascontiguousarray(img_hwc_u8.transpose(2, 0, 1)), self.target,
                                  self.model.cfg.patch, self.cuda_branch)
         return normalise(x)

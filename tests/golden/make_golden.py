@@ -39,7 +39,7 @@ def _versions():
 
 
 def gen_model(model: str, res: int, frames, store_inputs: bool, full_taps: bool, out: str, fp32=True, metric="",
-              cuda_branch=False):
+              cuda_branch=False, square=False):
     """predict_depth taps for one (model, depth_resolution).  cuda_branch: run _resize_patch_aligned_t's IS_CUDA branch
     (bicubic + antialias, reference depth.py:698-699 -- what the reference does on a CUDA *or ROCm* device; the flag is
     read at call time) instead of the CPU branch this container would take."""
@@ -49,8 +49,25 @@ def gen_model(model: str, res: int, frames, store_inputs: bool, full_taps: bool,
     D = load_reference(model, res, seed=0, fp32=fp32, metric=metric)
     if cuda_branch:
         D.IS_CUDA = True
+    captured = []
+    if square:
+        # get_patch_size() reads the module global at call time (depth.py:531-538); the model input predict_depth builds on this
+        # branch is captured at the model call itself (a transparent proxy around the reference's wrapper object)
+        D.CAPTURE_MODE = "Window"
+        assert D.get_patch_size() is None
+        inner = D.model_wraper
+
+        class _Tap:
+            def __call__(self, t):
+                captured.append(t.detach().clone())
+                return inner(t)
+
+            def __getattr__(self, k):
+                return getattr(inner, k)
+        D.model_wraper = _Tap()
     data = {}
     meta = {"model": model, "depth_resolution": res, "weights_seed": 0, "fp32": fp32, "metric": metric, "cuda_branch": cuda_branch,
+            "square": square,
             "max_depth": {"": 0.0, "Indoor": 20.0, "Outdoor": 80.0}[metric],
             "frames": [], "versions": _versions()}
     if metric:
@@ -73,10 +90,16 @@ def gen_model(model: str, res: int, frames, store_inputs: bool, full_taps: bool,
         img = synth.structured_frame(h, w, seed) if kind == "S2" else synth.noise_frame(h, w, seed)
         meta["frames"].append({"kind": kind, "h": h, "w": w, "seed": seed})
         x = torch.from_numpy(img).permute(2, 0, 1).unsqueeze(0)
-        xr = D._resize_patch_aligned_t(x, res, 14)
-        xn = xr / 255.0
-        m, s = D._normalization_tensors_for(xn)
-        xn = (xn - m) / s
+        if square:
+            del captured[:]
+            D.predict_depth(img, use_temporal_smooth=False)          # the reference builds the input itself (depth.py:1937-1950)
+            xn = captured[-1].float()                                 # (earlier entries: the engine warm-up on zeros, depth.py:1861)
+            assert tuple(xn.shape) == (1, 3, res, res), xn.shape
+        else:
+            xr = D._resize_patch_aligned_t(x, res, 14)
+            xn = xr / 255.0
+            m, s = D._normalization_tensors_for(xn)
+            xn = (xn - m) / s
         with torch.no_grad():
             raw = D.model_wraper(xn)
             post = D.post_process_depth(raw.float())
@@ -85,6 +108,8 @@ def gen_model(model: str, res: int, frames, store_inputs: bool, full_taps: bool,
             data[pre + "img"] = img
         if cuda_branch:
             data[pre + "resized_rows"] = xr[0, :, ::14].numpy()          # every 14th row of the resized (un-normalised) frame
+        if square and not full_taps:
+            data[pre + "model_input_rows"] = xn[0, :, ::37].numpy()
         if full_taps:
             data[pre + "model_input"] = xn[0].numpy()
             with torch.no_grad():
@@ -155,28 +180,61 @@ INGEST_CASES = [  # (name, H0, W0, channels, target_height, stored row stride)
 OVERLAY_CASES = [("h90", 90, 160, 59.9), ("h270", 270, 480, 123.4), ("h1080", 1080, 1920, 7.0), ("narrow", 120, 30, 60.0)]
 
 
-def gen_ingest(out: str):
-    """A1 process() and A15 overlay_fps().  process(): a CPU-only container imports the reference's cv2 branch
-    (depth.py:570-629; cv2 is absent), so the torch branch a ROCm device takes (depth.py:540-566) is reproduced
-    with the same torch call, F.interpolate(bilinear, align_corners=False, antialias=True).  overlay_fps() is the
-    reference's own function."""
+def _reference_process_defs(D):
+    """Both definitions of process() in the reference (`if IS_CUDA: def process ... else: def process ...`, depth.py:540-629):
+    only one exists after import, so the two FunctionDef nodes are taken from the reference's source with `ast` at generation time
+    and executed in the imported module's own namespace (DEVICE = cpu, DTYPE = float32).  Nothing of the source is stored."""
+    import ast
     import torch
-    import torch.nn.functional as F
+    with open(os.path.join("/root/reference", "depth.py")) as f:
+        tree = ast.parse(f.read())
+    node = next(n for n in tree.body if isinstance(n, ast.If) and isinstance(n.test, ast.Name) and n.test.id == "IS_CUDA"
+                and any(isinstance(c, ast.FunctionDef) and c.name == "process" for c in n.body))
+    fns = {}
+    for key, body in (("cuda", node.body), ("cpu", node.orelse)):
+        fd = next(c for c in body if isinstance(c, ast.FunctionDef) and c.name == "process")
+        ns = dict(D.__dict__)
+        ns.update(DEVICE=torch.device("cpu"), DTYPE=torch.float32)
+        exec(compile(ast.Module(body=[fd], type_ignores=[]), f"<reference depth.py:{fd.lineno}-{fd.end_lineno}>", "exec"), ns)
+        fns[key] = (ns["process"], [fd.lineno, fd.end_lineno])
+    return fns
+
+
+TENSOR_CASES = [  # (name, layout, planes/channels, dtype, H0, W0, target_height, stored row stride): process()'s tensor branch
+    ("chw3_u8_270_to_100", "chw", 3, "u8", 270, 480, 100, 1), ("chw4_u8_101_to_33", "chw", 4, "u8", 101, 75, 33, 1),
+    ("hwc4_u8_1080_to_720", "hwc", 4, "u8", 1080, 1920, 720, 45), ("chw3_f32_90_to_41", "chw", 3, "f32", 90, 160, 41, 1),
+    ("chw3_u8_90_keep", "chw", 3, "u8", 90, 160, 90, 1),
+]
+
+
+def gen_ingest(out: str):
+    """A1 process() and A15 overlay_fps().  process(): BOTH of the reference's definitions are executed (see
+    _reference_process_defs): the IS_CUDA one (depth.py:540-566, what a ROCm device runs) on BGR(A) uint8 frames, and the tensor
+    branch of the other (depth.py:576-601).  Its cv2 branch (INTER_AREA) cannot run here: cv2 is not installed.
+    overlay_fps() is the reference's own function."""
+    import torch
     from ref_harness import load_reference
     from desktop2stereo_amd import synth
     D = load_reference("tiny", 84, seed=0, fp32=True)
-    data, meta = {}, {"process": [], "overlay": [], "versions": _versions()}
+    fns = _reference_process_defs(D)
+    data, meta = {}, {"process": [], "process_tensor": [], "overlay": [], "versions": _versions(),
+                      "process_source": {k: f"reference depth.py:{v[1][0]}-{v[1][1]}, executed via ast extraction" for k, v in fns.items()}}
     for name, H0, W0, ch, target, rs in INGEST_CASES:
         img = np.random.default_rng([11, H0, W0]).integers(0, 256, (H0, W0, ch), dtype=np.uint8)
-        t = torch.from_numpy(img)[..., :3].flip(-1).permute(2, 0, 1).contiguous()
-        if target < H0:
-            nh, nw = (target // 2) * 2, (int(W0 * target / H0) // 2) * 2
-            t = F.interpolate(t.float().unsqueeze(0), size=(nh, nw), mode="bilinear", align_corners=False,
-                              antialias=nh < H0).squeeze(0)
-        res = t.float().numpy()
+        res = fns["cuda"][0](img.copy(), target).float().numpy()
         data["process_" + name] = res[:, ::rs]
         meta["process"].append({"name": name, "H0": H0, "W0": W0, "channels": ch, "target": target, "row_stride": rs,
                                 "out_shape": list(res.shape), "seed": [11, H0, W0]})
+    for name, layout, ch, dt, H0, W0, target, rs in TENSOR_CASES:
+        rng = np.random.default_rng([12, H0, W0])
+        shape = (ch, H0, W0) if layout == "chw" else (H0, W0, ch)
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        t = torch.from_numpy(img) if dt == "u8" else torch.from_numpy(img.astype(np.float32) + np.float32(0.25))
+        r = fns["cpu"][0](t.clone(), target)
+        res = r.numpy()
+        data["ptensor_" + name] = res[:, ::rs]
+        meta["process_tensor"].append({"name": name, "layout": layout, "channels": ch, "dtype": dt, "H0": H0, "W0": W0, "target": target,
+                                       "row_stride": rs, "out_shape": list(res.shape), "out_dtype": str(res.dtype), "seed": [12, H0, W0]})
     for name, H, W, fps in OVERLAY_CASES:
         rgb = torch.from_numpy(synth.structured_frame(H, W, 4)).permute(2, 0, 1).float()
         D._FPS_MASK_CACHE.update(mask=None, frame=0)
@@ -202,6 +260,7 @@ JOBS = {
     "vitb_r518": lambda o: gen_model("vitb", 518, [("S2", 1080, 1920, 0)], False, False, o),
     # the as-shipped CPU autocast (bf16) result, to report distance to it
     "vits_r518_bf16": lambda o: gen_model("vits", 518, [("S2", 1080, 1920, 0)], False, False, o, fp32=False),
+    "vitb_r518_bf16": lambda o: gen_model("vitb", 518, [("S2", 1080, 1920, 0)], False, False, o, fp32=False),
     # config 3 shapes: ViT-L, 3840x2160 frame (CPU branch decimates ::3 before the bilinear resize)
     "vitl_r518_4k": lambda o: gen_model("vitl", 518, [("S2", 2160, 3840, 0)], False, False, o),
     # metric head + metric normalize (reference ids Depth-Anything-V2-Metric-{Indoor,Outdoor}-*)
@@ -216,6 +275,10 @@ JOBS = {
     # noise frame: Full-TAB and Half-TAB only)
     "warp_uhd": lambda o: gen_warp(o, shapes=[("uhd", 2160, 3840, 270)], big=("uhd",), s1_cases=(2, 3)),
     "ingest": gen_ingest,
+    # the fixed-square input branch of predict_depth (CAPTURE_MODE == "Window" -> get_patch_size() is None, depth.py:531-538,
+    # 1937-1946): every tap of the KAT model at 84 x 84, and ViT-S at 518 x 518 (1 370 tokens) from a 1080p frame
+    "tiny_r84_square": lambda o: gen_model("tiny", 84, [("S2", 90, 160, 0), ("S1", 84, 84, 1)], True, True, o, square=True),
+    "vits_r518_square": lambda o: gen_model("vits", 518, [("S2", 1080, 1920, 0)], False, False, o, square=True),
 }
 
 if __name__ == "__main__":

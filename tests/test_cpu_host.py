@@ -37,7 +37,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_lib.PostParams) == 28 and _lib.PostParams.metric.offset == 24
     assert C.sizeof(_lib.SbsParams) == 24 and _lib.SbsParams.ipd_uv.offset == 0 and _lib.SbsParams.depth_ratio.offset == 8
     assert C.sizeof(_lib.DibrParams) == 72 and _lib.DibrParams.corner_radius.offset == 52 and _lib.DibrParams.viewport.offset == 56
-    assert C.sizeof(_lib.PreParams) == 28 and _lib.PreParams.std.offset == 12 and _lib.PreParams.resample.offset == 24
+    assert C.sizeof(_lib.PreParams) == 32 and _lib.PreParams.std.offset == 12 and _lib.PreParams.resample.offset == 24 and _lib.PreParams.square.offset == 28
 
 
 def test_sbs_shape_matches_reference_padding(lib):

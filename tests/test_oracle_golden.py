@@ -134,10 +134,85 @@ def test_metric_model_and_normalize(golden_dir, tiny):
     np.testing.assert_allclose(O.normalize_depth(z["fewcase_in"], metric=True), z["fewcase_norm"], atol=1e-6)
 
 
+def test_fixed_square_branch(golden_dir, tiny):
+    """predict_depth's fixed-square input branch (get_patch_size() is None: CAPTURE_MODE == "Window", reference depth.py:531-538,
+    1937-1946) as the reference ran it: the model input it fed its model (captured at the call), every tap of the KAT model at
+    84 x 84 incl. a frame that already is 84 x 84, and ViT-S at 518 x 518 from a 1080p frame."""
+    cfg, w = tiny
+    z, meta = _load(golden_dir, "tiny_r84_square")
+    assert meta["square"]
+    orc = O.PipelineOracle(cfg, w, 84, square=True)
+    for fi, fr in enumerate(meta["frames"]):
+        p = f"f{fi}_"
+        x = orc.model_input(z[p + "img"])
+        assert x.shape == (3, 84, 84)
+        np.testing.assert_allclose(x, z[p + "model_input"], atol=2e-5)
+        taps = {}
+        d = orc.predict_depth(z[p + "img"], use_temporal_smooth=True, taps=taps)      # the EMA chain runs across both frames (84 x 84 state)
+        for li in range(1, cfg.layers + 1):
+            np.testing.assert_allclose(taps[f"layer{li}"], z[p + f"layer{li}"], atol=5e-5)
+        assert np.abs(taps["raw_depth"] - z[p + "raw_depth"]).max() <= 2e-5 * float(z[p + "raw_depth"].max())
+        np.testing.assert_allclose(taps["post_depth"], z[p + "post_depth"], atol=1e-4)
+        np.testing.assert_allclose(d, z[p + "depth_ema_full"], atol=1e-4)
+    z, meta = _load(golden_dir, "vits_r518_square")
+    cfg = MODELS["vits"]
+    fr = meta["frames"][0]
+    orc = O.PipelineOracle(cfg, make_weights(cfg, 0), 518, square=True)
+    taps = {}
+    orc.predict_depth(synth.structured_frame(fr["h"], fr["w"], fr["seed"]), taps=taps)
+    np.testing.assert_allclose(taps["model_input"][:, ::37], z["f0_model_input_rows"], atol=2e-5)
+    assert np.abs(taps["raw_depth"] - z["f0_raw_depth"]).max() <= 3e-5 * float(z["f0_raw_depth"].max())
+    assert np.abs(taps["post_depth"] - z["f0_post_depth"]).max() <= 1e-4
+
+
+def test_process_area_restatement():
+    """process()'s cv2 branch (reference depth.py:603-629; cv2.resize INTER_AREA).  cv2 is not installed here, so this row is
+    PARITY UNPINNED against OpenCV itself: the restatement of its published algorithm is held to an exact float64 area
+    integral (what INTER_AREA approximates in float32) within one level, on integer (2x2, 3x3) and fractional factors."""
+    rng = np.random.default_rng(3)
+
+    def exact(img, dw, dh):
+        H, W, _ = img.shape
+
+        def mat(s, d):
+            M, sc = np.zeros((d, s)), s / d
+            for i in range(d):
+                a, b = i * sc, (i + 1) * sc
+                for j in range(int(np.floor(a)), min(s, int(np.ceil(b)))):
+                    M[i, j] = max(0.0, min(b, j + 1) - max(a, j)) / sc
+            return M
+        return np.einsum("ij,jkc,lk->ilc", mat(H, dh), img.astype(np.float64), mat(W, dw))
+    for (H0, W0, ch, t) in [(90, 160, 3, 45), (90, 160, 4, 30), (108, 192, 3, 72), (101, 75, 4, 33), (96, 128, 3, 67), (60, 80, 3, 60)]:
+        img = rng.integers(0, 256, (H0, W0, ch), dtype=np.uint8)
+        got = O.process_area(img, t)
+        if t >= H0:
+            assert np.array_equal(got, img[..., :3][..., ::-1])
+            continue
+        assert got.shape == (t, int(W0 * t / H0), 3) and got.dtype == np.uint8
+        ex = exact(img[..., :3][..., ::-1], got.shape[1], got.shape[0])
+        # right / bottom source cells beyond dsize * scale are never read by OpenCV's tables when W0 * t / H0 is not an integer
+        if abs(W0 / got.shape[1] - H0 / t) < 1e-9:
+            assert np.abs(got.astype(np.float64) - ex).max() <= 0.5 + 1e-3, (H0, W0, t)
+
+
 def test_process_and_overlay(golden_dir):
-    """A1 process() (BGR(A) swizzle + anti-aliased bilinear down-scale, depth.py:540-566) against torch's own kernel
-    called the way the reference calls it, and A15 overlay_fps() against the reference's function."""
+    """A1 process(): BOTH definitions of the reference executed at generation time (ast-extracted from depth.py:540-629, never
+    stored): the IS_CUDA one on BGR(A) frames (swizzle + anti-aliased bilinear down-scale) and the tensor branch of the other
+    (plain bilinear, no flip); A15 overlay_fps() against the reference's function."""
     z, meta = _load(golden_dir, "ingest")
+    assert "ast" in meta["process_source"]["cuda"]
+    for c in meta["process_tensor"]:
+        rng = np.random.default_rng(c["seed"])
+        shape = (c["channels"], c["H0"], c["W0"]) if c["layout"] == "chw" else (c["H0"], c["W0"], c["channels"])
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        if c["dtype"] == "f32":
+            img = img.astype(np.float32) + np.float32(0.25)
+        got = O.process_tensor(img, c["target"])
+        assert list(got.shape) == c["out_shape"] and str(got.dtype) == c["out_dtype"], c
+        err = np.abs(got[:, ::c["row_stride"]].astype(np.float32) - z["ptensor_" + c["name"]]).max()
+        # of 255, on noise frames: ATen's CPU kernel and the restatement round the source coordinate (up to ~500, float32 ulp
+        # 3e-5) in a different order, and neighbouring noise pixels differ by up to 255 levels
+        assert err <= 2e-3, (c["name"], err)
     for c in meta["process"]:
         img = np.random.default_rng(c["seed"]).integers(0, 256, (c["H0"], c["W0"], c["channels"]), dtype=np.uint8)
         got = O.process_frame(img, c["target"])
