@@ -19,8 +19,12 @@ int hip_fail(hipError_t err, const char* what, const char* file, int line) {
 
 static std::atomic<int> g_env_gen{1};
 int env_generation() { return g_env_gen.load(std::memory_order_relaxed); }
+// Two host threads may enter a launcher at once (two engines, or the depth and the warp thread of the reference's main loop): the
+// cached (generation, value) pair is read and refreshed under one lock -- a few nanoseconds per launch decision.
+static std::mutex g_env_mu;
 int EnvInt::get() {
     const int g = env_generation();
+    std::lock_guard<std::mutex> lk(g_env_mu);
     if (gen != g) { const char* v = getenv(name); val = v ? atoi(v) : dflt; gen = g; }
     return val;
 }

@@ -314,7 +314,7 @@ GemmEpi rowsE(void* out, int out_type, long ldc, const float* bias) {
 int gemm(d2s_engine* e, const GemmA& a, const PackedW& w, int M, const GemmEpi& ep, hipStream_t st) {
     int Kl = w.K % (e->prec == D2S_PREC_BF16 ? 8 : 4) ? w.Kpad : w.K;   // ragged K (patch embed): A is zero padded to Kpad
     GemmEpi ep2 = ep;
-    if (ep.map == MAP_ROWS && !ep.stats_out) {     // launcher decides whether to split K; each stream has its own partials
+    if (ep.map == MAP_ROWS) {     // launcher decides whether to split K (never the small-tile kernels when LN statistics are due); each stream has its own partials
         ep2.part = (e->side && st == e->side) ? e->splitk_ws_side : e->splitk_ws;
         ep2.part_elems = e->splitk_elems;
     }
@@ -455,7 +455,13 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     // 1 670 -> 1 758 frames/s at batch 4, 1 815 -> 2 000 at 5, 2 052 -> 2 275 at 8 with the limit at 3 (same box).
     static const int lnf_maxb = getenv("D2S_LNF_MAXB") ? atoi(getenv("D2S_LNF_MAXB")) : 3;       // tuning aid
     static const bool no_lnf = getenv("D2S_NO_LNFUSE") && atoi(getenv("D2S_NO_LNFUSE")) != 0;
-    const bool lnf = ((e->lnf && !e->fp8) || (f8 && !no_lnf)) && !e->calib && (prec == D2S_PREC_BF16 || x3) && B <= (x3 ? 8 : lnf_maxb);   // (bf16x3: no ping-pong kernel to give way to)
+    // Round 4: the ping-pong kernel folds LayerNorm itself (gemm_pp.hip, PP_K_*_LN) once the residual-update linears (N = D) run on
+    // it too, i.e. from gemm_pp_min_tiles() tiles of 256 x 256 over [M, D]: the 24 LayerNorm launches of the batched regime (0.66 ms of
+    // a 9.8 ms step at batch 32) are gone as well.  In between (QKV / FC1 on the ping-pong kernel, proj / FC2 not yet) nothing folds.
+    static EnvInt lnf_pp{"D2S_LNF_PP", 1};
+    const bool pp_fold = lnf_pp.get() && e->lnf && !e->fp8 && !x3 && prec == D2S_PREC_BF16 && !e->calib && !e->taps && D % 256 == 0 && D <= 1024 &&
+                         gemm_pp_min_tiles() > 0 && (long)cdiv(M, 256) * (D / 256) >= gemm_pp_min_tiles();
+    const bool lnf = (((e->lnf && !e->fp8) || (f8 && !no_lnf)) && !e->calib && (prec == D2S_PREC_BF16 || x3) && B <= (x3 ? 8 : lnf_maxb)) || pp_fold;   // (bf16x3: no ping-pong kernel to give way to)
     int ln_slots = 0;
     // batch 1, bf16: the four tap LayerNorms fold into the reassemble projections the same way (the statistics and the raw
     // residual of a tap layer are still in lnbuf / lnstats when its projection runs; the main stream waits for that launch

@@ -84,6 +84,9 @@ bool conv3_upsample_ok(int precision, int tile, const GemmA& a, int M, int N, in
 bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, const GemmEpi& e);
 int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st);
 
+// smallest number of 256 x 256 tiles from which plain linears go to the ping-pong kernel (D2S_GEMM_PP; 0 = never)
+int gemm_pp_min_tiles();
+
 // packed-weight geometry
 static inline size_t elem_size(int precision) { return precision == D2S_PREC_BF16 ? 2 : (precision == D2S_PREC_FP8_OPERANDS ? 1 : 4); }   // fp32, bf16x3: 4
 // host-side packing of one bf16x3 weight row: element k of a row lives in unit k / 8

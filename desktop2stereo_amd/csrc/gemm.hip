@@ -641,7 +641,7 @@ static inline bool buf_eligible(const GemmA& a, int M, int N, int K, int Kpad, i
 // launches to the general instantiations.
 static inline bool splitk_wanted(const GemmEpi& e, long tiles, int K, int bk) {
     static const int sk_grid = getenv("D2S_SPLITK_GRID") ? atoi(getenv("D2S_SPLITK_GRID")) : 128;
-    return e.part && e.part_elems > 0 && tiles < sk_grid && cdiv(K, bk) >= 24;
+    return e.part && e.part_elems > 0 && !e.stats_out && tiles < sk_grid && cdiv(K, bk) >= 24;     // (splitk_reduce_kernel writes no LN statistics)
 }
 
 // tile codes: 64 (64x64), 128 (128x128), 256128 / 256256 (8 waves), 25664 / 25632 (256 x 64|32, 4 waves); 0 = auto
@@ -655,7 +655,7 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
     int ks = 1;
     static const int sk_grid = getenv("D2S_SPLITK_GRID") ? atoi(getenv("D2S_SPLITK_GRID")) : 128;       // tuning aids
     static const int sk_div = getenv("D2S_SPLITK_DIV") ? atoi(getenv("D2S_SPLITK_DIV")) : 6;
-    if (STG != 2 && e.part && e.part_elems > 0 && (int)grid < sk_grid && nkt >= 24) {
+    if (STG != 2 && e.part && e.part_elems > 0 && !e.stats_out && (int)grid < sk_grid && nkt >= 24) {
         ks = nkt / sk_div; if (ks > 16) ks = 16;
         while (ks > 1 && (size_t)ks * M * N > e.part_elems) --ks;
     }
@@ -769,6 +769,11 @@ static void small_tile_of(int M, int N, int& bm, int& bn) {
 //  XCDs that will read them, two launches ahead -- 761-778 frames/s at batch 1 with and without.  Like the K-loop instruction
 //  count (descriptor addressing: +2 %), the K-tile size (256-byte tiles: +-0) and split-K for FC2 (-5 %), cold weights are not
 //  what paces the batch-1 launches.)
+int gemm_pp_min_tiles() {
+    static const int v = getenv("D2S_GEMM_PP") ? atoi(getenv("D2S_GEMM_PP")) : 100;
+    return v;
+}
+
 template <typename T>
 static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st) {
     static const int force_tile = getenv("D2S_GEMM_TILE") ? atoi(getenv("D2S_GEMM_TILE")) : 0;
@@ -780,7 +785,7 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
         // batched plain linears: the 256 x 256 ping-pong kernel (gemm_pp.hip) once the launch has enough tiles to fill the chip
         // measured (tools/pp_check.py, ViT-B shapes): from ~140 tiles of 256 x 256 the ping-pong kernel wins every encoder
         // linear (batch 16: +14..+30 %, batch 32: +9..+48 %); at 75 tiles (batch 8, N = 768) it loses.  D2S_GEMM_PP=0: off
-        static const int pp_min_tiles = getenv("D2S_GEMM_PP") ? atoi(getenv("D2S_GEMM_PP")) : 100;       // (100 vs 140: +5 % at batch 12, proj / FC2 there)
+        const int pp_min_tiles = gemm_pp_min_tiles();                                       // (100 vs 140: +5 % at batch 12, proj / FC2 there)
         const int prec = std::is_same<T, bf16_t>::value ? D2S_PREC_BF16 : D2S_PREC_FP8_OPERANDS;
         if (tile == 0 && pp_min_tiles > 0 && (long)cdiv(M, 256) * cdiv(N, 256) >= pp_min_tiles && pp_supported(prec, a, M, N, K, Kpad, e))
             return launch_gemm_pp(prec, a, W, M, N, K, Kpad, e, st);

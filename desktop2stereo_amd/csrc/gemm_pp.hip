@@ -168,9 +168,17 @@ __device__ __forceinline__ f32x4 pp_act4(f32x4 v) {
 // and pinned (one exposed L2 latency per tile); after the hook only stores and the ring's refills are issued.
 // LDS patch rows are 128 bytes = 8 chunks, chunk index XOR (row & 7) on both sides.  Wave-private: no barrier, the LDS ops
 // of one wave execute in order.
-template <int MODE, int ACT, bool DEQ, bool RES, bool IDENT = false, typename HOOK>
+// LN = LayerNorm folded into the linears either side of it, here for the batched regime:
+//   producer (PP_EP_F32 with the residual): the pass order becomes row block outer / column half inner, so that a lane meets both
+//     halves of its rows back to back; it also stores the value as bf16 (out2: the raw residual the next linear reads) and adds up
+//     (sum x, sum x^2) of its 4 columns per row; the 8 lanes of a row combine by ds_swizzle, the block's four N-quarter waves
+//     through `lnred` -- LDS the next tile's prologue does not touch until its second phase -- behind ONE extra block barrier,
+//     in fixed order (bit-reproducible): one float2 per (row, 256-column tile) in stats_out[tile column][M];
+//   consumer (PP_EP_BF16 / PP_EP_VT): A is that raw bf16 residual, W is gamma-folded; v = rstd[m] (acc - mean[m] colsum[n]) + bias
+//     with mean / rstd from the <= 4 partials per row (the two K halves of a lane pair load two slots each).
+template <int MODE, int ACT, bool DEQ, bool RES, bool IDENT = false, bool LN = false, typename HOOK>
 __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& e, int bm0, int bn0, int M, int grp, int wn,
-                                            int lane, u32x4* stg, HOOK&& hook) {
+                                            int lane, u32x4* stg, float2* lnred, float* colv, HOOK&& hook) {
 #define PP_QUAD(I, J, Q4) (f32x4){acc[I][J][4 * (Q4) + 0], acc[I][J][4 * (Q4) + 1], acc[I][J][4 * (Q4) + 2], acc[I][J][4 * (Q4) + 3]}
     const int fl = lane & 31, kg = lane >> 5;
     const int rr = lane >> 3, rc = lane & 7;
@@ -187,6 +195,8 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, nrec, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)e.res1, 0, RES ? nrec : 0u, 0x00020000);
         const unsigned vo = ((unsigned)(wm0 + rr) * ldc + (unsigned)(wn0 + rc * 4)) * 4u;
+        const __amdgpu_buffer_rsrc_t rsO2 = __builtin_amdgcn_make_buffer_rsrc(LN ? e.out2 : e.out, 0, LN ? (unsigned)M * ldc * 2u : 0u, 0x00020000);
+        float s1[4], s2[4];                          // LN producer: this lane's share of (sum, sum of squares) of its 4 rows of block i
         auto col_load = [&](auto jc) {
             constexpr int j = decltype(jc)::value;
 #pragma unroll
@@ -199,15 +209,25 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
         };
         auto res_load = [&](auto pc) {
             constexpr int p = decltype(pc)::value;
-            constexpr int j = p >> 2, i = p & 3;
+            constexpr int j = LN ? (p & 1) : (p >> 2), i = LN ? (p >> 1) : (p & 3);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 res[p % PP_RING][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo + ((i * 32 + r * 8) * ldc + j * 32) * 4u, 0, 0));
         };
         // IDENT: raw accumulators (the partial sums of a K split go to their slab untouched)
-        if constexpr (!IDENT) col_load(std::integral_constant<int, 0>{});
+        if constexpr (!IDENT && !LN) col_load(std::integral_constant<int, 0>{});
+        if constexpr (LN) {                          // ca | cc of the wave's 64 columns -> colv[0..63] | colv[64..127]
+            if (lane < 32) {
+                const int c = (lane & 15) * 4;
+                const f32x4 sc = pp_col4(e.scale, wn0 + c);
+                f32x4 x;
+                if (lane < 16) { if constexpr (DEQ) x = pp_col4(e.deq, wn0 + c) * sc; else x = sc; }
+                else x = pp_col4(e.bias, wn0 + c) * sc;
+                *(f32x4*)(colv + (lane >> 4) * 64 + c) = x;
+            }
+        }
         if constexpr (RES) static_for<PP_RING>([&](auto pc) { res_load(pc); });
-        if constexpr (!IDENT) {
+        if constexpr (!IDENT && !LN) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { PP_PIN4(ca[0][q]); PP_PIN4(cc[0][q]); }
         }
@@ -220,11 +240,12 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
         hook();
         static_for<8>([&](auto pc) {
             constexpr int p = decltype(pc)::value;
-            constexpr int j = p >> 2, i = p & 3;
+            constexpr int j = LN ? (p & 1) : (p >> 2), i = LN ? (p >> 1) : (p & 3);
             static_for<4>([&](auto qc) {
                 constexpr int q4 = decltype(qc)::value;
                 f32x4 v = PP_QUAD(i, j, q4);
-                if constexpr (!IDENT) v = v * ca[j][q4] + cc[j][q4];
+                if constexpr (LN) v = v * *(const f32x4*)(colv + j * 32 + 8 * q4 + 4 * kg) + *(const f32x4*)(colv + 64 + j * 32 + 8 * q4 + 4 * kg);
+                else if constexpr (!IDENT) v = v * ca[j][q4] + cc[j][q4];
                 stg[fl * 8 + ((2 * q4 + kg) ^ (fl & 7))] = __builtin_bit_cast(u32x4, v);
             });
 #pragma unroll
@@ -233,30 +254,122 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
                 f32x4 x = __builtin_bit_cast(f32x4, stg[row * 8 + (rc ^ (row & 7))]);
                 if constexpr (RES) x += res[p % PP_RING][r];
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rsO, vo + ((i * 32 + r * 8) * ldc + j * 32) * 4u, 0, 0);
+                if constexpr (LN) {
+                    typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+                    const u32x2_ t = {pk_bf16(x[0], x[1]), pk_bf16(x[2], x[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(t, rsO2, (vo >> 1) + ((i * 32 + r * 8) * ldc + j * 32) * 2u, 0, 0);
+                    const float a1 = (x[0] + x[1]) + (x[2] + x[3]), a2 = (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+                    if constexpr (j == 0) { s1[r] = a1; s2[r] = a2; } else { s1[r] += a1; s2[r] += a2; }
+                }
+            }
+            if constexpr (LN && j == 1) {
+                // the 8 lanes rc = 0..7 of a row: xor 1, 2, 4 inside the wave's 32-lane halves (ds_swizzle: no LDS memory involved)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // DPP, no LDS round trips: quad_perm [1,0,3,2] (xor 1), [2,3,0,1] (xor 2), row_half_mirror (lane k <-> 7 - k of its 8)
+                    float t1 = s1[r], t2 = s2[r];
+                    t1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t1), 0xB1, 0xf, 0xf, false));
+                    t2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t2), 0xB1, 0xf, 0xf, false));
+                    t1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t1), 0x4E, 0xf, 0xf, false));
+                    t2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t2), 0x4E, 0xf, 0xf, false));
+                    t1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t1), 0x141, 0xf, 0xf, false));
+                    t2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t2), 0x141, 0xf, 0xf, false));
+                    if (rc == 0) lnred[wn * 128 + i * 32 + r * 8 + rr] = make_float2(t1, t2);
+                }
             }
             asm volatile("" ::: "memory");                        // (keeps the ring PP_RING passes deep: no hoisting of later loads)
             if constexpr (RES && p + PP_RING < 8) res_load(std::integral_constant<int, p + PP_RING>{});
-            if constexpr (p == 1 && !IDENT) col_load(std::integral_constant<int, 1>{});     // two more passes until the other column half
+            if constexpr (p == 1 && !IDENT && !LN) col_load(std::integral_constant<int, 1>{});     // two more passes until the other column half
         });
+        if constexpr (LN) {
+            // the four N-quarter waves of this M half -> one partial per row and tile column.  One block barrier (every wave of the
+            // block passes it exactly once per tile, so the two groups' barrier counts stay equal), then wave wn == 0 adds in fixed order.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pp_barrier();
+            if (wn == 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = h * 64 + lane;
+                    float2 t = lnred[row];
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) { const float2 u = lnred[w * 128 + row]; t.x += u.x; t.y += u.y; }
+                    const int m = wm0 + row;
+                    if (m < M) ((float2*)e.stats_out)[(long)(bn0 >> 8) * M + m] = t;
+                }
+            }
+        }
         return;
     } else {
         f32x4 cb[2][4], cd[2][4];
+        float lmean[4], lrstd[4];
+        float2 lst[4][2];
+        auto ln_request = [&]() {
+            // LN consumer: the (sum, sum of squares) partials of this lane's four rows (they come from the fabric: another XCD wrote
+            // them) -- K half kg takes slots kg and kg + 2; a slot past ln_slots re-reads slot 0 and is dropped by a select (no
+            // branch around a load).  colsum(W') of the wave's 64 columns goes through `colv` (LDS); the bias stays in registers like
+            // the plain kinds' where there is room (FC1): with both vectors in LDS every quad waits for two dependent ds_read_b128.
+            static_assert(!LN || !DEQ, "LN-folded consumers run on bf16 operands");
+            const long lnM = e.ln_M ? e.ln_M : M;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 4; ++i) {
+                int m = wm0 + i * 32 + fl; m = m < M ? m : M - 1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n0 = wn0 + j * 32 + 8 * q + 4 * kg;
-                cb[j][q] = pp_col4(e.bias, n0);
-                if constexpr (DEQ) cd[j][q] = pp_col4(e.deq, n0);
+                for (int q = 0; q < 2; ++q) {
+                    const int sl = kg + 2 * q;
+                    lst[i][q] = ((const float2*)e.ln_stats)[(sl < e.ln_slots ? sl : 0) * lnM + m];
+                }
             }
+        };
+        // (the QKV kinds carry two epilogues -- row-major and V transposed -- and have no registers left for the bias: both vectors
+        //  through LDS there, measured 8 spilled registers against 88 and 110 vs 150 us per launch at batch 32)
+        constexpr bool CBREG = !LN || ACT == ACT_GELU;
+        if constexpr (LN && CBREG) ln_request();
+        if constexpr (CBREG) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { PP_PIN4(cb[j][q]); if constexpr (DEQ) PP_PIN4(cd[j][q]); }
+                for (int q = 0; q < 4; ++q) {
+                    const int n0 = wn0 + j * 32 + 8 * q + 4 * kg;
+                    cb[j][q] = pp_col4(e.bias, n0);
+                    if constexpr (DEQ) cd[j][q] = pp_col4(e.deq, n0);
+                }
+        }
+        if constexpr (LN) {
+            if constexpr (CBREG) { if (lane < 16) *(f32x4*)(colv + lane * 4) = pp_col4(e.ln_csum, wn0 + lane * 4); }
+            else if (lane < 32) *(f32x4*)(colv + (lane >> 4) * 64 + (lane & 15) * 4) = pp_col4(lane < 16 ? e.ln_csum : e.bias, wn0 + (lane & 15) * 4);
+        }
+        if constexpr (LN && !CBREG) ln_request();
+        if constexpr (CBREG) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { PP_PIN4(cb[j][q]); if constexpr (DEQ) PP_PIN4(cd[j][q]); }
+        }
+        auto ln_rows = [&]() {                       // mean / rstd of this lane's four rows, as the two factors the passes use
+            const float inv_d = 1.0f / (float)e.ln_dim;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t1 = (kg + 2 < e.ln_slots ? lst[i][1].x : 0.f) + (kg < e.ln_slots ? lst[i][0].x : 0.f);
+                float t2 = (kg + 2 < e.ln_slots ? lst[i][1].y : 0.f) + (kg < e.ln_slots ? lst[i][0].y : 0.f);
+                t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+                lmean[i] = t1 * inv_d;
+                lrstd[i] = rsqrtf(fmaxf(t2 * inv_d - lmean[i] * lmean[i], 0.f) + e.ln_eps);
+                if constexpr (CBREG) lmean[i] = -lmean[i] * lrstd[i];   // FC1: v = acc * rstd + colsum * (-mean * rstd) + bias
+                asm volatile("" : "+v"(lmean[i]), "+v"(lrstd[i]));
+            }
+        };
+        if constexpr (LN && CBREG) ln_rows();        // (FC1: before the hook, 8 live registers instead of 16)
+        if constexpr (LN && !CBREG) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { asm volatile("" : "+v"(lst[i][q].x), "+v"(lst[i][q].y)); }
+        }
         const unsigned ldc = (unsigned)e.ldc;
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, (unsigned)M * ldc * 2u, 0x00020000);
         const unsigned vo = ((unsigned)(wm0 + rr) * ldc + (unsigned)(wn0 + rc * 8)) * 2u;
         hook();
+        if constexpr (LN && !CBREG) ln_rows();
         static_for<4>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             if constexpr (MODE == PP_EP_VT) {
@@ -269,7 +382,9 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
                         const int n0 = wn0 + j * 32 + 8 * q4 + 4 * kg;
                         f32x4 v = PP_QUAD(i, j, q4);
                         if constexpr (DEQ) v *= cd[j][q4];
-                        v += cb[j][q4];
+                        if constexpr (LN && CBREG) v = v * lrstd[i] + (*(const f32x4*)(colv + j * 32 + 8 * q4 + 4 * kg) * lmean[i] + cb[j][q4]);
+                        else if constexpr (LN) v = (v - *(const f32x4*)(colv + j * 32 + 8 * q4 + 4 * kg) * lmean[i]) * lrstd[i] + *(const f32x4*)(colv + 64 + j * 32 + 8 * q4 + 4 * kg);
+                        else v += cb[j][q4];
                         bf16_t* p = (bf16_t*)e.vt + ((long)b * e.heads * 64 + (n0 - e.qk_cols)) * e.npad + t;
                         p[0] = f2bf(v[0]); p[e.npad] = f2bf(v[1]); p[2L * e.npad] = f2bf(v[2]); p[3L * e.npad] = f2bf(v[3]);
                     });
@@ -281,7 +396,9 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
                         constexpr int q4 = decltype(qc)::value;
                         f32x4 v = PP_QUAD(i, j, q4);
                         if constexpr (DEQ) v *= cd[j][q4];
-                        v = pp_act4<ACT>(v + cb[j][q4]);
+                        if constexpr (LN && CBREG) v = pp_act4<ACT>(v * lrstd[i] + (*(const f32x4*)(colv + j * 32 + 8 * q4 + 4 * kg) * lmean[i] + cb[j][q4]));
+                        else if constexpr (LN) v = pp_act4<ACT>((v - *(const f32x4*)(colv + j * 32 + 8 * q4 + 4 * kg) * lmean[i]) * lrstd[i] + *(const f32x4*)(colv + 64 + j * 32 + 8 * q4 + 4 * kg));
+                        else v = pp_act4<ACT>(v + cb[j][q4]);
                         uint2 t;
                         t.x = pk_bf16(v[0], v[1]); t.y = pk_bf16(v[2], v[3]);
                         ((uint2*)stg)[(fl * 8 + ((j * 4 + q4) ^ (fl & 7))) * 2 + kg] = t;
@@ -317,7 +434,9 @@ __device__ __forceinline__ void pp_tile_of(int lin, int tiles_m, int tiles_n, in
     }
     tm = lin / nl; tn = n0 + (lin - tm * nl);
 }
-enum { PP_K_BF16 = 0, PP_K_GELU = 1, PP_K_QKV = 2, PP_K_F32 = 3 };     // epilogue of a launch (one kernel instance each)
+enum { PP_K_BF16 = 0, PP_K_GELU = 1, PP_K_QKV = 2, PP_K_F32 = 3,       // epilogue of a launch (one kernel instance each)
+       PP_K_GELU_LN = 4, PP_K_QKV_LN = 5, PP_K_F32_LN = 6 };             // the same with LayerNorm folded in (consumer, consumer, producer)
+constexpr bool pp_kind_f32(int k) { return k == PP_K_F32 || k == PP_K_F32_LN; }
 
 template <typename T, int KIND>
 __global__ void __launch_bounds__(512)
@@ -342,7 +461,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     // go to fp32 slabs [unit][256][256] and are summed + finished by pp_tail_reduce_kernel.
     int runA = 0, nA = 0, runB = 0, nB = 0;
     pp_run(xcd, tw, runA, nA);
-    if constexpr (KIND == PP_K_F32) pp_run(xcd, (tiles_m * tiles_n - tw) * ks, runB, nB);
+    if constexpr (pp_kind_f32(KIND)) pp_run(xcd, (tiles_m * tiles_n - tw) * ks, runB, nB);
     const int ntl = nA + nB;
     int tl = blockIdx.x >> 3;                                        // this block's position in its XCD's unit list
     if (tl >= ntl) return;
@@ -471,7 +590,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
 
     // ---- this block's units.  unit j of the list -> (tile, first K tile, K tiles, slab index or -1)
     auto unit_of = [&](int j, int& tm, int& tn, int& k0, int& nk, int& slab) {
-        if (KIND != PP_K_F32 || j < nA) { pp_tile_of(runA + j, tiles_m, tiles_n, xn, tm, tn); k0 = 0; nk = nkt; slab = -1; }
+        if (!pp_kind_f32(KIND) || j < nA) { pp_tile_of(runA + j, tiles_m, tiles_n, xn, tm, tn); k0 = 0; nk = nkt; slab = -1; }
         else {
             const int u = runB + (j - nA), tt = u / ks;
             pp_tile_of(tw + tt, tiles_m, tiles_n, xn, tm, tn);
@@ -525,26 +644,42 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
             asm volatile("" : "+v"(lane_e));
             el.out = (char*)e.out + z; el.bias = e.bias + z; el.scale = e.scale + z; el.deq = e.deq + z;
             el.res1 = e.res1 ? (const char*)e.res1 + z : nullptr; el.vt = e.vt ? (char*)e.vt + z : nullptr;
+            if constexpr (KIND >= PP_K_GELU_LN) {
+                el.out2 = e.out2 ? (char*)e.out2 + z : nullptr; el.stats_out = e.stats_out ? e.stats_out + z : nullptr;
+                el.ln_stats = e.ln_stats ? e.ln_stats + z : nullptr; el.ln_csum = e.ln_csum ? e.ln_csum + z : nullptr;
+            }
         }
         u32x4* stg = lds + 2 * PP_STAGE + wid * 256;
+        // LN producer: 2 x 4 x 128 float2 partials in the rows 64..127 of stage 1's A part -- the last K tile's fragment reads have
+        // returned (barrier above) and the next tile's prologue does not write there before its first K tile's second phase
+        float2* lnred = (float2*)(lds + PP_STAGE + 64 * 8) + grp * 512;
+        // LN variants: the two column vectors of this wave's 64 columns (128 floats) live in LDS during the epilogue instead of 64
+        // VGPRs -- rows 32.. of this wave's N quarter of stage 1's W part, which the next tile requests in its first phase, i.e.
+        // behind the tile-start barrier every wave reaches with its epilogue (and its LDS reads) complete
+        float* colv = (float*)(lds + PP_STAGE + PP_WOFF + (wn * 64 + 32) * 8 + grp * 64);
         // the next segment's first twelve pieces leave from inside the epilogue (both stages are free: the last fragment
         // read returned before the barrier above), followed by >= PP_TAIL stores of this wave
         auto hook = [&]() { if (more) { PP_SET_TILE(ntm * 256, ntn * 256, lane_e) PP_PROLOGUE() } };
         {
-            if constexpr (KIND == PP_K_F32) {
+            if constexpr (pp_kind_f32(KIND)) {
                 if (slab_u >= 0) {                  // a K split of a tail tile: raw partial sums to the unit's slab
                     GemmEpi es = el;
                     es.out = (char*)e.part + (size_t)slab_u * (65536 * 4);
                     es.ldc = 256;
-                    pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, false, true>(acc, es, 0, 0, 256, grp, wn, lane_e, stg, hook);
-                } else if (e.res1) pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
-                else pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+                    pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, false, true>(acc, es, 0, 0, 256, grp, wn, lane_e, stg, lnred, colv, hook);
+                } else if constexpr (KIND == PP_K_F32_LN) pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, true, false, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
+                else if (e.res1) pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
+                else pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
             }
-            else if constexpr (KIND == PP_K_GELU) pp_epilogue<PP_EP_BF16, ACT_GELU, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+            else if constexpr (KIND == PP_K_GELU) pp_epilogue<PP_EP_BF16, ACT_GELU, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
+            else if constexpr (KIND == PP_K_GELU_LN) pp_epilogue<PP_EP_BF16, ACT_GELU, DEQ, false, false, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
             else if constexpr (KIND == PP_K_QKV) {
-                if (bn0 >= e.qk_cols) pp_epilogue<PP_EP_VT, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
-                else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
-            } else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, hook);
+                if (bn0 >= e.qk_cols) pp_epilogue<PP_EP_VT, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
+                else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
+            } else if constexpr (KIND == PP_K_QKV_LN) {
+                if (bn0 >= e.qk_cols) pp_epilogue<PP_EP_VT, ACT_NONE, DEQ, false, false, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
+                else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false, false, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
+            } else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
         }
         PP_STAMP(stamp_ + 2)
         PP_WSTAMP(stamp_ + 2)
@@ -579,7 +714,13 @@ pp_tail_reduce_kernel(GemmEpi e, int M, int N, int tw, int ks, int lxn) {
     const float* p = e.part + (size_t)tt * ks * 65536 + r * 256 + c;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < ks; ++s) { float t[4]; load4(p + (size_t)s * 65536, t); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
-    epilogue_dispatch<T>(e, m, n0, v);
+    epilogue_dispatch<T>(e, m, n0, v);                      // (writes out2 as well; v = the stored values)
+    if (e.stats_out) {                                       // LN producer: a wave = the 256 columns of one row of this tile
+        float t1 = (v[0] + v[1]) + (v[2] + v[3]), t2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+        if ((threadIdx.x & 63) == 0) ((float2*)e.stats_out)[(long)tn * M + m] = make_float2(t1, t2);
+    }
 }
 
 // tile code 256256: the ping-pong kernel.  Requirements: plain row-major A, no ReLU-on-load, an even number (>= 2) of whole K
@@ -591,7 +732,15 @@ bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, 
     if (M <= 0 || N <= 0 || K < 2 * bk) return false;                   // (K = 0 would pass the parity test below and run two unloaded tiles)
     if (a.mode != A_PLAIN || a.relu || K % (2 * bk) || (N & 255)) return false;
     if (e.map != MAP_ROWS && e.map != MAP_QKV) return false;
-    if (e.ln_stats || e.ln_csum || e.stats_out || e.out2) return false;
+    const bool ln_cons = e.ln_stats || e.ln_csum, ln_prod = e.stats_out || e.out2;
+    if (ln_cons || ln_prod) {
+        // LayerNorm folded in (bf16 only): the consumer reads <= 4 partials per row (N of the producer <= 1024), the producer is the
+        // fp32 in-place residual update writing the bf16 copy + one partial per 256-column tile
+        static EnvInt off{"D2S_PP_NO_LN", 0};
+        if (off.get() || precision != D2S_PREC_BF16 || (ln_cons && ln_prod)) return false;
+        if (ln_cons && !(e.ln_stats && e.ln_csum && e.ln_slots >= 1 && e.ln_slots <= 4 && e.out_type != OUT_F32)) return false;
+        if (ln_prod && !(e.stats_out && e.out2 && e.stats_slots && e.out_type == OUT_F32 && e.res1 && e.res1 == e.out && !e.out2_bx3 && e.out2_qscale == 0.f && N <= 1024)) return false;
+    }
     if (e.rows_per_img || e.res1_mod || (e.ldc & 7) || e.res2 || N > PP_MAXN) return false;
     const bool out_bf16 = e.out_type == OUT_BF16 || (e.out_type == OUT_T && precision == D2S_PREC_BF16);
     if (e.out_type == OUT_F32) { if (e.act != ACT_NONE || e.map != MAP_ROWS) return false; }
@@ -630,14 +779,17 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
     // one 160-KiB block per CU, cpx blocks per XCD (blocks beyond an XCD's list exit at once)
     static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
     const int lxn = xn <= 1 ? 0 : (xn == 2 ? 1 : (xn == 4 ? 2 : 3));
-    const int kind = e.out_type == OUT_F32 ? PP_K_F32 : (e.map == MAP_QKV ? PP_K_QKV : (e.act == ACT_GELU ? PP_K_GELU : PP_K_BF16));
+    const bool ln = e.ln_csum != nullptr || e.stats_out != nullptr;
+    if (ln && e.out_type != OUT_F32 && e.map != MAP_QKV && e.act != ACT_GELU) { set_error("launch_gemm_pp: LN-folded consumer: QKV or FC1 only"); return D2S_E_UNSUPPORTED; }
+    const int kind = e.out_type == OUT_F32 ? (ln ? PP_K_F32_LN : PP_K_F32) : (e.map == MAP_QKV ? (ln ? PP_K_QKV_LN : PP_K_QKV) : (e.act == ACT_GELU ? (ln ? PP_K_GELU_LN : PP_K_GELU) : PP_K_BF16));
+    if (e.stats_slots) *e.stats_slots = e.stats_out ? tiles_n : 1 << 20;                 // partials per row the consumer will find
     // K-split tail (see the kernel): when the last round would be less than 45 % full and the launch is a residual update
     const int tiles = tiles_m * tiles_n, nkt = K / (128 / (int)elem_size(precision));
     int tw = tiles, ks = 1, kps = nkt;
     static const int split_pct = getenv("D2S_PP_SPLIT") ? atoi(getenv("D2S_PP_SPLIT")) : 45;
     // (only for long K loops: the slab round trip + the second launch cost ~30 us, a 12-K-tile round of proj costs 25 --
     //  measured at batch 32: FC2 164 -> 144 us, proj 65 -> 71)
-    if (kind == PP_K_F32 && e.part && split_pct > 0 && nkt >= 24) {
+    if (pp_kind_f32(kind) && e.part && split_pct > 0 && nkt >= 24) {
         const int rounds = tiles / ncu, rem = tiles - rounds * ncu;
         if (rounds >= 1 && rem > 0 && rem * 100 <= split_pct * ncu)
             for (int s = 8; s >= 2; --s)
@@ -658,7 +810,9 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
 #define PP_LAUNCH(T_, KIND_) hipLaunchKernelGGL((gemm_pp_kernel<T_, KIND_>), dim3(grid), dim3(512), 0, st, (const T_*)a.ptr, a.lda, (const T_*)W, M, N, K, Kpad, e1, lxn, skew_us, tw, ks, kps)
     if (precision == D2S_PREC_BF16) {
         if (kind == PP_K_F32) PP_LAUNCH(bf16_t, PP_K_F32); else if (kind == PP_K_QKV) PP_LAUNCH(bf16_t, PP_K_QKV);
-        else if (kind == PP_K_GELU) PP_LAUNCH(bf16_t, PP_K_GELU); else PP_LAUNCH(bf16_t, PP_K_BF16);
+        else if (kind == PP_K_GELU) PP_LAUNCH(bf16_t, PP_K_GELU);
+        else if (kind == PP_K_F32_LN) PP_LAUNCH(bf16_t, PP_K_F32_LN); else if (kind == PP_K_QKV_LN) PP_LAUNCH(bf16_t, PP_K_QKV_LN);
+        else if (kind == PP_K_GELU_LN) PP_LAUNCH(bf16_t, PP_K_GELU_LN); else PP_LAUNCH(bf16_t, PP_K_BF16);
     } else {
         if (kind == PP_K_F32) PP_LAUNCH(fp8_t, PP_K_F32); else if (kind == PP_K_QKV) PP_LAUNCH(fp8_t, PP_K_QKV);
         else if (kind == PP_K_GELU) PP_LAUNCH(fp8_t, PP_K_GELU); else PP_LAUNCH(fp8_t, PP_K_BF16);

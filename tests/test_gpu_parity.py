@@ -484,6 +484,48 @@ def test_layernorm_fusion_equals_separate_kernels(dev, monkeypatch):
         assert d.max() <= 0.03 * scale and d.mean() <= 0.004 * scale, (d.max() / scale, d.mean() / scale)
 
 
+def test_layernorm_fusion_in_the_pingpong_kernel(dev, monkeypatch):
+    """Batched regime (round 4): once proj / FC2 run on the 256 x 256 ping-pong kernel (>= 100 tiles over [M, D]: batch 11 for
+    ViT-B) its epilogues fold LN1 / LN2 themselves (gemm_pp.hip, PP_K_*_LN): the residual update also writes the bf16 raw residual
+    and one (sum, sum of squares) partial per row and 256-column tile, QKV / FC1 apply rstd (acc - mean colsum) + bias.  Against
+    the same engine with the LayerNorm kernels (D2S_LNF_PP=0): same arithmetic up to where the bf16 rounding falls; frame 0 of
+    both is held to the REFERENCE's depth (vitb_r518); bit-reproducible; a ragged last row tile (M = 12 x 778 = 9336 = 36.5 tiles)
+    and the K-split tail path of FC2 (batch 32: 38 tail tiles through pp_tail_reduce_kernel) are both exercised."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS, engine_shape
+    from desktop2stereo_amd.config import PipelineParams
+    from desktop2stereo_amd.weights import make_weights
+    cfg = MODELS["vitb"]
+    wts = make_weights(cfg, 0)
+    h, w, _ = engine_shape(1080, 1920, 518)
+    z, meta = _golden(os.path.join(os.path.dirname(__file__), "golden"), "vitb_r518")
+    for B in (12, 32):
+        seeds = [meta["frames"][0]["seed"]] + list(range(100, 100 + B - 1))
+        x = ops.preprocess(torch.stack([_t(synth.structured_frame(1080, 1920, s), dev) for s in seeds]), 518)
+        outs = []
+        for on in ("1", "0"):
+            monkeypatch.setenv("D2S_LNF_PP", on)
+            ops.reload_env()
+            eng = ops.Engine(cfg, wts, h, w, B, "bf16")
+            eng.profile(True)
+            outs.append(eng(x).cpu().numpy())
+            ln_launches = eng.profile_read()["layernorm"]["launches"]
+            eng.profile(False)
+            assert ln_launches == (5 if on == "1" else 28), (on, ln_launches)      # layer 0's LN1 + the four tap LayerNorms stay kernels
+            assert np.array_equal(outs[-1], eng(x).cpu().numpy())                  # fixed-order partial sums: bit-reproducible
+            post = ops.post_process_depth(_t(outs[-1][0], dev), PipelineParams(depth_resolution=518)).cpu().numpy()
+            dr = np.abs(post - z["f0_post_depth"])
+            print(f"[vitb B={B} LN {'folded into gemm_pp' if on == '1' else 'kernels'}] post-depth vs the reference (fp32): max {dr.max():.4f} mean {dr.mean():.5f}")
+            assert dr.max() <= 0.0375 and dr.mean() <= 0.005, (on, dr.max(), dr.mean())
+            eng.close()
+        scale = float(np.abs(outs[1]).max())
+        d = np.abs(outs[0] - outs[1])
+        print(f"[vitb B={B}] LN folded into gemm_pp vs LN kernels: max {d.max() / scale:.4f} mean {d.mean() / scale:.5f} of the depth range")
+        assert d.max() <= 0.03 * scale and d.mean() <= 0.004 * scale, (d.max() / scale, d.mean() / scale)
+    monkeypatch.delenv("D2S_LNF_PP")
+    ops.reload_env()
+
+
 def test_conv_kernel_generations_agree(dev, monkeypatch):
     """The 3x3 convolutions of the DPT neck / head have three generations of kernels behind one dispatcher (conv3.hip): the
     implicit-GEMM loader, the one-shot halo blocks (conv3_halo / conv3_halo2 / conv3_head) and, from ~7 frames per launch, the

@@ -13,6 +13,7 @@ from desktop2stereo_amd.weights import make_weights
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--blocks", type=int, nargs="*", default=[0, 1, 8, 100, 255])
+ap.add_argument("--kinds", type=int, nargs="*", default=None, help="epilogue kinds (gemm_pp.hip PP_K_*); default: those the engine uses at this batch")
 a = ap.parse_args()
 lib = _lib.load()
 if not hasattr(lib, "d2s_pp_timing"):
@@ -31,8 +32,10 @@ out = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=dev)
 for _ in range(3):
     eng.pipeline(frames, p, sp, use_ema=False, out=out)
 torch.cuda.synchronize()
-names = {0: "bf16 (proj-like / plain)", 1: "FC1 (GELU, bf16)", 2: "QKV", 3: "f32 residual (proj, FC2)"}
-for kind in (2, 1, 3):
+names = {0: "bf16 (proj-like / plain)", 1: "FC1 (GELU, bf16)", 2: "QKV", 3: "f32 residual (proj, FC2)",
+         4: "FC1, LayerNorm folded (consumer)", 5: "QKV, LayerNorm folded (consumer)", 6: "f32 residual + LN statistics (proj, FC2: producer)"}
+folded = os.environ.get("D2S_LNF_PP", "1") != "0"
+for kind in (a.kinds if a.kinds is not None else ((5, 4, 6) if folded else (2, 1, 3))):
     assert lib.d2s_pp_timing(kind, None) == 0
     eng.pipeline(frames, p, sp, use_ema=False, out=out)
     torch.cuda.synchronize()
