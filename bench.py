@@ -75,16 +75,79 @@ def cpu_baseline(cfg, weights, p, H, W, mode, budget_s=10.0, max_frames=3):
         return n, t_total
 
     n, t = run(None, budget_s, max_frames)
+    ref_note = ""
+    try:                                                 # the reference itself, timed in the build container (tests/golden/time_reference.py)
+        with open(os.path.join(REPO, "profiles", "r4_reference_cpu_timing.json")) as f:
+            rt = json.load(f)
+        r1, ra = rt["rows"]["one_thread_as_shipped"], rt["rows"]["all_cores"]
+        ref_note = (f" The REFERENCE ITSELF (imported, ViT-B, same workload, bf16 CPU autocast as shipped, median of {r1['frames']} frames after "
+                    f"{rt['warmups']} warm-ups) measured in the build container on {rt['cpu_model']}: {r1['frames_per_s']:.3f} frames/s on 1 thread "
+                    f"(as shipped, depth.py:19), {ra['frames_per_s']:.3f} frames/s on {ra['threads']} threads (profiles/r4_reference_cpu_timing.json).")
+    except (OSError, KeyError, ValueError):
+        rt = None
     out = {"value": n / t, "unit": "stereo frames/s", "cores": int(threads), "kind": "port",
            "sample": f"{n} frame(s) {W}x{H} {cfg.name} fp32 numpy oracle, {mode}, {t:.1f} s of CPU work",
            "host_cpus": os.cpu_count(),
            "note": "kind 'port': the numpy restatement under oracle/ (the Python reference cannot travel to this box). It is a "
-                   "checker, not a tuned CPU implementation: the reference's own torch CPU path measured 1.6 fps (ViT-S, "
-                   "1 thread, bf16 autocast) in the build container (SURVEY.md section 6), several times this port's rate."}
+                   "checker, not a tuned CPU implementation." + ref_note}
+    if rt is not None:
+        out["reference_in_build_container"] = {"cpu_model": rt["cpu_model"], "host_cpus": rt["host_cpus"], "rows": rt["rows"]}
     if threadpool_limits is not None:
         n1, t1 = run(1, budget_s, 1)
         out["one_thread"] = {"value": n1 / t1, "unit": "stereo frames/s", "cores": 1,
                              "sample": f"{n1} frame(s), {t1:.1f} s of CPU work; the reference ships torch.set_num_threads(1) (depth.py:19)"}
+    return out
+
+
+def parity_vs_reference(ops, synth, cfg, weights, p, engines, dev):
+    """The second half of BASELINE.json's metric ("...; depth L1 vs ref"), outside every timed region: the committed
+    reference-generated fixtures only (no oracle, no /root/reference).
+      depth: tests/golden/<model>_r518.npz -- the reference's fp32 CPU path on the seeded structured 1080p frame; post-processed
+             depth at model resolution: L1 (mean |diff|) and max |diff| (the depth range is 1) per engine precision;
+      warp:  tests/golden/warp.npz -- the reference's make_sbs on a 1080p frame with a GIVEN depth (isolates the warp), every
+             135th row stored: max |diff| in uint8 levels after round-half-even, Full-SBS (BASELINE configs[1]'s packing)."""
+    import numpy as np
+    import torch
+    from desktop2stereo_amd.config import engine_shape
+    gdir = os.path.join(REPO, "tests", "golden")
+    out = {}
+    try:
+        z = np.load(os.path.join(gdir, f"{cfg.name}_r518.npz"))
+        with open(os.path.join(gdir, f"{cfg.name}_r518.json")) as f:
+            fr = json.load(f)["frames"][0]
+    except OSError:
+        return None
+    if p.depth_resolution != 518 or p.resample != "bilinear":
+        return None
+    img = synth.structured_frame(fr["h"], fr["w"], fr["seed"]) if fr["kind"] == "S2" else synth.noise_frame(fr["h"], fr["w"], fr["seed"])
+    h, w, _ = engine_shape(fr["h"], fr["w"], 518)
+    x = ops.preprocess(torch.from_numpy(img).to(dev), 518)
+    ref = z["f0_post_depth"]
+    for name, mk in engines.items():
+        e = mk(h, w)
+        post = ops.post_process_depth(e(x), p).cpu().numpy()[0]
+        e.close()
+        d = np.abs(post - ref)
+        out[name] = {"depth_l1_vs_ref": float(d.mean()), "depth_max_vs_ref": float(d.max())}
+    out["depth_fixture"] = f"tests/golden/{cfg.name}_r518.npz: the reference's fp32 CPU path (autocast off), frame {fr['kind']} seed {fr['seed']} {fr['w']}x{fr['h']}, seeded synthetic weights"
+    try:
+        zw = np.load(os.path.join(gdir, "warp.npz"))
+        with open(os.path.join(gdir, "warp.json")) as f:
+            cases = [c for c in json.load(f)["cases"] if c["shape"] == "hd" and c["mode"] == "Full-SBS"]
+        worst, n = 0, 0
+        for c in cases:
+            gen = synth.structured_frame if c["kind"] == "S2" else synth.noise_frame
+            rgb = torch.from_numpy(gen(c["h"], c["w"], c["seed"])).to(dev)
+            dep = torch.from_numpy(synth.smooth_depth(c["h"], c["w"], c["seed"])).to(dev)
+            sp = ops.sbs_params(c["ipd_uv"], c["depth_ratio"], c["convergence"], c["mode"], c["fill_16_9"])
+            got = ops.make_sbs(rgb, dep, sp).cpu().numpy()[:: c["row_stride"]].astype(np.int32)
+            want = np.clip(np.rint(zw[c["key"]].astype(np.float32) / 256.0), 0, 255).astype(np.int32)
+            worst = max(worst, int(np.abs(got - want).max()))
+            n += 1
+        out["warp_max_lsb"] = worst
+        out["warp_fixture"] = f"tests/golden/warp.npz: {n} Full-SBS cases of the reference's make_sbs at 1920x1080 (given depth, every 135th row)"
+    except OSError:
+        pass
     return out
 
 
@@ -351,17 +414,41 @@ def rank_body(args, engine_factory=None, device=None):
         pool0 = [frames_for(5000 + 100 * j, n_total).to(dev) for j in range(2)] if rank == 0 else [None, None]
         out_r = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=dev)
 
-        def ingest_step(i):
-            mine = shard.scatter_frames(pool0[i & 1], n_total, (H, W, 3), dev) if world > 1 else pool0[i & 1]
-            eng.pipeline(mine, p, sp, use_ema=False, out=out_r)
-            return shard.gather_outputs(out_r, n_total) if world > 1 else out_r
-
         steps_i = args.steps if args.ingest == "rank0" else max(5, args.steps // 4)
-        dti = timed(ingest_step, max(2, args.warmup // 4), steps_i)
+        if world > 1:
+            # software-pipelined (shard.PipelinedIngest): scatter(k + 1) and gather(k - 1) travel under compute(k) on their own
+            # streams, grouped point-to-point batches, double buffers; the drain is inside the timed region
+            pipe = shard.PipelinedIngest(n_total, (H, W, 3), (oh, ow, 3), dev, lambda f, o: eng.pipeline(f, p, sp, use_ema=False, out=o))
+
+            def ingest_step(i):
+                return pipe.submit(pool0[i & 1])
+
+            def ingest_run(warm, n):
+                for i in range(warm):
+                    ingest_step(i)
+                pipe.flush()
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(n):
+                    ingest_step(i)
+                pipe.flush()
+                sync()
+                dt_ = time.perf_counter() - t0
+                t = torch.tensor([dt_], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                barrier()
+                return float(t.item())
+            dti = ingest_run(max(2, args.warmup // 4), steps_i)
+        else:
+            def ingest_step(i):
+                eng.pipeline(pool0[i & 1], p, sp, use_ema=False, out=out_r)
+                return out_r
+            dti = timed(ingest_step, max(2, args.warmup // 4), steps_i)
         ing = {"value": steps_i * n_total / dti, "unit": "stereo frames/s", "steps": steps_i, "ms_per_step": 1e3 * dti / steps_i,
                "frames_per_step": n_total,
-               "exchange": (f"per step: {world - 1} x isend of {B * H * W * 3 / 1e6:.1f} MB uint8 frames from rank 0, {world - 1} x irecv of "
-                            f"{B * oh * ow * 3 / 1e6:.1f} MB packed frames to rank 0 ({backend})") if world > 1 else "single rank: no exchange"}
+               "exchange": (f"per step: one grouped batch of {world - 1} x isend of {B * H * W * 3 / 1e6:.1f} MB uint8 frames from rank 0 and one of "
+                            f"{world - 1} x irecv of {B * oh * ow * 3 / 1e6:.1f} MB packed frames to rank 0 ({backend}), overlapped with the "
+                            f"neighbouring steps' compute (shard.PipelinedIngest)") if world > 1 else "single rank: no exchange"}
         if args.ingest == "rank0":
             result["value"], result["ms_per_step"] = ing["value"], ing["ms_per_step"]
             result["config"]["parallelism"] = f"frame-sharded dp{world}, rank-0 ingest: point-to-point scatter / gather per step ({backend})"
@@ -460,6 +547,22 @@ def rank_body(args, engine_factory=None, device=None):
                                            "edge pixels (tests/test_gpu_configs.py::test_config2...); the headline bf16 engine: max 0.012-0.016 / "
                                            "mean 0.0022 (the reference's own bf16 CPU autocast: 0.036 / 0.0029)")
 
+    if rank == 0 and world == 1 and not fake and not args.vda:
+        # "depth L1 vs ref" -- the parity half of the metric, from the committed reference fixtures, outside the timed regions
+        mk = {args.precision: (lambda hh, ww: ops.Engine(cfg, weights, hh, ww, max_batch=1, precision=args.precision, device=local_rank))}
+        if args.precision not in ("fp32", "bf16x3") and not args.no_parity_class:
+            mk["bf16x3"] = lambda hh, ww: ops.Engine(cfg, weights, hh, ww, max_batch=1, precision="bf16x3", device=local_rank)
+        if args.precision != "fp8":                       # (an fp8 engine needs calibration inputs: its error is reported by tests/test_gpu_fp8.py)
+            par = parity_vs_reference(ops, synth, cfg, weights, p, mk, dev)
+            if par:
+                result["parity"] = par
+                head = par.get(args.precision, {})
+                result["depth_l1_vs_ref"] = head.get("depth_l1_vs_ref")
+                result["depth_max_vs_ref"] = head.get("depth_max_vs_ref")
+                result["warp_max_lsb"] = par.get("warp_max_lsb")
+                if "parity_class" in result and "bf16x3" in par:
+                    result["parity_class"].update(par["bf16x3"])
+
     if rank == 0 and world == 1 and not fake and args.sink_quality > 0:
         # the Streamer modes' sink (cv2.imencode -> here the HIP JPEG encoder) behind the same step,
         # frame never leaving HBM.  Reported beside the headline number, not in it (the metric ends at make_sbs).
@@ -529,7 +632,7 @@ def rank_body(args, engine_factory=None, device=None):
 
     if rank == 0 and world == 1 and not fake and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, weights, p, H, W, args.mode)
-        result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        # (no GPU / CPU ratio: a speed-up over a CPU path says nothing about kernel quality -- the roofline fractions do)
         if default_run:
             # BASELINE configs[0] (the reference's own CPU-runnable case): ViT-S, Half-SBS, 1080p, fill_16_9, Depth Resolution 518
             # and 336 -- the CPU port beside the HIP path on the same workload

@@ -90,6 +90,7 @@ SYMBOLS = {
     "d2s_present_bind_gl_buffer": (C.c_int, [_P, C.c_int, C.c_uint]),
     "d2s_present_acquire": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "d2s_present_publish": (C.c_int, [_P, C.c_int, _P]),
+    "d2s_present_cancel": (C.c_int, [_P, C.c_int, _P]),
     "d2s_present_consume": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "d2s_present_release": (C.c_int, [_P, C.c_int, _P]),
     "d2s_present_destroy": (C.c_int, [_P]),

@@ -31,9 +31,8 @@ int hip_fail(hipError_t err, const char* what, const char* file, int line);
 // cold from device memory; the compiler fetches it lazily -- an s_load where a field is first needed, behind the branches of the
 // tile map -- so a kernel with ~370 bytes of arguments pays three or four serialised ~0.5 us misses before its first operand
 // request (gemm_glds_kernel: first LDS-DMA at instruction 775).  KERNARG_WARM(ka) at the top of the kernel requests one dword of
-// each 64-byte line at once (six lines); KERNARG_WARM_END(ka) -- placed where the compiler has already waited for its own scalar
-// loads -- waits for them and releases the six scratch SGPRs (they must stay reserved until the loads have landed: the hardware
-// writes them when the data arrives).  The compiler's own s_loads then hit the scalar cache.
+// each 64-byte line at once (six lines) and waits for them in the same asm statement (one ~0.5 us round trip instead of three or
+// four); the compiler's own s_loads then hit the scalar cache.
 struct KernargWarm { int d0, d1, d2, d3, d4, d5; };
 #ifdef D2S_NO_KERNARG_WARM                       // (A/B builds)
 #define KERNARG_WARM(ka) {}
@@ -43,11 +42,16 @@ struct KernargWarm { int d0, d1, d2, d3, d4, d5; };
     KernargWarm ka;                                                                                                   \
     {                                                                                                                 \
         auto p_ = __builtin_amdgcn_kernarg_segment_ptr();                                                             \
+        /* loads AND their wait in ONE asm statement: the six destination SGPRs are written by the hardware when the data lands, */  \
+        /* so they must not be visible to the register allocator as "defined" before that (it could copy or reuse them)          */  \
         asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\t"          \
-                     "s_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140"           \
-                     : "=&s"(ka.d0), "=&s"(ka.d1), "=&s"(ka.d2), "=&s"(ka.d3), "=&s"(ka.d4), "=&s"(ka.d5) : "s"(p_));   \
+                     "s_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\t"      \
+                     "s_waitcnt lgkmcnt(0)"                                                                           \
+                     : "=&s"(ka.d0), "=&s"(ka.d1), "=&s"(ka.d2), "=&s"(ka.d3), "=&s"(ka.d4), "=&s"(ka.d5) : "s"(p_) : "memory");   \
     }
-#define KERNARG_WARM_END(ka) asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(ka.d0), "s"(ka.d1), "s"(ka.d2), "s"(ka.d3), "s"(ka.d4), "s"(ka.d5) : "memory");
+#define KERNARG_WARM_END(ka) {}
+// the macro reads one dword at 0x140 of the kernarg segment: a kernel that uses it must have at least that many argument bytes
+#define KERNARG_WARM_BYTES 0x144
 #endif
 
 // Integer switch from the environment (kernel selection for A/B runs and tests): cached, re-read after

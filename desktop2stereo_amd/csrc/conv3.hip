@@ -19,6 +19,10 @@
 
 namespace d2s {
 
+// every kernel of this file that warms its argument lines (KERNARG_WARM, common.h) takes at least a GemmA and a GemmEpi by value
+static_assert(sizeof(GemmA) + sizeof(GemmEpi) + 8 >= KERNARG_WARM_BYTES, "KERNARG_WARM reads past the kernarg segment");
+
+
 template <int N_> __device__ __forceinline__ void c3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory"); }
 
 // Bank rule of the halo reads.  ds_read_b128 serves the wave in four groups of 16 lanes, {0-3, 12-15, 20-27}, {4-11, 16-19,

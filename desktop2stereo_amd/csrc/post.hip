@@ -316,6 +316,11 @@ extern "C" int d2s_post_process_to(const float* depth_in, float* depth_out, int 
     // out of place and few frames: one launch for both passes (tiles tap their neighbours' inputs, so never in place)
     static EnvInt fuse_max{"D2S_POST_FUSE_MAXB", 2};        // (it re-shapes the window borders, 1.8 x the pow() work: +0.6 % at batch 1, -0.7 % at 4)
     const size_t sb_bytes = ((size_t)(SB_TR + 2 * r) * (SB_TC + 2 * r) + (size_t)(SB_TR + 2 * r) * SB_TC) * sizeof(float);
+    {   // in place (equal pointers) or disjoint: a partially overlapping pair would be corrupted silently by either form below
+        const char *i0 = (const char*)depth_in, *o0 = (const char*)depth_out;
+        const size_t nb = (size_t)batch * h * w * sizeof(float);
+        D2S_REQUIRE(depth_out == depth_in || i0 + nb <= o0 || o0 + nb <= i0, "d2s_post_process_to: depth_in and depth_out overlap without being equal");
+    }
     if (depth_out != depth_in && batch <= fuse_max.get() && sb_bytes <= 64 * 1024 && cdiv(h, SB_TR) <= 65535 && batch <= 65535) {
         hipLaunchKernelGGL(shape_blur_kernel, dim3(cdiv(w, SB_TC), cdiv(h, SB_TR), batch), dim3(256), sb_bytes, st,
                            depth, bounds, depth_out, h, w, p->gamma, fg_exp, fg_on, p->metric != 0, taps);

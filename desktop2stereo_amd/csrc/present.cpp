@@ -143,15 +143,36 @@ extern "C" int d2s_present_publish(d2s_present* p, int slot, void* producer_stre
     std::lock_guard<std::mutex> lk(p->mu);
     auto& s = p->slots[slot];
     if (!s.writing) { set_error("d2s_present_publish: the slot was not acquired (or was published already)"); return D2S_E_STATE; }
+    s.writing = false;                              // a failure below leaves the slot unpublished (seq 0) but acquirable again
     if (s.gl_resource && s.mapped) {
         static map_fn unmap = sym<map_fn>("hipGraphicsUnmapResources");
         if (!unmap) { set_error("hipGraphicsUnmapResources missing"); return D2S_E_UNSUPPORTED; }
-        D2S_HIP(unmap(1, &s.gl_resource, (hipStream_t)producer_stream));     // stream-ordered: GL sees the buffer after the writes
         s.mapped = false;
+        D2S_HIP(unmap(1, &s.gl_resource, (hipStream_t)producer_stream));     // stream-ordered: GL sees the buffer after the writes
     }
     D2S_HIP(hipEventRecord(s.ready, (hipStream_t)producer_stream));
-    s.writing = false;
     s.seq = ++p->seq;
+    return D2S_OK;
+}
+
+// producer: give an acquired slot back WITHOUT publishing it (the frame was not produced: the pipeline raised, the mapped buffer
+// turned out too small, ...).  The slot becomes acquirable again with its old contents marked unusable (seq stays 0, so the consumer
+// never sees it); a GL-bound slot is unmapped, stream-ordered, like at publish.  Without this an abandoned slot would stay
+// `writing` forever -- excluded from acquire, not re-bindable -- and two such failures with a consumer holding the third slot would
+// stall a 3-slot ring for good.
+extern "C" int d2s_present_cancel(d2s_present* p, int slot, void* producer_stream) {
+    D2S_REQUIRE(p && slot >= 0 && slot < (int)p->slots.size(), "bad argument");
+    D2S_ON_DEVICE(p->device);
+    std::lock_guard<std::mutex> lk(p->mu);
+    auto& s = p->slots[slot];
+    if (!s.writing) { set_error("d2s_present_cancel: the slot is not acquired"); return D2S_E_STATE; }
+    s.writing = false;                              // first: whatever fails below, the slot is not lost
+    if (s.gl_resource && s.mapped) {
+        static map_fn unmap = sym<map_fn>("hipGraphicsUnmapResources");
+        s.mapped = false;
+        if (!unmap) { set_error("hipGraphicsUnmapResources missing"); return D2S_E_UNSUPPORTED; }
+        D2S_HIP(unmap(1, &s.gl_resource, (hipStream_t)producer_stream));
+    }
     return D2S_OK;
 }
 

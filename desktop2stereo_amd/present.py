@@ -78,7 +78,27 @@ class PresentRing:
         st = stream or torch.cuda.current_stream(self.device)
         slot, ptr, n = C.c_int(), C.c_void_p(), C.c_uint64()
         check(self.lib.d2s_present_acquire(self._h, C.c_void_p(st.cuda_stream), C.byref(slot), C.byref(ptr), C.byref(n)), "d2s_present_acquire")
-        return slot.value, self._view(slot.value, ptr.value, n.value)
+        try:
+            return slot.value, self._view(slot.value, ptr.value, n.value)
+        except Exception:
+            self.cancel(slot.value, st)            # e.g. the mapped GL buffer is smaller than a frame: the slot must not stay acquired
+            raise
+
+    def cancel(self, slot: int, stream: Optional[torch.cuda.Stream] = None):
+        """Give an acquired slot back without publishing it (the producer failed between acquire and publish)."""
+        st = stream or torch.cuda.current_stream(self.device)
+        check(self.lib.d2s_present_cancel(self._h, slot, C.c_void_p(st.cuda_stream)), "d2s_present_cancel")
+
+    def produce(self, fn, stream: Optional[torch.cuda.Stream] = None):
+        """acquire -> fn(slot_tensor) -> publish, cancelling the slot if fn raises.  Returns the slot index."""
+        slot, buf = self.acquire(stream)
+        try:
+            fn(buf)
+        except Exception:
+            self.cancel(slot, stream)
+            raise
+        self.publish(slot, stream)
+        return slot
 
     def publish(self, slot: int, stream: Optional[torch.cuda.Stream] = None):
         st = stream or torch.cuda.current_stream(self.device)

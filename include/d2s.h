@@ -220,7 +220,7 @@ int d2s_engine_calibrate(d2s_engine* e, const float* x, int batch, void* stream)
 int d2s_post_process(float* depth, int batch, int h, int w, const d2s_post_params* p,
                      void* workspace, uint64_t workspace_bytes, void* stream);
 uint64_t d2s_post_process_workspace(int batch, int h, int w);
-/* The same, out of place (depth_out may equal depth_in): with distinct buffers and few frames the normalise / gamma / foreground
+/* The same, out of place (depth_out may equal depth_in; a PARTIAL overlap is rejected with D2S_E_INVALID): with distinct buffers and few frames the normalise / gamma / foreground
  * step and both blur passes run as one launch. */
 int d2s_post_process_to(const float* depth_in, float* depth_out, int batch, int h, int w, const d2s_post_params* p,
                         void* workspace, uint64_t workspace_bytes, void* stream);
@@ -286,6 +286,8 @@ int d2s_present_bind(d2s_present* p, int slot, void* dev_ptr, uint64_t bytes);
 int d2s_present_bind_gl_buffer(d2s_present* p, int slot, unsigned gl_buffer);
 int d2s_present_acquire(d2s_present* p, void* producer_stream, int* slot, void** dev_ptr, uint64_t* bytes);
 int d2s_present_publish(d2s_present* p, int slot, void* producer_stream);
+/* producer: hand an acquired slot back unpublished (the frame was not produced); it becomes acquirable again, the consumer never sees it */
+int d2s_present_cancel(d2s_present* p, int slot, void* producer_stream);
 int d2s_present_consume(d2s_present* p, void* consumer_stream, int* slot, void** dev_ptr, uint64_t* seq);
 int d2s_present_release(d2s_present* p, int slot, void* consumer_stream);
 int d2s_present_destroy(d2s_present* p);

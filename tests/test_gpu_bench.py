@@ -33,6 +33,10 @@ def test_bench_contract_n1():
     assert rf["bound"] in ("mfma", "hbm") and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     pc = res["parity_class"]                       # the engines that meet the 1e-3 gate: split precision (fast) and fp32
     assert pc["dtype"] == "bf16x3" and 0 < pc["fp32_engine"]["value"] < pc["value"] < res["value"]
+    # the parity half of BASELINE.json's metric, from the committed reference fixtures (vits_r518, warp): the headline bf16 engine inside
+    # the reference's own bf16 class, the parity-class engine inside north_star's 1e-3, the warp within 1 LSB
+    assert 0 < res["depth_l1_vs_ref"] <= 0.00287 and res["depth_max_vs_ref"] <= 0.0357 and res["warp_max_lsb"] <= 1, res["parity"]
+    assert pc["depth_max_vs_ref"] <= 1e-3 and res["parity"]["bf16x3"]["depth_l1_vs_ref"] <= 1e-4
 
 
 def test_bench_spawns_its_own_ranks():

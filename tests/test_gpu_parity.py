@@ -569,6 +569,31 @@ def test_conv_kernel_generations_agree(dev, monkeypatch):
     assert np.allclose(outs["no_wide"], outs["no_halo2"], rtol=0, atol=2e-6 * scale)
     d = np.abs(outs["default"] - outs["implicit"])
     assert d.max() <= 0.02 * scale and d.mean() <= 0.002 * scale, (d.max() / scale, d.mean() / scale)
+    # The headline batches take OTHER loaders for the folded up-samples: below D2S_HEADP_MIN head tiles (batch 1-3) conv2's fold goes
+    # through conv_halo_fill / lerp_chunk of the one-shot conv3_halo2 blocks (MAP_HEAD), and with D2S_NO_HALO2=1 through the first-
+    # generation halo kernel's loader: the same bilerp1 expression everywhere, so folded == stand-alone bit for bit there too.
+    keys = ("D2S_NO_WIDE", "D2S_NO_HALO2", "D2S_NO_HALO", "D2S_NO_HEADUPS", "D2S_NO_UPSFOLD")
+    try:
+        for Bs in (1, 2):
+            xs = x[:Bs].contiguous()
+            got = {}
+            for name, env in (("default", {}), ("no_upsfold", {"D2S_NO_UPSFOLD": "1"}), ("no_headups", {"D2S_NO_HEADUPS": "1"}),
+                              ("halo1_fold", {"D2S_NO_HALO2": "1"}), ("halo1_nofold", {"D2S_NO_HALO2": "1", "D2S_NO_UPSFOLD": "1"})):
+                for k in keys:
+                    monkeypatch.delenv(k, raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                ops.reload_env()
+                eng = ops.Engine(cfg, wts, h, w, Bs, "bf16")
+                got[name] = eng(xs).cpu().numpy()
+                eng.close()
+            assert np.array_equal(got["default"], got["no_upsfold"]), Bs
+            assert np.array_equal(got["default"], got["no_headups"]), Bs
+            assert np.array_equal(got["halo1_fold"], got["halo1_nofold"]), Bs
+    finally:
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        ops.reload_env()
 
 
 @pytest.mark.parametrize("name,model,res", [("tiny_r518", "tiny", 518), ("vits_r518", "vits", 518),

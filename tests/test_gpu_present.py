@@ -83,6 +83,26 @@ def test_present_ring_producer_consumer(dev):
     s2, b2 = ring.acquire()
     assert s1 != s2 and b1.data_ptr() != b2.data_ptr()
     ring.publish(s1); ring.publish(s2)
+    # a producer that fails between acquire and publish gives the slot back (d2s_present_cancel): the ring never loses slots.  With
+    # one slot held by the consumer, far more failures than slots in a row must leave the ring usable, and a cancelled slot is never
+    # consumable (the consumer keeps seeing the last PUBLISHED frame).
+    slot_c, buf_c, seq_c = ring.consume(host_wait=True)
+    for _ in range(8):
+        with pytest.raises(ZeroDivisionError):
+            ring.produce(lambda b: 1 / 0)
+    s3, _ = ring.acquire()
+    ring.cancel(s3)
+    with pytest.raises(Exception):
+        ring.cancel(s3)                                                          # not acquired any more
+    with pytest.raises(Exception):
+        ring.publish(s3)                                                         # ... and not publishable
+    ring.release(slot_c)
+    assert ring.consume(host_wait=True)[2] in (seq_c, seq_c + 1, seq_c + 2)      # still a published frame, none of the cancelled ones
+    ring.release(ring.consume(host_wait=True)[0])
+    done = ring.produce(lambda b: b.fill_(7))
+    slot_d, buf_d, seq_d = ring.consume(host_wait=True)
+    assert slot_d == done and int(buf_d.max()) == 7 and int(buf_d.min()) == 7
+    ring.release(slot_d)
     # a view over a pointer the library reports (what a GL-bound slot hands out): aliases the memory, no copy
     from desktop2stereo_amd.present import _DevMem
     src = torch.arange(64, dtype=torch.uint8, device=dev)

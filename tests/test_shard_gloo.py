@@ -64,6 +64,18 @@ def test_scatter_gather_world2(n_frames):
     assert q.get(timeout=5) is True
 
 
+def ema_step_torch(depth, state, initialised, alpha):
+    """Test stand-in for the HIP d2s_ema_update on host tensors (the package itself computes on the GPU only): one
+    DepthStabilizer step, reference depth.py:1873-1887 -- first frame seeds the state and passes through, later frames return
+    prev.lerp_(depth, 1 - alpha); `depth` is overwritten with the returned map."""
+    if not initialised:
+        state.copy_(depth)
+        return depth
+    state.lerp_(depth, 1.0 - alpha)
+    depth.copy_(state)
+    return depth
+
+
 # ---- EMA under frame sharding (SURVEY.md 8e): gather to the stream owner -> scan -> send back ------------------------
 def _ema_worker(rank, world, port, owner, q):
     sys.path.insert(0, REPO)
@@ -76,7 +88,7 @@ def _ema_worker(rank, world, port, owner, q):
     lo, hi = frame_range(n, world, rank)
     mine = torch.from_numpy(np.stack([z[f"f{i}_post_depth"] for i in range(lo, hi)]) if hi > lo else np.zeros((0,) + z["f0_post_depth"].shape, np.float32))
     state = torch.zeros(z["f0_post_depth"].shape, dtype=torch.float32)
-    out, init = ema_exchange(mine.clone(), n, state, False, 0.9, owner=owner)
+    out, init = ema_exchange(mine.clone(), n, state, False, 0.9, owner=owner, ema_step=ema_step_torch)
     # every frame's stabilised map == the REFERENCE's single-stream EMA chain (DepthStabilizer, alpha 0.9; golden tiny_r84)
     errs = [float(np.abs(out[i - lo].numpy() - z[f"f{i}_ema_state"]).max()) for i in range(lo, hi)]
     if rank == owner:
@@ -101,6 +113,132 @@ def test_ema_exchange_matches_single_rank_chain(world, owner):
     for rank, errs, init in got:
         assert init and all(e <= 2e-6 for e in errs), (rank, errs)
     assert sum(len(e) for _, e, _ in got) == 3 + 1
+
+
+def test_ema_exchange_has_no_cpu_arithmetic():
+    """Host tensors without an explicit step: refused (the product computes on the GPU only)."""
+    from desktop2stereo_amd.shard import ema_exchange
+    with pytest.raises(RuntimeError):
+        ema_exchange(torch.zeros(1, 2, 2), 1, torch.zeros(2, 2), False, 0.9)
+
+
+# ---- rank-0 ingest as a software pipeline: scatter(k + 1) | compute(k) | gather(k - 1) ---------------------------------------
+def _pipe_worker(rank, world, port, n_frames, steps, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from desktop2stereo_amd.shard import PipelinedIngest, gather_outputs, scatter_frames
+    H, W = 5, 7
+    dev = torch.device("cpu")
+    rng = np.random.default_rng(3)
+    seq = [torch.from_numpy(rng.integers(0, 256, (n_frames, H, W, 3), dtype=np.uint8)) for _ in range(steps)]       # same on every rank (seeded)
+    calls = []
+
+    def compute(f, o):                                   # stand-in for engine.pipeline: a per-frame map that depends on the call index
+        calls.append(f.shape[0])
+        o.copy_(torch.cat([f, (f.to(torch.int32) * 3 % 251).to(torch.uint8)], dim=2))
+    # reference schedule: step by step, nothing overlapped
+    want = []
+    for k in range(steps):
+        mine = scatter_frames(seq[k] if rank == 0 else None, n_frames, (H, W, 3), dev)
+        o = torch.empty((mine.shape[0], H, 2 * W, 3), dtype=torch.uint8)
+        compute(mine, o)
+        g = gather_outputs(o, n_frames)
+        if rank == 0:
+            want.append(g.clone())
+    # pipelined schedule
+    pipe = PipelinedIngest(n_frames, (H, W, 3), (H, 2 * W, 3), dev, compute)
+    got = []
+    for k in range(steps):
+        r = pipe.submit(seq[k] if rank == 0 else None)
+        if rank == 0:
+            assert (r is None) == (k < 2), k
+            if r is not None:
+                got.append(r.clone())
+        else:
+            assert r is None
+    got += pipe.flush()
+    dist.barrier()
+    if rank == 0:
+        q.put(len(got) == steps and all(torch.equal(a, b) for a, b in zip(got, want))
+              and torch.equal(want[0], torch.cat([seq[0], (seq[0].to(torch.int32) * 3 % 251).to(torch.uint8)], dim=2)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames,steps", [(2, 5, 6), (3, 7, 5), (2, 1, 3), (3, 2, 1)])
+def test_pipelined_ingest_equals_stepwise(world, n_frames, steps):
+    """Results of the overlapped schedule == scatter -> compute -> gather step by step, every step, incl. the drain, ragged
+    blocks, ranks with no frames and runs shorter than the pipeline depth."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() + 11 * world + n_frames + steps) % 2000
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, n_frames, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=180)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ok is True
+
+
+# ---- one stream, frames sharded, temporal smoothing on: ShardedStream == the single-rank chain -------------------------------
+class _GoldenStages:
+    """Stand-in stages on host tensors: depth_small returns the reference's post-processed maps of the golden frames (looked up by
+    the frame's tag pixel), warp returns the depth it was given -- what reaches the warp is exactly the stabilised map."""
+
+    def __init__(self, z):
+        self.z = z
+
+    def depth_small(self, frames):
+        return torch.from_numpy(np.stack([self.z[f"f{int(f[0, 0, 0])}_post_depth"] for f in frames]).astype(np.float32)) if frames.shape[0] else \
+            torch.zeros((0,) + self.z["f0_post_depth"].shape, dtype=torch.float32)
+
+    def warp(self, frames, depth_small):
+        return depth_small
+
+
+def _stream_worker(rank, world, port, stream_id, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from desktop2stereo_amd.shard import ShardedStream, frame_range, stream_owner
+    z = np.load(os.path.join(REPO, "tests", "golden", "tiny_r84.npz"))
+    st = ShardedStream(_GoldenStages(z), stream_id=stream_id, alpha=0.9, ema_step=ema_step_torch)
+    assert st.owner == stream_owner(stream_id, world)
+    errs = []
+    # two calls on the same stream: frames 0-1, then frame 2 -- the state carries over on the owner (the golden chain is 3 frames)
+    for first, n in ((0, 2), (2, 1)):
+        lo, hi = frame_range(n, world, rank)
+        frames = torch.zeros((hi - lo, 2, 2, 3), dtype=torch.uint8)
+        for i in range(hi - lo):
+            frames[i, 0, 0, 0] = first + lo + i                    # tag: which golden frame this is
+        out = st(frames, n)
+        errs += [float(np.abs(out[i].numpy() - z[f"f{first + lo + i}_ema_state"]).max()) for i in range(hi - lo)]
+    q.put((rank, errs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,stream_id", [(2, 0), (2, 1), (3, 2)])
+def test_sharded_stream_matches_reference_chain(world, stream_id):
+    """predict_depth(use_temporal_smooth=True) for a stream whose frames are sharded: every frame's stabilised map == the
+    REFERENCE's single-stream DepthStabilizer chain (golden tiny_r84), across two calls."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() + 13 * world + stream_id) % 2000
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, stream_id, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sum(len(e) for _, e in got) == 3
+    for rank, errs in got:
+        assert all(e <= 2e-6 for e in errs), (rank, errs)
 
 
 # ---- bench.py's rank body under gloo, world_size 2 -------------------------------------------------------------------
