@@ -112,6 +112,35 @@ def test_vda_vits_stream(dev, golden_dir):
     eng.close()
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 3e-4), ("bf16", 0.036)])
+def test_vda_window_wrap_at_real_dimensions(dev, golden_dir, prec, tol):
+    """The 32-frame window wrapping AT SIZE: 40 frames of the REFERENCE's streaming VideoDepthAnything, ViT-S at 196 x 336 on 1080p
+    frames (tests/golden/vda_vits_long: every 7th depth row of every frame; caches of 1344 / 336 / 84 sites).  Frames 32..39 see a
+    window whose oldest entries were evicted by the reference's update_cache shift (vda2_s.py:177-187); the HIP engine's in-place
+    ring of projected rows must produce the same maps."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS
+    from desktop2stereo_amd.vda_weights import make_vda_weights
+    cfg = MODELS["vits"]
+    z = np.load(os.path.join(golden_dir, "vda_vits_long.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "vda_vits_long.json")))
+    rs = meta["row_stride"]
+    assert len(meta["frames"]) == 40
+    eng = ops.Engine(cfg, make_vda_weights(cfg, 0), 196, 336, 1, prec, temporal=True)
+    worst, worst_wrapped = 0.0, 0.0
+    for fi, fr in enumerate(meta["frames"]):
+        x = ops.preprocess(_t(synth.structured_frame(fr["h"], fr["w"], fr["seed"]), dev), meta["depth_resolution"])
+        d = eng(x).cpu().numpy()[0][::rs]
+        ref = z[f"f{fi}_depth"]
+        err = float(np.abs(d - ref).max() / max(1.0, float(fr["range"][1])))
+        worst = max(worst, err)
+        if fi >= 32:
+            worst_wrapped = max(worst_wrapped, err)
+        assert err <= tol, (prec, fi, err)
+    print(f"[vda ViT-S 196x336 window wrap, {prec}] worst frame error {worst:.2e} of the range over 40 frames ({worst_wrapped:.2e} over frames 32-39)")
+    eng.close()
+
+
 @pytest.mark.parametrize("prec,tol", [("fp32", 3e-4), ("bf16x3", 3e-4), ("bf16", None)])
 def test_vda_vitb_stream_at_the_quoted_size(dev, golden_dir, prec, tol):
     """ViT-B VDA at 294 x 518 on 1080p frames -- the size BASELINE config 4's stream throughput is quoted on -- 3 frames of the
