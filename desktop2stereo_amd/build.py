@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libd2s_hip.so")
-SOURCES = ["core.cpp", "present.cpp", "ingest.hip", "frame_ops.hip", "dibr.hip", "jpeg.hip", "post.hip", "gemm.hip", "conv3.hip", "gemm_pp.hip", "vit_ops.hip", "attention.hip", "temporal.hip", "engine.hip"]
+SOURCES = ["core.cpp", "present.cpp", "ingest.hip", "frame_ops.hip", "dibr.hip", "jpeg.hip", "post.hip", "gemm.hip", "conv3.hip", "gemm_pp.hip", "gemm_sk.hip", "vit_ops.hip", "attention.hip", "temporal.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          # kernarg preload (gfx950): the first 16 argument dwords of a kernel arrive in SGPRs with the wave instead of through a cold
          # s_load -- scalar / pointer arguments up to the first by-value struct.  gemm_glds_kernel's argument order is built around it

@@ -84,6 +84,10 @@ bool conv3_upsample_ok(int precision, int tile, const GemmA& a, int M, int N, in
 bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, const GemmEpi& e);
 int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st);
 
+// streaming kernel for the thin linears of the DPT neck (gemm_sk.hip: K <= 256, W tile resident in LDS, A streamed)
+bool sk_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, const GemmEpi& e);
+int launch_gemm_sk(const GemmA& a, const void* W, int M, int N, int K, int Kpad, const GemmEpi& e, hipStream_t st);
+
 // smallest number of 256 x 256 tiles from which plain linears go to the ping-pong kernel (D2S_GEMM_PP; 0 = never)
 int gemm_pp_min_tiles();
 

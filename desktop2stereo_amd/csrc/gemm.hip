@@ -781,6 +781,10 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
     if (tile == 0 && launch_conv_halo<T>(a, W, M, N, K, Kpad, e, st)) { D2S_CHECK_LAUNCH(); return D2S_OK; }
     static EnvInt conv_tile{"D2S_CONV_TILE", 0};          // tuning aid: tile code for the implicit 3x3 convolutions
     if (tile == 0 && a.mode == A_CONV3 && N > 64) tile = conv_tile.get();
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        // thin linears (K <= 256: ConvTranspose(k = s), fusion 1x1 projections): HBM-bound, one prologue per block instead of per tile
+        if (tile == 0 && sk_supported(D2S_PREC_BF16, a, M, N, K, Kpad, e)) return launch_gemm_sk(a, W, M, N, K, Kpad, e, st);
+    }
     if constexpr (!std::is_same<T, float>::value) {
         // batched plain linears: the 256 x 256 ping-pong kernel (gemm_pp.hip) once the launch has enough tiles to fill the chip
         // measured (tools/pp_check.py, ViT-B shapes): from ~140 tiles of 256 x 256 the ping-pong kernel wins every encoder
