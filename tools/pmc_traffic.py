@@ -12,7 +12,7 @@ the counter reported, in the same run).  MI355X_MICROARCH.md: FETCH_SIZE reports
 import collections, csv, glob, json, os, sys
 
 CLASSES = [  # (bench.py class, substring(s) of the kernel name)
-    ("gemm_linear", ("gemm_pp_kernel", "gemm_glds_kernel")),
+    ("gemm_linear", ("gemm_pp_kernel", "gemm_glds_kernel", "gemm_sk_kernel", "pp_tail_reduce_kernel")),
     ("stereo_warp", ("stereo_warp",)),
     ("attention", ("attention_kernel",)),
 ]
