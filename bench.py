@@ -255,6 +255,7 @@ def parse_args(argv=None):
                          "frames, RCCL point-to-point scatter / gather each step; both: headline = own, rank0 reported beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-class", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the depth / warp parity leg against the committed reference fixtures (counter passes)")
     ap.add_argument("--sink-quality", type=int, default=90, help="also time the step with the MJPEG sink behind it (0 = off)")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args(argv)
@@ -547,7 +548,7 @@ def rank_body(args, engine_factory=None, device=None):
                                            "edge pixels (tests/test_gpu_configs.py::test_config2...); the headline bf16 engine: max 0.012-0.016 / "
                                            "mean 0.0022 (the reference's own bf16 CPU autocast: 0.036 / 0.0029)")
 
-    if rank == 0 and world == 1 and not fake and not args.vda:
+    if rank == 0 and world == 1 and not fake and not args.vda and not args.no_parity:
         # "depth L1 vs ref" -- the parity half of the metric, from the committed reference fixtures, outside the timed regions
         mk = {args.precision: (lambda hh, ww: ops.Engine(cfg, weights, hh, ww, max_batch=1, precision=args.precision, device=local_rank))}
         if args.precision not in ("fp32", "bf16x3") and not args.no_parity_class:

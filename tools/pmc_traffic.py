@@ -14,7 +14,7 @@ import collections, csv, glob, json, os, sys
 CLASSES = [  # (bench.py class, substring(s) of the kernel name)
     ("gemm_linear", ("gemm_pp_kernel", "gemm_glds_kernel", "gemm_sk_kernel", "pp_tail_reduce_kernel")),
     ("stereo_warp", ("stereo_warp",)),
-    ("attention", ("attention_kernel",)),
+    ("attention", ("attention_kernel", "attention32_kernel")),
 ]
 KNOWN = {"d2s_calib_copy16": (512 << 20, 512 << 20), "d2s_calib_copy16to8": (512 << 20, 256 << 20)}
 
