@@ -83,9 +83,13 @@ def test_config2_bench_step_vitb_bf16_1080p_full_sbs(dev, golden_dir):
             assert frac_e2e <= 1e-4, frac_e2e        # a 1e-3 depth error is < 0.03 px of shift: isolated 2-LSB flips on sharp edges
             assert lsb_e2e <= (1 if prec == "fp32" else 2), (prec, lsb_e2e)
         else:
-            # measured on MI355X (round 2): max 0.0146 / mean 0.0024 -- the reference's own CPU path is bf16 autocast and sits
-            # 0.036 / 0.0029 from its fp32 self (tests/golden/vits_r518_bf16); bound = 1.5 x measured
-            assert d.max() <= 0.022 and d.mean() <= 0.0036, (d.max(), d.mean())
+            # reference-derived bound (round 4): the reference as shipped runs its CPU path under bf16 autocast; on this very frame it
+            # sits max 0.0180 / mean 0.00355 from its own fp32 result (tests/golden/vitb_r518_bf16 vs vitb_r518, model resolution; the
+            # bilinear up-sample to the frame is a convex combination, so the same bounds hold at full resolution)
+            zb = np.load(os.path.join(golden_dir, "vitb_r518_bf16.npz"))
+            gap = np.abs(zb["f0_post_depth"].astype(np.float32) - z["f0_post_depth"])
+            print(f"[config 2] the reference's own bf16 path vs its fp32 self: max {gap.max():.5f} mean {gap.mean():.6f}")
+            assert d.max() <= gap.max() and d.mean() <= gap.mean(), (d.max(), d.mean(), gap.max(), gap.mean())
         eng.close()
 
 

@@ -35,6 +35,14 @@ def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+def _ref_bf16_gap(golden_dir, name):
+    """(max, mean) distance of the reference AS SHIPPED (bf16 CPU autocast, tests/golden/<name>_bf16) from its own fp32 result
+    (tests/golden/<name>) on the post-processed depth of the fixture frame: the bound every HIP bf16 engine variant is held to."""
+    g = np.abs(np.load(os.path.join(golden_dir, name + "_bf16.npz"))["f0_post_depth"].astype(np.float32)
+               - np.load(os.path.join(golden_dir, name + ".npz"))["f0_post_depth"])
+    return float(g.max()), float(g.mean())
+
+
 # ------------------------------------------------------------------------------------------------
 def test_preprocess_matches_oracle(dev):
     from desktop2stereo_amd import ops, synth
@@ -476,7 +484,8 @@ def test_layernorm_fusion_equals_separate_kernels(dev, monkeypatch):
             post = ops.post_process_depth(_t(outs[-1][0], dev), PipelineParams(depth_resolution=518)).cpu().numpy()
             dr = np.abs(post - z["f0_post_depth"])
             print(f"[{model} B={B} LN {'kernels' if off == '1' else 'folded'}] post-depth vs the reference (fp32): max {dr.max():.4f} mean {dr.mean():.5f}")
-            assert dr.max() <= 0.0375 and dr.mean() <= 0.005, (off, dr.max(), dr.mean())      # the bf16 class of test_full_size_predict_depth
+            gmax, gmean = _ref_bf16_gap(os.path.join(os.path.dirname(__file__), "golden"), f"{model}_r518")
+            assert dr.max() <= gmax and dr.mean() <= gmean, (off, dr.max(), dr.mean(), gmax, gmean)     # no further than the reference's own bf16 path
             eng.close()
         scale = float(np.abs(outs[1]).max())
         d = np.abs(outs[0] - outs[1])
@@ -516,7 +525,8 @@ def test_layernorm_fusion_in_the_pingpong_kernel(dev, monkeypatch):
             post = ops.post_process_depth(_t(outs[-1][0], dev), PipelineParams(depth_resolution=518)).cpu().numpy()
             dr = np.abs(post - z["f0_post_depth"])
             print(f"[vitb B={B} LN {'folded into gemm_pp' if on == '1' else 'kernels'}] post-depth vs the reference (fp32): max {dr.max():.4f} mean {dr.mean():.5f}")
-            assert dr.max() <= 0.0375 and dr.mean() <= 0.005, (on, dr.max(), dr.mean())
+            gmax, gmean = _ref_bf16_gap(os.path.join(os.path.dirname(__file__), "golden"), "vitb_r518")
+            assert dr.max() <= gmax and dr.mean() <= gmean, (on, dr.max(), dr.mean(), gmax, gmean)       # no further than the reference's own bf16 path
             eng.close()
         scale = float(np.abs(outs[1]).max())
         d = np.abs(outs[0] - outs[1])
@@ -636,9 +646,12 @@ def test_full_size_predict_depth(dev, golden_dir, name, model, res):
     post = ops.post_process_depth(raw, p).cpu().numpy()[0]
     d = np.abs(post - ref_post)
     print(f"[{name}] bf16 engine post-depth vs fp32 reference: max {d.max():.4f} mean {d.mean():.5f}")
-    # measured on MI355X over the five fixtures (round 2): max 0.0157-0.0249, mean 0.0023-0.0033; bound = 1.5 x the worst
-    # (the reference's own bf16 CPU autocast sits max 0.036 / mean 0.0029 from its fp32 self, tests/golden/vits_r518_bf16)
-    assert d.max() <= 0.0375 and d.mean() <= 0.005, (d.max(), d.mean())
+    # Reference-derived bound (round 4): tests/golden/<name>_bf16 is the reference AS SHIPPED (bf16 CPU autocast, depth.py:661-664) on this
+    # very frame; the HIP bf16 engine must be no further from the reference's fp32 result than the reference's own bf16 path is.
+    zb = np.load(os.path.join(golden_dir, name + "_bf16.npz"))
+    ref_gap = np.abs(zb["f0_post_depth"].astype(np.float32) - ref_post)
+    print(f"[{name}] the reference's own bf16 autocast vs its fp32 self: max {ref_gap.max():.4f} mean {ref_gap.mean():.5f}")
+    assert d.max() <= ref_gap.max() and d.mean() <= ref_gap.mean(), (d.max(), d.mean(), ref_gap.max(), ref_gap.mean())
     eng.close()
 
 
