@@ -388,8 +388,16 @@ int neck_proj(d2s_engine* e, int i, int B, hipStream_t st, bool fold) {
     const int D = d.hidden, Mp = B * e->P, c = d.neck[i];
     if (!fold) return gemm(e, plainA(e->tapbuf[i], D), e->re[i].proj, Mp, rowsE(e->rproj[i], OUT_T, c, e->re[i].proj.bias), st);
     GemmEpi ep = rowsE(e->rproj[i], OUT_T, c, e->re[i].proj_ln.bias);
-    ep.ln_stats = e->lnstats + 2; ep.ln_M = e->N; ep.ln_slots = e->tap_slots; ep.ln_csum = e->re[i].csum; ep.ln_eps = d.ln_eps; ep.ln_dim = D;
-    return gemm(e, plainA((const bf16_t*)e->lnbuf + D, D), e->re[i].proj_ln, Mp, ep, st);
+    ep.ln_slots = e->tap_slots; ep.ln_csum = e->re[i].csum; ep.ln_eps = d.ln_eps; ep.ln_dim = D;
+    if (B == 1) {                                      // one frame: skip its cls row by starting one row in
+        ep.ln_stats = e->lnstats + 2; ep.ln_M = e->N;
+        return gemm(e, plainA((const bf16_t*)e->lnbuf + D, D), e->re[i].proj_ln, Mp, ep, st);
+    }
+    // several frames: the projection runs over ALL token rows (one cls row per frame: 0.13 % more rows) and the store mapping drops
+    // them -- token t of frame b lands on patch row b * P + t - 1 (gemm_epi.h epilogue4: row_off < 0)
+    ep.ln_stats = e->lnstats;
+    ep.rows_per_img = e->N; ep.img_rows = e->P; ep.row_off = -1;
+    return gemm(e, plainA(e->lnbuf, D), e->re[i].proj_ln, B * e->N, ep, st);
 }
 
 int neck_rest(d2s_engine* e, int i, int B, hipStream_t st) {
@@ -466,7 +474,9 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     // batch 1, bf16: the four tap LayerNorms fold into the reassemble projections the same way (the statistics and the raw
     // residual of a tap layer are still in lnbuf / lnstats when its projection runs; the main stream waits for that launch
     // -- ev_ln -- before the next layer's projection GEMM overwrites them)
-    const bool tap_fold = lnf && !f8 && !x3 && e->lnf && B == 1;           // (bf16x3: the tap LayerNorms stay kernels)
+    // round 4: also in the batched regime where the ping-pong kernel produces the statistics (3-4 partials per row)
+    static EnvInt tapf_pp{"D2S_TAPFOLD_PP", 1};
+    const bool tap_fold = lnf && !f8 && !x3 && e->lnf && (B == 1 || (pp_fold && tapf_pp.get()));           // (bf16x3: the tap LayerNorms stay kernels)
     bool tap_folded[4] = {false, false, false, false};
     int pending_ln = -1;
     for (int l = 0; l < d.layers; ++l) {

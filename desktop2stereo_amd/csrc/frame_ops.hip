@@ -1073,7 +1073,8 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
             // (Half-SBS stays on stereo_warp_stream: the lane-strided kernel needs the neighbour lane's values for the 2:1 column
             //  mean -- 24 cross-lane moves per row -- and measured 117 vs 101 us at batch 16)
             const bool lanes = lanes_ok && (g.mode == D2S_MODE_FULL_SBS || g.mode == D2S_MODE_FULL_TAB);
-            const int bpc = lanes ? 4 : 6;                                // resident blocks per CU (3 / 6 / 8 measured slower for lanes)
+            static EnvInt bpc_env{"D2S_WARP_BPC", 0};                     // tuning aid: rows are cut into 256 * bpc block walks
+            const int bpc = bpc_env.get() > 0 ? bpc_env.get() : (lanes ? 4 : 6);   // resident blocks per CU (3 / 6 / 8 measured slower for lanes at batch 16)
             long rounds = (rows * tiles_x + 256 * bpc - 1) / (256 * bpc);   // balanced persistent grid: every block walks `rounds` rows
             dim3 pgrid((unsigned)((rows + rounds - 1) / rounds), tiles_x);
             if (lanes && g.mode == D2S_MODE_FULL_SBS)

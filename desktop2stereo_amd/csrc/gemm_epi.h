@@ -305,6 +305,9 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float
         }
         return;
     }
+    // row re-mapping with a negative offset DROPS the rows that would land before their image's block (the folded tap LayerNorm at
+    // batch > 1 runs the reassemble projection over ALL token rows and leaves the cls row of every frame out: row_off = -1)
+    if (e.rows_per_img && e.row_off < 0 && (m % e.rows_per_img) + e.row_off < 0) return;
     const long off = epi_out_offset(e, m, n0);
     if (e.res1) {
         if (pre) { v[0] += pre[0]; v[1] += pre[1]; v[2] += pre[2]; v[3] += pre[3]; }

@@ -738,7 +738,7 @@ bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, 
         // fp32 in-place residual update writing the bf16 copy + one partial per 256-column tile
         static EnvInt off{"D2S_PP_NO_LN", 0};
         if (off.get() || precision != D2S_PREC_BF16 || (ln_cons && ln_prod)) return false;
-        if (ln_cons && !(e.ln_stats && e.ln_csum && e.ln_slots >= 1 && e.ln_slots <= 4 && e.out_type != OUT_F32)) return false;
+        if (ln_cons && !(e.ln_stats && e.ln_csum && e.ln_slots >= 1 && e.ln_slots <= 4 && e.out_type != OUT_F32 && (e.map == MAP_QKV || e.act == ACT_GELU))) return false;
         if (ln_prod && !(e.stats_out && e.out2 && e.stats_slots && e.out_type == OUT_F32 && e.res1 && e.res1 == e.out && !e.out2_bx3 && e.out2_qscale == 0.f && N <= 1024)) return false;
     }
     if (e.rows_per_img || e.res1_mod || (e.ldc & 7) || e.res2 || N > PP_MAXN) return false;
