@@ -375,6 +375,11 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
             if constexpr (MODE == PP_EP_VT) {
                 int m = wm0 + i * 32 + fl; m = m < M ? m : M - 1;
                 const int b = m / e.ntok, t = m - b * e.ntok;
+                // one per-lane byte offset for the row block (column 0 of this wave) + a wave-uniform offset per column: buffer stores,
+                // no 64-bit pointer per quad (the V^T tensor is far below 2 GiB: pp_supported)
+                const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(e.vt, 0, 0x7fffffff, 0x00020000);
+                const unsigned vtv = (unsigned)((((long)b * e.heads * 64 + (wn0 + 4 * kg - e.qk_cols)) * e.npad + t) * 2);
+                const int col_bytes = e.npad * 2;
                 static_for<2>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     static_for<4>([&](auto qc) {
@@ -385,8 +390,13 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
                         if constexpr (LN && CBREG) v = v * lrstd[i] + (*(const f32x4*)(colv + j * 32 + 8 * q4 + 4 * kg) * lmean[i] + cb[j][q4]);
                         else if constexpr (LN) v = (v - *(const f32x4*)(colv + j * 32 + 8 * q4 + 4 * kg) * lmean[i]) * lrstd[i] + *(const f32x4*)(colv + 64 + j * 32 + 8 * q4 + 4 * kg);
                         else v += cb[j][q4];
-                        bf16_t* p = (bf16_t*)e.vt + ((long)b * e.heads * 64 + (n0 - e.qk_cols)) * e.npad + t;
-                        p[0] = f2bf(v[0]); p[e.npad] = f2bf(v[1]); p[2L * e.npad] = f2bf(v[2]); p[3L * e.npad] = f2bf(v[3]);
+                        (void)n0;
+                        const unsigned pk01 = pk_bf16(v[0], v[1]), pk23 = pk_bf16(v[2], v[3]);
+                        constexpr int c0 = j * 32 + 8 * q4;
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pk01 & 0xffffu), rsV, vtv, (c0 + 0) * col_bytes, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pk01 >> 16), rsV, vtv, (c0 + 1) * col_bytes, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pk23 & 0xffffu), rsV, vtv, (c0 + 2) * col_bytes, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pk23 >> 16), rsV, vtv, (c0 + 3) * col_bytes, 0);
                     });
                 });
             } else {
@@ -747,6 +757,7 @@ bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, 
     else if (!(out_bf16 && !e.res1 && !e.res2 && !e.scale && (e.act == ACT_NONE || (e.act == ACT_GELU && e.map == MAP_ROWS)))) return false;
     if (e.map == MAP_QKV && (e.qk_cols & 255)) return false;            // a block tile is entirely q|k or entirely v
     if ((long)M * e.ldc * 4 >= (1L << 31)) return false;               // the epilogue's 32-bit buffer offsets
+    if (e.map == MAP_QKV && (long)cdiv(M, e.ntok > 0 ? e.ntok : 1) * e.heads * 64 * e.npad * 2 >= (1L << 31)) return false;   // ... and the V^T store's
     if ((long)M * a.lda * (long)elem_size(precision) >= (1L << 31) || (long)gemm_npad(N) * Kpad * (long)elem_size(precision) >= (1L << 31)) return false;
     return true;
 }
