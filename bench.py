@@ -258,6 +258,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-parity", action="store_true", help="skip the depth / warp parity leg against the committed reference fixtures (counter passes)")
     ap.add_argument("--sink-quality", type=int, default=90, help="also time the step with the MJPEG sink behind it (0 = off)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE configs[2] sub-run (ViT-L, 3840x2160, Full-TAB: bf16 and fp8 engines)")
     return ap.parse_args(argv)
 
 
@@ -659,6 +660,46 @@ def rank_body(args, engine_factory=None, device=None):
                                                                   "GPU: bf16 HIP engine; CPU: numpy oracle (kind 'port') on this host")
 
     eng.close()
+    if rank == 0 and world == 1 and not fake and default_run and not args.no_config3:
+        # BASELINE configs[2]: DepthAnything-v2 ViT-L, 3840x2160, batch 1, TAB output -- bf16 engine and the e4m3 engine (the four encoder
+        # linears on OCP e4m3 operands, static per-tensor activation scales calibrated on two structured frames), Full-TAB 4320x3840.
+        # Depth error of each against the committed reference fixture (vitl_r518_4k: the reference's fp32 CPU path on that frame).
+        import numpy as np
+        from desktop2stereo_amd.config import MODELS as _M3
+        from desktop2stereo_amd.weights import make_weights as _mw3
+        cfg3, H3, W3 = _M3["vitl"], 2160, 3840
+        w3 = _mw3(cfg3, 0)
+        h3, w3_, _ = engine_shape(H3, W3, 518)
+        p3 = PipelineParams(depth_resolution=518, display_mode="Full-TAB")
+        sp3 = ops.sbs_params(p3.ipd, p3.depth_strength, p3.convergence, "Full-TAB", p3.fill_16_9)
+        oh3, ow3 = ops.sbs_shape(H3, W3, sp3)
+        pool3 = [torch.from_numpy(synth.noise_frame(H3, W3, 9000 + j)[None]).to(dev) for j in range(2)]
+        out3 = torch.empty((1, oh3, ow3, 3), dtype=torch.uint8, device=dev)
+        ref3 = None
+        try:
+            z3 = np.load(os.path.join(REPO, "tests", "golden", "vitl_r518_4k.npz"))
+            with open(os.path.join(REPO, "tests", "golden", "vitl_r518_4k.json")) as f:
+                fr3 = json.load(f)["frames"][0]
+            ref3 = (z3["f0_post_depth"], synth.structured_frame(fr3["h"], fr3["w"], fr3["seed"]))
+        except OSError:
+            pass
+        rows3 = {}
+        for prec3 in ("bf16", "fp8"):
+            e3 = ops.Engine(cfg3, w3, h3, w3_, max_batch=1, precision=prec3, device=local_rank)
+            if prec3 == "fp8":
+                e3.calibrate(torch.cat([ops.preprocess(torch.from_numpy(synth.structured_frame(H3, W3, s_)).to(dev), 518) for s_ in (0, 5)])[:1])
+            dt3 = timed(lambda i: e3.pipeline(pool3[i & 1], p3, sp3, use_ema=False, out=out3), 5, 40)
+            row = {"value": 40 / dt3, "unit": "stereo frames/s", "ms_per_step": 1e3 * dt3 / 40}
+            if ref3 is not None:
+                post = ops.post_process_depth(e3(ops.preprocess(torch.from_numpy(ref3[1]).to(dev), 518)), p3).cpu().numpy()[0]
+                dd = np.abs(post - ref3[0])
+                row.update(depth_l1_vs_ref=float(dd.mean()), depth_max_vs_ref=float(dd.max()))
+            rows3[prec3] = row
+            e3.close()
+        result["config3_vitl_4k_full_tab"] = dict(rows3, fp8_over_bf16=rows3["fp8"]["value"] / rows3["bf16"]["value"],
+                                                  workload="DepthAnything-v2-vitl, 3840x2160 uint8 noise frames, batch 1, Depth Resolution 518 (CPU-branch ::3 "
+                                                           "decimation, model input 294x518), Full-TAB uint8 output 3840x4320 (BASELINE configs[2]); depth error vs "
+                                                           "tests/golden/vitl_r518_4k (structured frame); fp8 = non-scaled e4m3 MFMA (bf16 issue rate), per-tensor scales")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -127,10 +127,15 @@ def test_config3_vitl_fp8_4k_tab(dev, golden_dir):
             print(f"[config 3, ViT-L {prec}, 4K {mode}] depth vs reference fp32: max {d.max():.4f} mean {d.mean():.5f}; "
                   f"warp (same depth) max {lsb_same} LSB, {frac_same:.2e} > 1 LSB")
             assert lsb_same <= 1, (prec, mode, lsb_same)
-            # bounds = 1.5 x measured on MI355X (round 2: bf16 max 0.0178 / mean 0.0033; fp8 mean 0.0206 -- fp8 max is reported only)
             if prec == "bf16":
-                assert d.max() <= 0.027 and d.mean() <= 0.005, (d.max(), d.mean())
+                # reference-derived (round 4): the reference's own bf16 CPU autocast on this very frame sits max 0.0250 / mean 0.00371 from
+                # its fp32 result (tests/golden/vitl_r518_4k_bf16, model resolution; the up-sample is a convex combination)
+                zb = np.load(os.path.join(golden_dir, "vitl_r518_4k_bf16.npz"))
+                gap = np.abs(zb["f0_post_depth"].astype(np.float32) - z["f0_post_depth"])
+                assert d.max() <= gap.max() and d.mean() <= gap.mean(), (d.max(), d.mean(), gap.max(), gap.mean())
             else:
+                # e4m3 has 3 mantissa bits: no reference counterpart to derive a bound from (the reference has FP16 only); gate =
+                # 1.5 x the measured mean 0.0206 (MI355X, round 2-4) so that breakage shows; the max is reported only
                 assert d.mean() <= 0.031, d.mean()
         eng.close()
 
