@@ -428,6 +428,349 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
 }
 
 // ================================================================================================
+// conv3_head_ups_kernel: the head's conv2 with the up-sample in front of it folded in (what conv3_head_kernel<1> does), re-cut into
+// PRODUCER and CONSUMER waves.
+// What conv3_head_kernel<1> spends (profiles/r3_06, batch 32: 349 us, MFMA busy 0.23, 36 % of the LDS cycles in bank conflicts): its
+// eight waves run in lock-step -- 72 MFMAs each, then ALL of them interpolate the next tile's 18 x 18 halo (four taps x two
+// ds_read_b128 of unpacked floats + 24 packed FMAs per 8-channel chunk: ~2 900 VALU cycles and ~5 000 LDS cycles per SIMD per tile
+// against 2 304 MFMA cycles), then a barrier: the matrix pipe idles through the interpolation and the vector pipe through the MFMAs.
+// Here
+//   * waves 0-3 (one per SIMD) are consumers: 4 output rows x 16 pixels x 32 channels each, W in registers as before; an input row's
+//     fragment (row r of the wave's 6, kx, ks) is read ONCE and feeds the output rows r - 2 .. r that tap it (36 fragment reads per
+//     144 MFMAs instead of 72 per 144); per accumulator the (tap, ks) order is conv3_head_kernel's, so results are bit-identical;
+//   * waves 4-7 are producers: they build the NEXT tile's halo in the other buffer while the consumers compute, and the bilinear
+//     sample is evaluated SEPARABLY with the stand-alone kernel's own expression (bilerp1: top / bot = the horizontal lerps, then the
+//     vertical one; the horizontal results stay fp32, so every value rounds exactly as before):
+//       H pass  (13 source rows x 18 halo columns x 64 channels): two 8-byte taps straight from global memory (requested one phase
+//               ahead, L2-resident source map), one packed mul + fma per channel pair, fp32 rows into LDS  [r][x][64];
+//       V pass  (18 x 18 x 64): two ds_read_b128 of H rows, one packed mul + fma per pair, bf16, into the halo buffer.
+//     35 700 lerps per tile instead of 62 200, 2 + 2 LDS reads per 4 channels instead of 8 per 8, and every LDS access is a
+//     16-lane group on one aligned 256-byte line (conflict-free by construction);
+//   * two block barriers per tile: [consumers: input rows 0-2 (72 MFMAs) | producers: H pass]  [consumers: rows 3-5 + epilogue |
+//     producers: V pass + the H-pass loads of the tile after].
+// LDS: 2 x 51 840 B of halo + 59 904 B of H rows = 163 584 B of the 163 840.
+// ================================================================================================
+// tuning aid (-DD2S_C3U_TIMING): lane 0 of the first consumer wave / the first producer wave accumulates 100 MHz wall-clock time per
+// phase: [0] consumer phase A, [1] its wait at barrier 1, [2] phase B, [3] wait at barrier 2; [4..7] the same for the producer
+#ifdef D2S_C3U_TIMING
+__device__ unsigned long long c3u_timing[256 * 9];
+#define C3U_T(var) const long var = wall_clock64();
+#define C3U_ACC(SLOT, expr) { if ((threadIdx.x & 255) == 0 && blockIdx.x < 256) c3u_timing[blockIdx.x * 9 + (SLOT)] += (unsigned long long)(expr); }
+#else
+#define C3U_T(var) {}
+#define C3U_ACC(SLOT, expr) {}
+#endif
+__global__ void __launch_bounds__(512)
+conv3_head_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEpi e, int ntiles) {
+    KERNARG_WARM(kaw_)
+    KERNARG_WARM_END(kaw_)
+    constexpr int CPP = 8, PST = 10, TH = 16, TW = 16, HWD = TW + 2, HPX = (TH + 2) * HWD, HALO = HPX * PST;
+    constexpr int SR = 13;                                   // source rows under 18 halo rows, scales <= 0.6
+    constexpr int NPAIR = SR * HWD;                          // 234 (row, column) cells of the H buffer, row-major: cell = r * HWD + x
+    constexpr int HPL = NPAIR * CPP;                         // one PLANE of the H buffer in f32x4: [cell][chunk], plane h = channels 4 h .. 4 h + 3 of every chunk
+    constexpr int HU = (NPAIR + 31) / 32;                    // H-pass cells per producer thread (8): 32 pixel slots x 8 chunk lanes
+    constexpr int VU = (HPX + 31) / 32;                      // V-pass halo pixels per producer thread (11)
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * HALO + 2 * HPL];
+    D2S_POISON_LDS(lds, 2 * HALO + 2 * HPL)
+    f32x4* const hbuf = (f32x4*)(lds + 2 * HALO);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wid < 4;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+
+    auto tile_org = [&](int t, int& b, int& ty0, int& tx0) {
+        b = t / (tiles_y * tiles_x);
+        const int r = t - b * (tiles_y * tiles_x);
+        ty0 = (r / tiles_x) * TH; tx0 = (r % tiles_x) * TW;
+    };
+    const bool xcd_walk = (gridDim.x & 7) == 0;
+    const int xcd_ = blockIdx.x & 7, slot_ = blockIdx.x >> 3, nslot_ = gridDim.x >> 3, per_ = (ntiles + 7) >> 3;
+    auto tile_at = [&](int k) {
+        if (!xcd_walk) { const int tt = blockIdx.x + k * gridDim.x; return tt < ntiles ? tt : -1; }
+        const int j = slot_ + k * nslot_, tt = xcd_ * per_ + j;
+        return (j < per_ && tt < ntiles) ? tt : -1;
+    };
+
+    // ---------------- producer side.  Thread = (chunk pc of 8 channels, pixel slot ps of 32): a wave covers 8 consecutive cells /
+    // halo pixels x 8 chunks, so that every ds_read_b128 / ds_write_b128 service group of 16 lanes meets 16 distinct bank quads (four
+    // 128-byte runs whose cells differ by 1 and 3: MI355X_MICROARCH.md, LDS table).
+    const int ptid = tid & 255, pc = ptid & 7, ps = ptid >> 3;
+    // source map through a buffer descriptor: taps outside the image are requested past num_records and come back as zeros
+    const unsigned src_frame = (unsigned)a.Hs * a.Ws * a.C * 2u;
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.ptr), 0, (unsigned)(ntiles / (tiles_y * tiles_x)) * src_frame, 0x00020000);
+    u32x4 hv0[HU], hv1[HU];                                  // the H-pass taps of the tile in production, requested one phase ahead
+    float hw1[HU];                                           // ... and their horizontal weights
+    // Tile-invariant coordinates of this thread's work items (the per-item arithmetic that is left inside the tile loop is what the
+    // producers are bound by: one wave per SIMD, 4 cycles per instruction).  H pass: cell ps + 32 k = (row hr, column hxx) -> LDS index
+    // (ps * 8 + pc) + 256 k.  V pass: halo pixel ps + 32 k = (row vy, column vx) -> halo index (ps * 10 + pc) + 320 k.
+    int hr[HU], hx4[HU], vy4[VU], vcell[VU];
+#pragma unroll
+    for (int k = 0; k < HU; ++k) { const int cell = ps + 32 * k < NPAIR ? ps + 32 * k : NPAIR - 1; hr[k] = cell / HWD; hx4[k] = (cell - hr[k] * HWD) * 4; }
+#pragma unroll
+    for (int k = 0; k < VU; ++k) { const int p = ps + 32 * k < HPX ? ps + 32 * k : HPX - 1; const int hy = p / HWD; vy4[k] = hy * 4; vcell[k] = (p - hy * HWD) * CPP + pc; }
+    // The bilinear taps of a tile's 18 halo columns / rows are computed ONCE per wave -- lane l holds column / row l -- and every work
+    // item fetches its own through ds_bpermute_b32 (the LDS crossbar, no LDS memory): packed word = offset | step << 16 | valid << 31,
+    // and the weight w1.
+    const int tl = lane < HWD ? lane : HWD - 1;
+    // geometry of a tile, worked out once (tile_org's integer divisions are ~40 scalar instructions, and a lone wave per SIMD issues
+    // one instruction of ANY kind per 4 cycles: the producers are bound by their instruction count, scalar ones included)
+    struct TileGeo { int b, ty0, tx0, rs0; };
+    auto tile_geo = [&](int t) {
+        TileGeo g;
+        tile_org(t, g.b, g.ty0, g.tx0);
+        g.rs0 = __builtin_amdgcn_readfirstlane(linear_tap(g.ty0 > 0 ? g.ty0 - 1 : 0, a.usy, a.Hs, true).i0);
+        return g;
+    };
+    // H pass, part 1: request the two horizontal taps of cells ps + 32 k of tile t (source row rs0 + hr, halo column hxx)
+    auto h_request = [&](const TileGeo& g) {
+        const int ty0 = g.ty0, tx0 = g.tx0, rs0 = g.rs0; (void)ty0;
+        const unsigned fbase = (unsigned)g.b * src_frame + (unsigned)pc * 16u;
+        const int ix = tx0 + tl - 1;
+        const Tap tx = linear_tap(ix < 0 ? 0 : ix, a.usx, a.Ws, true);
+        const int pw = (tx.i0 * a.C * 2) | ((tx.i1 - tx.i0) * a.C * 2) << 16 | ((ix >= 0 && ix < a.Wi) ? 0 : (int)0x80000000u);    // bit 31: column outside the image
+        const int pf = __float_as_int(tx.w1);
+        const int rowb = a.Ws * a.C * 2;
+#pragma unroll
+        for (int k = 0; k < HU; ++k) {
+            const int w = __builtin_amdgcn_ds_bpermute(hx4[k], pw);
+            hw1[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(hx4[k], pf));
+            const int row = rs0 + hr[k] < a.Hs ? rs0 + hr[k] : a.Hs - 1;
+            const unsigned o0 = fbase + (unsigned)(row * rowb) + (unsigned)(w & 0xffff);
+#if defined(C3U_EXP) && (C3U_EXP & 4)
+            hv0[k] = (u32x4){o0, o0, o0, o0}; hv1[k] = (u32x4){o0, (unsigned)w, o0, o0};
+#else
+            hv0[k] = __builtin_amdgcn_raw_buffer_load_b128(rsS, w < 0 ? 0xfffffff0u : o0, 0, 0);
+            hv1[k] = __builtin_amdgcn_raw_buffer_load_b128(rsS, w < 0 ? 0xfffffff0u : o0 + (unsigned)((w >> 16) & 0x7fff), 0, 0);
+#endif
+        }
+    };
+    // H pass, part 2: top = fma(w1x, v01, w0x * v00) per channel (bilerp1's horizontal lerp), fp32, two planes of hbuf; columns outside
+    // the image hold zeros (both taps came back as zeros)
+    auto h_compute = [&]() {
+#pragma unroll
+        for (int k = 0; k < HU; ++k) {
+            const float w0 = 1.0f - hw1[k];
+            const f2_ w0x = {w0, w0}, w1x = {hw1[k], hw1[k]};
+            f32x4 o[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned p0 = hv0[k][2 * h], p1 = hv0[k][2 * h + 1], q0 = hv1[k][2 * h], q1 = hv1[k][2 * h + 1];
+                const f2_ a0 = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)}, b0 = {__uint_as_float(q0 << 16), __uint_as_float(q0 & 0xffff0000u)};
+                const f2_ a1 = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)}, b1 = {__uint_as_float(q1 << 16), __uint_as_float(q1 & 0xffff0000u)};
+#if defined(C3U_SCALAR_H)
+                // (beside the consumers' MFMAs a packed f32 instruction costs more than the two plain ones it replaces: MI355X_MICROARCH.md)
+                float t_[4];
+                asm volatile("v_mul_f32 %0, %4, %5\n\tv_mul_f32 %1, %4, %6\n\tv_mul_f32 %2, %4, %7\n\tv_mul_f32 %3, %4, %8"
+                             : "=&v"(t_[0]), "=&v"(t_[1]), "=&v"(t_[2]), "=&v"(t_[3]) : "v"(w0), "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]));
+                asm volatile("v_fmac_f32 %0, %4, %5\n\tv_fmac_f32 %1, %4, %6\n\tv_fmac_f32 %2, %4, %7\n\tv_fmac_f32 %3, %4, %8"
+                             : "+v"(t_[0]), "+v"(t_[1]), "+v"(t_[2]), "+v"(t_[3]) : "v"(hw1[k]), "v"(b0[0]), "v"(b0[1]), "v"(b1[0]), "v"(b1[1]));
+                o[h] = (f32x4){t_[0], t_[1], t_[2], t_[3]};
+                (void)w0x; (void)w1x;
+#else
+                const f2_ t0 = __builtin_elementwise_fma(w1x, b0, w0x * a0);
+                const f2_ t1 = __builtin_elementwise_fma(w1x, b1, w0x * a1);
+                o[h] = (f32x4){t0[0], t0[1], t1[0], t1[1]};
+#endif
+            }
+            if (k < HU - 1 || ps + 32 * k < NPAIR) { hbuf[ps * CPP + pc + 32 * CPP * k] = o[0]; hbuf[HPL + ps * CPP + pc + 32 * CPP * k] = o[1]; }
+        }
+    };
+    // V pass: halo pixels ps + 32 k: o = fma(w1y, bot, w0y * top) (bilerp1's vertical lerp), bf16, into halo buffer `buf`; rows outside the
+    // image: zeros
+    // Items KA .. KB - 1 of the calling thread: the producers take the first VS items of every pixel slot, the CONSUMER waves the rest
+    // after their epilogue -- they are the older waves, win the VALU arbitration against the producers on their SIMD and would
+    // otherwise wait ~40 % of a tile at the barriers (measured with -DD2S_C3U_TIMING: 1.5 of 3.5 us)
+    auto v_pass = [&](const TileGeo& g, int buf, auto kac, auto kbc) {
+        constexpr int KA = decltype(kac)::value, KB = decltype(kbc)::value;
+        const int ty0 = g.ty0, rs0 = g.rs0;
+        const int iy = ty0 + tl - 1;
+        const bool rok = iy >= 0 && iy < a.Hi;
+        const Tap ty = linear_tap(rok ? iy : 0, a.usy, a.Hs, true);
+        const int pw = ((ty.i0 - rs0) * (HWD * CPP)) | ((ty.i1 - ty.i0) * (HWD * CPP)) << 16 | (rok ? 0 : (int)0x80000000u);          // bit 31: row outside the image
+        const int pf = __float_as_int(ty.w1);
+        u32x4* const hl = lds + buf * HALO + ps * PST + pc;
+        // in batches of VB pixels: all H-row reads of a batch are requested before the first is used (the halo stores of one pixel and
+        // the reads of the next are accesses to the same array -- left in program order they serialise on the LDS latency)
+        constexpr int VB = 4;
+        static_for<(KB - KA + VB - 1) / VB>([&](auto bc) {
+            constexpr int k0 = KA + decltype(bc)::value * VB, nb = KB - k0 < VB ? KB - k0 : VB;
+            f32x4 top[nb][2], bot[nb][2];
+            float w1[nb];
+            int w[nb];
+#pragma unroll
+            for (int u = 0; u < nb; ++u) {
+                w[u] = __builtin_amdgcn_ds_bpermute(vy4[k0 + u], pw);
+                w1[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(vy4[k0 + u], pf));
+            }
+#pragma unroll
+            for (int u = 0; u < nb; ++u) {
+                const int c0 = (w[u] & 0xffff) + vcell[k0 + u], c1 = c0 + ((w[u] >> 16) & 0x7fff);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { top[u][h] = hbuf[h * HPL + c0]; bot[u][h] = hbuf[h * HPL + c1]; }
+            }
+#pragma unroll
+            for (int u = 0; u < nb; ++u) {
+                const float w0 = 1.0f - w1[u];
+                const f2_ w0y = {w0, w0}, w1y = {w1[u], w1[u]};
+                u32x4 o;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f2_ o0 = __builtin_elementwise_fma(w1y, (f2_){bot[u][h][0], bot[u][h][1]}, w0y * (f2_){top[u][h][0], top[u][h][1]});
+                    const f2_ o1 = __builtin_elementwise_fma(w1y, (f2_){bot[u][h][2], bot[u][h][3]}, w0y * (f2_){top[u][h][2], top[u][h][3]});
+                    o[2 * h] = pk_bf16(o0[0], o0[1]); o[2 * h + 1] = pk_bf16(o1[0], o1[1]);
+                }
+                if (w[u] < 0) o = (u32x4){0u, 0u, 0u, 0u};
+                if (k0 + u < VU - 1 || ps + 32 * (k0 + u) < HPX) hl[32 * PST * (k0 + u)] = o;
+            }
+        });
+    };
+#ifndef C3U_VS
+#define C3U_VS 6
+#endif
+    constexpr int VS = C3U_VS;                               // V-pass items per pixel slot that stay with the producers
+    typedef std::integral_constant<int, 0> K0_;
+    typedef std::integral_constant<int, VS> KS_;
+    typedef std::integral_constant<int, VU> KU_;
+
+    int kk = 0;
+    int t = tile_at(0);
+    if (t < 0) return;
+    // The two roles run SEPARATE loops over the same tile sequence with the same number of barriers (the hardware barrier counts
+    // waves, not program counters): in one shared loop the register allocator keeps the consumers' 144 W registers live through
+    // the producers' code (522 spilled registers, measured).
+    if (consumer) {
+        // W fragments + epilogue constants (as conv3_head_kernel)
+        u32x4 wf[9][2][2];
+        float cb[2][4], cw[2][4];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = j * 16 + fr;
+                    wf[tap][ks][j] = n < N ? *(const u32x4*)(W + (long)n * Kpad + tap * 64 + (ks * 4 + fg) * 8) : (u32x4){0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n0 = j * 16 + fg * 4;
+            if (n0 < N) { load4(e.bias + n0, cb[j]); load4(e.scale + n0, cw[j]); }
+            else { cb[j][0] = cb[j][1] = cb[j][2] = cb[j][3] = 0.f; cw[j][0] = cw[j][1] = cw[j][2] = cw[j][3] = 0.f; }
+        }
+        __syncthreads();                                       // (prologue: H rows of the first tile)
+        int tn = tile_at(++kk);
+        __syncthreads();                                       // (prologue: its halo)
+        const int cw4 = wid * 4;                               // first output row of this wave
+        const int hb0 = (cw4 * HWD + fr) * PST + fg;
+        int buf = 0;
+        for (; t >= 0;) {
+            f32x4 acc[4][2];
+            const u32x4* hp = lds + buf * HALO + hb0;
+            // input rows R0 .. R0 + 2 of the wave's six: fragment (r, kx, ks) feeds output rows i = r - ky, ky = 0 .. 2
+            auto mma_rows = [&](auto r0c) {
+                constexpr int R0 = decltype(r0c)::value;
+                static_for<3>([&](auto rc) {
+                    constexpr int r = R0 + decltype(rc)::value;
+                    static_for<3>([&](auto kxc) {
+                        constexpr int kx = decltype(kxc)::value;
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const u32x4 fa = hp[(r * HWD + kx) * PST + ks * 4];
+                            static_for<3>([&](auto kyc) {
+                                constexpr int ky = 2 - decltype(kyc)::value;
+                                constexpr int i = r - ky;
+                                if constexpr (i >= 0 && i < 4) {
+#pragma unroll
+                                    for (int j = 0; j < 2; ++j) mma_chunk(acc[i][j], wf[ky * 3 + kx][ks][j], fa, bf16_t());
+                                }
+                            });
+                        }
+                    });
+                });
+            };
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            C3U_T(u0)
+            mma_rows(std::integral_constant<int, 0>());
+            C3U_T(u1)
+            __syncthreads();
+            C3U_T(u2)
+            const int tnn = tn >= 0 ? tile_at(++kk) : -1;
+            mma_rows(std::integral_constant<int, 3>());
+            int b, ty0, tx0;
+            tile_org(t, b, ty0, tx0);
+            // depth = act(b3 + sum_n w3[n] relu(acc + bias[n])): the four lane groups of a pixel hold 8 channels each.  Summed as
+            // (g0 + g1) + (g2 + g3) like conv3_head_kernel's two xor-shuffles, but through v_permlane16_swap / v_permlane32_swap on two
+            // rows at a time: no LDS round trips, and lane group fg ends up with output row fg -- one full-wave store per tile
+            float sr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    s += fmaxf(acc[i][j][0] + cb[j][0], 0.f) * cw[j][0] + fmaxf(acc[i][j][1] + cb[j][1], 0.f) * cw[j][1] +
+                         fmaxf(acc[i][j][2] + cb[j][2], 0.f) * cw[j][2] + fmaxf(acc[i][j][3] + cb[j][3], 0.f) * cw[j][3];
+                sr[i] = s;
+            }
+            typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+            const u2_ p01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sr[0]), __float_as_uint(sr[1]), false, false);
+            const u2_ p23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sr[2]), __float_as_uint(sr[3]), false, false);
+            const float c01 = __uint_as_float(p01[0]) + __uint_as_float(p01[1]);       // rows: [r0: g0 + g1 | r1: g0 + g1 | r0: g2 + g3 | r1: g2 + g3]
+            const float c23 = __uint_as_float(p23[0]) + __uint_as_float(p23[1]);
+            const u2_ q = __builtin_amdgcn_permlane32_swap(__float_as_uint(c01), __float_as_uint(c23), false, false);
+            const float sv = __uint_as_float(q[0]) + __uint_as_float(q[1]);             // lane group fg: output row fg, pixel fr
+            {
+                const int y = ty0 + cw4 + fg, x = tx0 + fr;
+                if (y < a.Ho && x < a.Wo) ((float*)e.out)[((long)b * a.Ho + y) * a.Wo + x] = head_activation(sv + e.head_b3, e.head_max_depth);
+            }
+            if (VS < VU && tn >= 0) v_pass(tile_geo(tn), buf ^ 1, KS_(), KU_());     // this wave's share of the next tile's V pass
+            C3U_T(u3)
+            __syncthreads();                                   // tile t is read out, tile tn's halo is in place
+            C3U_T(u4)
+            C3U_ACC(0, u1 - u0) C3U_ACC(1, u2 - u1) C3U_ACC(2, u3 - u2) C3U_ACC(3, u4 - u3) C3U_ACC(8, 1)
+            buf ^= 1;
+            t = tn; tn = tnn;
+        }
+    } else {
+        TileGeo gn = tile_geo(t), gnn = gn;                    // geometry of tile tn (in production) and of the one after
+        h_request(gn);
+        h_compute();
+        __syncthreads();
+        int tn = tile_at(++kk);
+        v_pass(gn, 0, K0_(), KU_());
+        if (tn >= 0) { gn = tile_geo(tn); h_request(gn); }
+        __syncthreads();
+        int buf = 0;
+        for (; t >= 0;) {
+            C3U_T(u0)
+            if (tn >= 0) h_compute();
+            C3U_T(u1)
+            __syncthreads();                                   // H rows of tile tn are in place
+            C3U_T(u2)
+            const int tnn = tn >= 0 ? tile_at(++kk) : -1;
+            if (tn >= 0) {
+                if (tnn >= 0) { gnn = tile_geo(tnn); h_request(gnn); }     // in flight under the V pass and the barrier
+#if !(defined(C3U_EXP) && (C3U_EXP & 8))
+                v_pass(gn, buf ^ 1, K0_(), KS_());
+#endif
+                gn = gnn;
+            }
+            C3U_T(u3)
+            __syncthreads();
+            C3U_T(u4)
+            C3U_ACC(4, u1 - u0) C3U_ACC(5, u2 - u1) C3U_ACC(6, u3 - u2) C3U_ACC(7, u4 - u3)
+            buf ^= 1;
+            t = tn; tn = tnn;
+        }
+    }
+}
+
+// ================================================================================================
 // C = 128 -> N = 128 on the large maps in the batched regime (the fusion stages' residual units: 8 of the 21 convolutions at batch
 // 32, 60 % of their time): persistent 8-wave blocks, 256-pixel tiles, the W ring running on ACROSS tiles, two wave groups in
 // ping-pong.  conv3_wide_kernel<TH, TW>.
@@ -704,7 +1047,9 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
         // (the staged 13 x 13 source window holds scales <= 0.6; ReLU-on-load is not part of the interpolating loader)
         if (a.ups && (no_headups.get() || a.usy > 0.6f || a.usx > 0.6f || a.relu)) return false;
         if (dry) return true;
-        if (a.ups) hipLaunchKernelGGL((conv3_head_kernel<1>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
+        static EnvInt ups_v1{"D2S_HEADUPS_V1", 0};             // A/B aid: the lock-step kernel of round 3
+        if (a.ups && !ups_v1.get()) hipLaunchKernelGGL(conv3_head_ups_kernel, dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
+        else if (a.ups) hipLaunchKernelGGL((conv3_head_kernel<1>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         else hipLaunchKernelGGL((conv3_head_kernel<0>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         return true;
     }
@@ -751,6 +1096,13 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
 
 }  // namespace d2s
 
+#ifdef D2S_C3U_TIMING
+extern "C" int d2s_c3u_timing(unsigned long long* out, int clear) {       // out != null: read 256 x 9 counters
+    if (out) D2S_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(d2s::c3u_timing), sizeof(unsigned long long) * 256 * 9));
+    if (clear) { static unsigned long long z[256 * 9]; D2S_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d2s::c3u_timing), z, sizeof(z))); }
+    return D2S_OK;
+}
+#endif
 #ifdef D2S_C3_TIMING
 extern "C" int d2s_c3_timing(unsigned long long* out, int clear) {        // out != null: read 256 x 8 counters
     if (out) D2S_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(d2s::c3_timing), sizeof(unsigned long long) * 256 * 8));
