@@ -539,12 +539,8 @@ conv3_head_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
             hw1[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(hx4[k], pf));
             const int row = rs0 + hr[k] < a.Hs ? rs0 + hr[k] : a.Hs - 1;
             const unsigned o0 = fbase + (unsigned)(row * rowb) + (unsigned)(w & 0xffff);
-#if defined(C3U_EXP) && (C3U_EXP & 4)
-            hv0[k] = (u32x4){o0, o0, o0, o0}; hv1[k] = (u32x4){o0, (unsigned)w, o0, o0};
-#else
             hv0[k] = __builtin_amdgcn_raw_buffer_load_b128(rsS, w < 0 ? 0xfffffff0u : o0, 0, 0);
             hv1[k] = __builtin_amdgcn_raw_buffer_load_b128(rsS, w < 0 ? 0xfffffff0u : o0 + (unsigned)((w >> 16) & 0x7fff), 0, 0);
-#endif
         }
     };
     // H pass, part 2: top = fma(w1x, v01, w0x * v00) per channel (bilerp1's horizontal lerp), fp32, two planes of hbuf; columns outside
@@ -560,7 +556,7 @@ conv3_head_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
                 const unsigned p0 = hv0[k][2 * h], p1 = hv0[k][2 * h + 1], q0 = hv1[k][2 * h], q1 = hv1[k][2 * h + 1];
                 const f2_ a0 = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)}, b0 = {__uint_as_float(q0 << 16), __uint_as_float(q0 & 0xffff0000u)};
                 const f2_ a1 = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)}, b1 = {__uint_as_float(q1 << 16), __uint_as_float(q1 & 0xffff0000u)};
-#if defined(C3U_SCALAR_H)
+#if !defined(C3U_PACKED_H)
                 // (beside the consumers' MFMAs a packed f32 instruction costs more than the two plain ones it replaces: MI355X_MICROARCH.md)
                 float t_[4];
                 asm volatile("v_mul_f32 %0, %4, %5\n\tv_mul_f32 %1, %4, %6\n\tv_mul_f32 %2, %4, %7\n\tv_mul_f32 %3, %4, %8"
@@ -755,9 +751,7 @@ conv3_head_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
             const int tnn = tn >= 0 ? tile_at(++kk) : -1;
             if (tn >= 0) {
                 if (tnn >= 0) { gnn = tile_geo(tnn); h_request(gnn); }     // in flight under the V pass and the barrier
-#if !(defined(C3U_EXP) && (C3U_EXP & 8))
                 v_pass(gn, buf ^ 1, K0_(), KS_());
-#endif
                 gn = gnn;
             }
             C3U_T(u3)
@@ -1048,7 +1042,8 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
         if (a.ups && (no_headups.get() || a.usy > 0.6f || a.usx > 0.6f || a.relu)) return false;
         if (dry) return true;
         static EnvInt ups_v1{"D2S_HEADUPS_V1", 0};             // A/B aid: the lock-step kernel of round 3
-        if (a.ups && !ups_v1.get()) hipLaunchKernelGGL(conv3_head_ups_kernel, dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
+        const bool ups_fits = (long)nimg * a.Hs * a.Ws * a.C * 2 < (1L << 31);      // (the source map is read through one buffer descriptor)
+        if (a.ups && !ups_v1.get() && ups_fits) hipLaunchKernelGGL(conv3_head_ups_kernel, dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         else if (a.ups) hipLaunchKernelGGL((conv3_head_kernel<1>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         else hipLaunchKernelGGL((conv3_head_kernel<0>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         return true;
