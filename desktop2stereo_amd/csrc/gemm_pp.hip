@@ -70,6 +70,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #ifndef PP_FP8_K64
 #define PP_FP8_K64 0
 #endif
+constexpr int PP_TAIL_MAX = 64;               // tail tiles an in-kernel tail reduce can count (2 counter words each)
 constexpr int PP_STAGE = 4096;                 // 16-byte chunks per stage: (256 + 256) rows x 8 chunks
 constexpr int PP_WOFF = 2048;                  // W rows start after the 256 A rows
 
@@ -448,10 +449,95 @@ enum { PP_K_BF16 = 0, PP_K_GELU = 1, PP_K_QKV = 2, PP_K_F32 = 3,       // epilog
        PP_K_GELU_LN = 4, PP_K_QKV_LN = 5, PP_K_F32_LN = 6 };             // the same with LayerNorm folded in (consumer, consumer, producer)
 constexpr bool pp_kind_f32(int k) { return k == PP_K_F32 || k == PP_K_F32_LN; }
 
+// ---- in-kernel tail reduce (ink).  The ks K-split units of a tail tile run on CUs of ONE XCD (unit lists above) at the same time
+// (every block of the launch is resident: one per CU).  Each has just written its raw partial sums to its fp32 slab with plain
+// stores; a CU's vector L1 is write-through, so once the stores are acknowledged (vmcnt 0) the data sits in the XCD's L2, which
+// every CU of the XCD reads coherently.  The units meet at a counter that lives in the same L2 -- a NON-device-scope atomic executes
+// there, no write-back / invalidate of the L2 (the `buffer_wbl2` of an agent-scope release is what made the stream-K exchange of
+// round 2 slower than the rounding it removed) -- and then unit s sums rows [s R, (s + 1) R) of all ks slabs in slab order (the order
+// pp_tail_reduce_kernel used: results are bit-identical to the two-launch path) and runs the fused epilogue on them.  Slab loads carry
+// sc1 (they must not be served from this CU's L1, which may still hold the lines from an earlier launch ... no: the L1 is invalidated
+// at kernel start and this CU has not read them since; sc1 makes that independent of the argument).  blockIdx % 8 = XCC id is how
+// the hardware deals workgroups to XCDs (tools/chain/xcd_exchange_probe.hip checks it against HW_REG_XCC_ID and the exchange against
+// a two-kernel reduce: 0 mismatches; + 5 us for a 4 x 32 KB exchange where a second kernel costs + 12).
+// Counters: two words per tail tile at the end of the split-K workspace (arrivals, departures; zero between launches: the last
+// unit to leave resets both; the workspace belongs to one stream).
+__device__ __forceinline__ f32x4 pp_load4_sc1(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ void pp_tail_reduce_inkernel(const GemmEpi& e, float* part, size_t part_elems, int M, int N, int tm, int tn, int slab, int ks, int tid) {
+    const int tt = slab / ks, sl = slab - tt * ks;
+    unsigned* ctr = (unsigned*)(part + part_elems) - 2 * PP_TAIL_MAX + 2 * tt;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's slab stores are in L2
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const long t0 = wall_clock64();
+        while (__hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ks) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 200000000L) break;             // 2 s at 100 MHz: never hang (a unit that cannot have started means a broken launch)
+        }
+    }
+    __syncthreads();
+    const int RW = (256 + ks - 1) / ks;                              // rows per unit
+    const int r_lo = sl * RW, r_hi = r_lo + RW < 256 ? r_lo + RW : 256;
+    const int w = tid >> 6, c = (tid & 63) * 4;                      // a wave = one row of the tile (256 columns), 4 columns per lane
+    const float* base = part + (size_t)tt * ks * 65536 + c;
+    constexpr int RB = 3;                                            // rows per wave in flight
+    for (int r0 = r_lo + w; r0 < r_hi; r0 += 8 * RB) {
+        f32x4 x[RB][8];
+        float pre[RB][4];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = r0 + 8 * i;
+            const bool ok = r < r_hi && tm * 256 + r < M;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (q < ks) x[i][q] = pp_load4_sc1(base + (size_t)q * 65536 + r * 256);
+                if (e.res1) epi_res1_load<T>(e, tm * 256 + r, tn * 256 + c, pre[i]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = r0 + 8 * i, m = tm * 256 + r;
+            // (the asm loads above are invisible to the compiler's own wait counting: tie every value to the wait)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(x[i][q]));
+            if (r < r_hi && m < M) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (q < ks) { v[0] += x[i][q][0]; v[1] += x[i][q][1]; v[2] += x[i][q][2]; v[3] += x[i][q][3]; }
+                epilogue_dispatch<T>(e, m, tn * 256 + c, v, false, e.res1 ? pre[i] : nullptr);
+                if (e.stats_out) {                                   // LN producer: the wave holds the 256 columns of this row
+                    float t1 = (v[0] + v[1]) + (v[2] + v[3]), t2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+                    if ((tid & 63) == 0) ((float2*)e.stats_out)[(long)tn * M + m] = make_float2(t1, t2);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (old == (unsigned)ks - 1) {                               // everybody is past the wait: clear for the next launch
+            __hip_atomic_store(&ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctr[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 template <typename T, int KIND>
 __global__ void __launch_bounds__(512)
 gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M, int N, int K, int Kpad, GemmEpi e, int xn /* log2 */,
-               int skew_us, int tw /* whole tiles */, int ks /* K splits of the remaining tiles */, int kps /* K tiles per split */) {
+               int skew_us, int tw /* whole tiles */, int ks /* K splits of the remaining tiles */, int kps /* K tiles per split */,
+               int ink /* the K splits of a tail tile share an XCD and reduce in this kernel */) {
     constexpr int ES = (int)sizeof(T);
     constexpr int BK = 128 / ES;                                    // K elements per tile
     constexpr bool DEQ = ES == 1;                                   // e4m3 operands: the accumulator is de-quantised per column
@@ -469,9 +555,14 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     // remaining tiles.  Tile rounding: one tile per CU per round, so 294 tiles (batch 32, N = 768) would pay a whole second
     // round for 38 tiles; instead those 38 are cut into ks K ranges each (228 units, one short round) whose raw partial sums
     // go to fp32 slabs [unit][256][256] and are summed + finished by pp_tail_reduce_kernel.
+    // ink: the TILES of the tail are dealt to the XCDs (not their K-split units), so that all ks units of a tile run on CUs of one
+    // XCD and can exchange their slabs through that XCD's L2 without device-scope fences (below, "in-kernel tail reduce").
     int runA = 0, nA = 0, runB = 0, nB = 0;
     pp_run(xcd, tw, runA, nA);
-    if constexpr (pp_kind_f32(KIND)) pp_run(xcd, (tiles_m * tiles_n - tw) * ks, runB, nB);
+    if constexpr (pp_kind_f32(KIND)) {
+        if (ink) { pp_run(xcd, tiles_m * tiles_n - tw, runB, nB); runB *= ks; nB *= ks; }
+        else pp_run(xcd, (tiles_m * tiles_n - tw) * ks, runB, nB);
+    }
     const int ntl = nA + nB;
     int tl = blockIdx.x >> 3;                                        // this block's position in its XCD's unit list
     if (tl >= ntl) return;
@@ -693,7 +784,12 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         }
         PP_STAMP(stamp_ + 2)
         PP_WSTAMP(stamp_ + 2)
-        if (!more) break;
+        if (!more) {
+            // in-kernel tail reduce: a K-split unit is always the LAST unit of its block (the launcher keeps an XCD's tail units <= its
+            // CUs), so the exchange runs here, outside the persistent loop -- nothing of the loop is live any more
+            if constexpr (pp_kind_f32(KIND)) { if (ink && slab_u >= 0) pp_tail_reduce_inkernel<T>(e, e.part, e.part_elems, M, N, tm_, tn_, slab_u, ks, tid); }
+            break;
+        }
         pp_wait_vm<6 + PP_TAIL>();                  // the first six pieces of the next segment have landed
         PP_STAMP(stamp_ + 3)
         stamp_ += 4;
@@ -800,13 +896,25 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
     static const int split_pct = getenv("D2S_PP_SPLIT") ? atoi(getenv("D2S_PP_SPLIT")) : 45;
     // (only for long K loops: the slab round trip + the second launch cost ~30 us, a 12-K-tile round of proj costs 25 --
     //  measured at batch 32: FC2 164 -> 144 us, proj 65 -> 71)
-    if (pp_kind_f32(kind) && e.part && split_pct > 0 && nkt >= 24) {
+    // Round 4: the K splits of a tail tile share an XCD and are reduced inside the kernel (pp_tail_reduce_inkernel): no second launch,
+    // the exchange stays in one L2 -- which makes the split pay for the 12-K-tile proj as well (D2S_PP_INK=0: the two-launch path)
+    static EnvInt ink_on{"D2S_PP_INK", 1};
+    int ink = 0;
+    if (pp_kind_f32(kind) && e.part && split_pct > 0) {
         const int rounds = tiles / ncu, rem = tiles - rounds * ncu;
-        if (rounds >= 1 && rem > 0 && rem * 100 <= split_pct * ncu)
-            for (int s = 8; s >= 2; --s)
-                if (nkt % (2 * s) == 0 && nkt / s >= 4 && rem * s <= ncu && (size_t)rem * s * 65536 <= e.part_elems) { ks = s; kps = nkt / s; tw = tiles - rem; break; }
+        if (rounds >= 1 && rem > 0 && rem * 100 <= split_pct * ncu) {
+            static EnvInt ink_mink{"D2S_PP_INK_MINK", 24};            // fewest K tiles per output tile for which the tail is split (proj, 12 K tiles, measured at batch 32: 82 -> 86-94 us split, the slab traffic costs more than its second round)
+            if (ink_on.get() && nkt >= ink_mink.get() && rem <= PP_TAIL_MAX && (ncu & 7) == 0) {
+                const int per_xcd = cdiv(rem, 8);                     // tail tiles of the busiest XCD
+                for (int s = 8; s >= 2; --s)
+                    if (nkt % (2 * s) == 0 && per_xcd * s <= ncu / 8 && (size_t)rem * s * 65536 + 2 * PP_TAIL_MAX <= e.part_elems) { ks = s; kps = nkt / s; tw = tiles - rem; ink = 1; break; }
+            }
+            if (!ink && nkt >= 24)
+                for (int s = 8; s >= 2; --s)
+                    if (nkt % (2 * s) == 0 && nkt / s >= 4 && rem * s <= ncu && (size_t)rem * s * 65536 <= e.part_elems) { ks = s; kps = nkt / s; tw = tiles - rem; break; }
+        }
     }
-    const int list_max = cdiv(tw, 8) + (ks > 1 ? cdiv((tiles - tw) * ks, 8) : 0);      // longest XCD unit list
+    const int list_max = cdiv(tw, 8) + (ks > 1 ? (ink ? cdiv(tiles - tw, 8) * ks : cdiv((tiles - tw) * ks, 8)) : 0);      // longest XCD unit list
     const unsigned grid = 8u * (unsigned)std::max(1, std::min(ncu / 8, list_max));
     GemmEpi e1 = e;
     e1.ksplit = 1;
@@ -818,7 +926,7 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
     static const int skew_pct = getenv("D2S_PP_SKEW") ? atoi(getenv("D2S_PP_SKEW")) : 50;
     // (with a K-split tail the lists end in short units: a block without one is not half a tile "lighter")
     const int skew_us = ks > 1 ? 0 : (int)((K / (128 / (int)elem_size(precision)) * 1.5 + 8.0) * skew_pct / 100.0);
-#define PP_LAUNCH(T_, KIND_) hipLaunchKernelGGL((gemm_pp_kernel<T_, KIND_>), dim3(grid), dim3(512), 0, st, (const T_*)a.ptr, a.lda, (const T_*)W, M, N, K, Kpad, e1, lxn, skew_us, tw, ks, kps)
+#define PP_LAUNCH(T_, KIND_) hipLaunchKernelGGL((gemm_pp_kernel<T_, KIND_>), dim3(grid), dim3(512), 0, st, (const T_*)a.ptr, a.lda, (const T_*)W, M, N, K, Kpad, e1, lxn, skew_us, tw, ks, kps, ink)
     if (precision == D2S_PREC_BF16) {
         if (kind == PP_K_F32) PP_LAUNCH(bf16_t, PP_K_F32); else if (kind == PP_K_QKV) PP_LAUNCH(bf16_t, PP_K_QKV);
         else if (kind == PP_K_GELU) PP_LAUNCH(bf16_t, PP_K_GELU);
@@ -830,7 +938,7 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
     }
 #undef PP_LAUNCH
     D2S_CHECK_LAUNCH();
-    if (ks > 1) {
+    if (ks > 1 && !ink) {
         GemmEpi e2 = e;
         e2.ksplit = 1;
         const unsigned rgrid = (unsigned)(tiles - tw) * 64u;
