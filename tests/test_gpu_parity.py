@@ -606,6 +606,71 @@ def test_conv_kernel_generations_agree(dev, monkeypatch):
         ops.reload_env()
 
 
+@pytest.mark.parametrize("H,W,res,B", [(1080, 1920, 518, 5), (720, 1280, 336, 9), (1440, 2560, 518, 4), (1080, 1440, 518, 6)])
+def test_head_ups_producer_consumer_kernel_equals_lockstep(dev, monkeypatch, H, W, res, B):
+    """conv3_head_ups_kernel (round 4: producer waves interpolate the next tile's halo separably while consumer waves run the MFMAs)
+    against the round-3 lock-step loader (D2S_HEADUPS_V1=1) and the stand-alone up-sample kernel (D2S_NO_HEADUPS=1): the same bilerp1
+    expression and the same accumulation order per output, so the depth maps must be bit-identical -- at several model-input sizes
+    (ragged edge tiles, another up-sample scale), over >= 2048 head tiles so that the persistent kernels run."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS, engine_shape
+    from desktop2stereo_amd.weights import make_weights
+    cfg = MODELS["vitb"]
+    wts = make_weights(cfg, 0)
+    h, w, _ = engine_shape(H, W, res)
+    assert B * ((h + 15) // 16) * ((w + 15) // 16) >= 2048
+    x = ops.preprocess(torch.stack([_t(synth.structured_frame(H, W, 70 + s), dev) for s in range(B)]), res)
+    keys = ("D2S_HEADUPS_V1", "D2S_NO_HEADUPS")
+    outs = {}
+    try:
+        for name, env in (("default", {}), ("lockstep", {"D2S_HEADUPS_V1": "1"}), ("standalone", {"D2S_NO_HEADUPS": "1"})):
+            for k in keys:
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ops.reload_env()
+            eng = ops.Engine(cfg, wts, h, w, B, "bf16")
+            outs[name] = eng(x).cpu().numpy()
+            assert np.array_equal(outs[name], eng(x).cpu().numpy()), name            # run-to-run identical
+            eng.close()
+    finally:
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        ops.reload_env()
+    assert np.isfinite(outs["default"]).all() and float(np.abs(outs["default"]).max()) > 0
+    assert np.array_equal(outs["default"], outs["lockstep"])
+    assert np.array_equal(outs["default"], outs["standalone"])
+
+
+@pytest.mark.parametrize("B", [32, 13])
+def test_gemm_pp_in_kernel_tail_reduce_equals_two_launches(dev, monkeypatch, B):
+    """gemm_pp.hip, D2S_PP_INK: the K-split units of a tail tile exchange their slabs through their XCD's L2 and finish the tile
+    inside the kernel; the slab order is pp_tail_reduce_kernel's, so the engine output equals the two-launch path bit for bit
+    (batch 32: FC2's 38 tail tiles in 6 K ranges; 13: another tail), 20 repeats each (a missed arrival would show as a difference)."""
+    from desktop2stereo_amd import ops
+    from desktop2stereo_amd.config import MODELS, engine_shape
+    from desktop2stereo_amd.weights import make_weights
+    cfg = MODELS["vitb"]
+    wts = make_weights(cfg, 0)
+    h, w, _ = engine_shape(1080, 1920, 518)
+    x = torch.randn(B, 3, h, w, device=dev, generator=torch.Generator(device=dev).manual_seed(B))
+    outs = {}
+    try:
+        for ink in ("0", "1"):
+            monkeypatch.setenv("D2S_PP_INK", ink)
+            ops.reload_env()
+            eng = ops.Engine(cfg, wts, h, w, B, "bf16")
+            outs[ink] = eng(x).cpu().numpy()
+            for _ in range(20):
+                assert np.array_equal(outs[ink], eng(x).cpu().numpy()), ink
+            eng.close()
+    finally:
+        monkeypatch.delenv("D2S_PP_INK", raising=False)
+        ops.reload_env()
+    assert np.isfinite(outs["1"]).all()
+    assert np.array_equal(outs["0"], outs["1"])
+
+
 @pytest.mark.parametrize("name,model,res", [("tiny_r518", "tiny", 518), ("vits_r518", "vits", 518),
                                             ("vits_r336", "vits", 336), ("vitb_r518", "vitb", 518),
                                             ("vitl_r518_4k", "vitl", 518)])
