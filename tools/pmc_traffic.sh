@@ -10,7 +10,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $OUT/calib/$c -o calib --output-format csv -- /tmp/copy_calib > $OUT/calib_$c.log 2>&1
   for B in 1 32; do
     rocprofv3 --pmc $c -d $OUT/bench_b$B/$c -o bench --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --batch $B --also-batch 0 \
-      --no-profile --no-cpu-baseline --no-parity-class --no-parity --sink-quality 0 --ingest own > $OUT/bench_b${B}_$c.log 2>&1
+      --no-profile --no-cpu-baseline --no-parity-class --no-parity --no-config3 --sink-quality 0 --ingest own > $OUT/bench_b${B}_$c.log 2>&1
   done
 done
 ls $OUT
