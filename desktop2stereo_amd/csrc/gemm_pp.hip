@@ -70,7 +70,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #ifndef PP_FP8_K64
 #define PP_FP8_K64 0
 #endif
-constexpr int PP_TAIL_MAX = 64;               // tail tiles an in-kernel tail reduce can count (2 counter words each)
+constexpr int PP_TAIL_MAX = 64;               // tail tiles an in-kernel tail reduce can count (4 counter words each)
 constexpr int PP_STAGE = 4096;                 // 16-byte chunks per stage: (256 + 256) rows x 8 chunks
 constexpr int PP_WOFF = 2048;                  // W rows start after the 256 A rows
 
@@ -460,77 +460,104 @@ constexpr bool pp_kind_f32(int k) { return k == PP_K_F32 || k == PP_K_F32_LN; }
 // at kernel start and this CU has not read them since; sc1 makes that independent of the argument).  blockIdx % 8 = XCC id is how
 // the hardware deals workgroups to XCDs (tools/chain/xcd_exchange_probe.hip checks it against HW_REG_XCC_ID and the exchange against
 // a two-kernel reduce: 0 mismatches; + 5 us for a 4 x 32 KB exchange where a second kernel costs + 12).
-// Counters: two words per tail tile at the end of the split-K workspace (arrivals, departures; zero between launches: the last
-// unit to leave resets both; the workspace belongs to one stream).
+// Counters: four words per tail tile at the end of the split-K workspace (arrivals, claimed shares, departures; zero between
+// launches: the last unit to leave clears them; the workspace belongs to one stream).
 __device__ __forceinline__ f32x4 pp_load4_sc1(const float* p) {
     f32x4 v;
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
+// Nobody depends on a unit that is not running: a unit waits a BOUNDED time for its partners (they are its XCD's other CUs in the same
+// round of the same launch: microseconds apart) and then leaves without its share; the LAST arrival never waits, and after its own
+// rows it finishes every share nobody has claimed (atomic claim mask: each share is summed exactly once, in the same slab order
+// whoever sums it -- the result does not depend on who did).  So two launches that hold part of the chip each (two engines on two
+// streams) cannot dead-lock on each other's unscheduled blocks; they only lose the parallel reduce.
 template <typename T>
-__device__ __forceinline__ void pp_tail_reduce_inkernel(const GemmEpi& e, float* part, size_t part_elems, int M, int N, int tm, int tn, int slab, int ks, int tid) {
+__device__ __forceinline__ void pp_tail_reduce_inkernel(const GemmEpi& e, float* part, size_t part_elems, int M, int N, int tm, int tn, int slab, int ks, int tid,
+                                                        volatile unsigned* sh /* 4 words of LDS, free at this point */, bool no_wait /* test aid */) {
     const int tt = slab / ks, sl = slab - tt * ks;
-    unsigned* ctr = (unsigned*)(part + part_elems) - 2 * PP_TAIL_MAX + 2 * tt;
+    unsigned* ctr = (unsigned*)(part + part_elems) - 4 * PP_TAIL_MAX + 4 * tt;       // [0] arrivals, [1] claimed shares (bit s), [2] departures
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's slab stores are in L2
     __syncthreads();
     if (tid == 0) {
-        __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const long t0 = wall_clock64();
-        while (__hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ks) {
-            __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > 200000000L) break;             // 2 s at 100 MHz: never hang (a unit that cannot have started means a broken launch)
-        }
-    }
-    __syncthreads();
-    const int RW = (256 + ks - 1) / ks;                              // rows per unit
-    const int r_lo = sl * RW, r_hi = r_lo + RW < 256 ? r_lo + RW : 256;
-    const int w = tid >> 6, c = (tid & 63) * 4;                      // a wave = one row of the tile (256 columns), 4 columns per lane
-    const float* base = part + (size_t)tt * ks * 65536 + c;
-    constexpr int RB = 3;                                            // rows per wave in flight
-    for (int r0 = r_lo + w; r0 < r_hi; r0 += 8 * RB) {
-        f32x4 x[RB][8];
-        float pre[RB][4];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int r = r0 + 8 * i;
-            const bool ok = r < r_hi && tm * 256 + r < M;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) x[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) if (q < ks) x[i][q] = pp_load4_sc1(base + (size_t)q * 65536 + r * 256);
-                if (e.res1) epi_res1_load<T>(e, tm * 256 + r, tn * 256 + c, pre[i]);
+        const unsigned old = __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool last = old == (unsigned)ks - 1;
+        bool all = last;
+        if (!last && !no_wait) {
+            const long t0 = wall_clock64();
+            while (!(all = __hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)ks)) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t0 > 5000L) break;              // 50 us at 100 MHz
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sh[0] = all ? 1u : 0u; sh[1] = last ? 1u : 0u;
+    }
+    __syncthreads();
+    // [2] counts DEPARTURES: every unit leaves exactly once (timed out or done), and whoever leaves last clears the three words --
+    // clearing on "all shares finished" instead would let a slow owner claim its (already stolen and finished) share a second time
+    auto depart = [&]() {
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(&ctr[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == (unsigned)ks - 1) {
+                __hip_atomic_store(&ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctr[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctr[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    if (!sh[0]) { depart(); return; }                                // timed out: the last arrival takes this unit's rows
+    const bool last = sh[1] != 0;
+    const int RW = (256 + ks - 1) / ks;                              // rows per share
+    const int w = tid >> 6, c = (tid & 63) * 4;                      // a wave = one row of the tile (256 columns), 4 columns per lane
+    const float* base = part + (size_t)tt * ks * 65536 + c;
+    for (int k = 0; k < (last ? ks : 1); ++k) {
+        const int s_ = (sl + k) % ks;                                // own share first; the last arrival then sweeps the others
+        __syncthreads();                                             // (sh[2] of the previous round has been read)
+        if (tid == 0) sh[2] = (__hip_atomic_fetch_or(&ctr[1], 1u << s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> s_) & 1u;
+        __syncthreads();
+        if (sh[2]) continue;                                         // somebody else has it
+        const int r_lo = s_ * RW, r_hi = r_lo + RW < 256 ? r_lo + RW : 256;
+        constexpr int RB = 3;                                        // rows per wave in flight
+        for (int r0 = r_lo + w; r0 < r_hi; r0 += 8 * RB) {
+            f32x4 x[RB][8];
+            float pre[RB][4];
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int r = r0 + 8 * i, m = tm * 256 + r;
-            // (the asm loads above are invisible to the compiler's own wait counting: tie every value to the wait)
+            for (int i = 0; i < RB; ++i) {
+                const int r = r0 + 8 * i;
+                const bool ok = r < r_hi && tm * 256 + r < M;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(x[i][q]));
-            if (r < r_hi && m < M) {
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < 8; ++q) x[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ok) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) if (q < ks) { v[0] += x[i][q][0]; v[1] += x[i][q][1]; v[2] += x[i][q][2]; v[3] += x[i][q][3]; }
-                epilogue_dispatch<T>(e, m, tn * 256 + c, v, false, e.res1 ? pre[i] : nullptr);
-                if (e.stats_out) {                                   // LN producer: the wave holds the 256 columns of this row
-                    float t1 = (v[0] + v[1]) + (v[2] + v[3]), t2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    for (int q = 0; q < 8; ++q) if (q < ks) x[i][q] = pp_load4_sc1(base + (size_t)q * 65536 + r * 256);
+                    if (e.res1) epi_res1_load<T>(e, tm * 256 + r, tn * 256 + c, pre[i]);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
-                    if ((tid & 63) == 0) ((float2*)e.stats_out)[(long)tn * M + m] = make_float2(t1, t2);
+            for (int i = 0; i < RB; ++i) {
+                const int r = r0 + 8 * i, m = tm * 256 + r;
+                // (the asm loads above are invisible to the compiler's own wait counting: tie every value to the wait)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(x[i][q]));
+                if (r < r_hi && m < M) {
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (q < ks) { v[0] += x[i][q][0]; v[1] += x[i][q][1]; v[2] += x[i][q][2]; v[3] += x[i][q][3]; }
+                    epilogue_dispatch<T>(e, m, tn * 256 + c, v, false, e.res1 ? pre[i] : nullptr);
+                    if (e.stats_out) {                               // LN producer: the wave holds the 256 columns of this row
+                        float t1 = (v[0] + v[1]) + (v[2] + v[3]), t2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+                        if ((tid & 63) == 0) ((float2*)e.stats_out)[(long)tn * M + m] = make_float2(t1, t2);
+                    }
                 }
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (this unit's stores are out before it counts as gone)
     __syncthreads();
-    if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(&ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (old == (unsigned)ks - 1) {                               // everybody is past the wait: clear for the next launch
-            __hip_atomic_store(&ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctr[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    depart();
 }
 
 template <typename T, int KIND>
@@ -787,7 +814,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         if (!more) {
             // in-kernel tail reduce: a K-split unit is always the LAST unit of its block (the launcher keeps an XCD's tail units <= its
             // CUs), so the exchange runs here, outside the persistent loop -- nothing of the loop is live any more
-            if constexpr (pp_kind_f32(KIND)) { if (ink && slab_u >= 0) pp_tail_reduce_inkernel<T>(e, e.part, e.part_elems, M, N, tm_, tn_, slab_u, ks, tid); }
+            if constexpr (pp_kind_f32(KIND)) { if (ink && slab_u >= 0) pp_tail_reduce_inkernel<T>(e, e.part, e.part_elems, M, N, tm_, tn_, slab_u, ks, tid, (volatile unsigned*)lds, (ink & 2) != 0); }
             break;
         }
         pp_wait_vm<6 + PP_TAIL>();                  // the first six pieces of the next segment have landed
@@ -907,7 +934,7 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
             if (ink_on.get() && nkt >= ink_mink.get() && rem <= PP_TAIL_MAX && (ncu & 7) == 0) {
                 const int per_xcd = cdiv(rem, 8);                     // tail tiles of the busiest XCD
                 for (int s = 8; s >= 2; --s)
-                    if (nkt % (2 * s) == 0 && per_xcd * s <= ncu / 8 && (size_t)rem * s * 65536 + 2 * PP_TAIL_MAX <= e.part_elems) { ks = s; kps = nkt / s; tw = tiles - rem; ink = 1; break; }
+                    if (nkt % (2 * s) == 0 && per_xcd * s <= ncu / 8 && (size_t)rem * s * 65536 + 4 * PP_TAIL_MAX <= e.part_elems) { ks = s; kps = nkt / s; tw = tiles - rem; ink = ink_on.get() == 2 ? 3 : 1; break; }     // D2S_PP_INK=2 (test aid): nobody waits, the last arrival of a tile sums all of it
             }
             if (!ink && nkt >= 24)
                 for (int s = 8; s >= 2; --s)

@@ -656,7 +656,7 @@ def test_gemm_pp_in_kernel_tail_reduce_equals_two_launches(dev, monkeypatch, B):
     x = torch.randn(B, 3, h, w, device=dev, generator=torch.Generator(device=dev).manual_seed(B))
     outs = {}
     try:
-        for ink in ("0", "1"):
+        for ink in ("0", "1", "2"):                     # 2: nobody waits, the last arrival of a tile sums all its shares (the fallback path)
             monkeypatch.setenv("D2S_PP_INK", ink)
             ops.reload_env()
             eng = ops.Engine(cfg, wts, h, w, B, "bf16")
@@ -669,6 +669,7 @@ def test_gemm_pp_in_kernel_tail_reduce_equals_two_launches(dev, monkeypatch, B):
         ops.reload_env()
     assert np.isfinite(outs["1"]).all()
     assert np.array_equal(outs["0"], outs["1"])
+    assert np.array_equal(outs["0"], outs["2"])
 
 
 @pytest.mark.parametrize("name,model,res", [("tiny_r518", "tiny", 518), ("vits_r518", "vits", 518),

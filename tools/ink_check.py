@@ -17,7 +17,7 @@ bad = 0
 for B in batches:
     x = torch.randn(B, 3, h, w, device="cuda", generator=torch.Generator(device="cuda").manual_seed(B))
     outs = {}
-    for ink in ("0", "1"):
+    for ink in ("0", "1", "2"):
         os.environ["D2S_PP_INK"] = ink
         ops.reload_env()
         eng = ops.Engine(cfg, wts, h, w, B, "bf16")
@@ -35,7 +35,7 @@ for B in batches:
         print(f"batch {B} D2S_PP_INK={ink}: {t0.elapsed_time(t1) / 10:.3f} ms per forward, run-to-run differences in 30 repeats: {rep}, finite: {np.isfinite(o).all()}")
         bad += rep
         eng.close()
-    same = np.array_equal(outs["0"], outs["1"])
+    same = np.array_equal(outs["0"], outs["1"]) and np.array_equal(outs["0"], outs["2"])
     print(f"batch {B}: in-kernel == two-launch: {same}")
     bad += int(not same)
 sys.exit(1 if bad else 0)
