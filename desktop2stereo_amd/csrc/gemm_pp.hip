@@ -178,8 +178,10 @@ __device__ __forceinline__ f32x4 pp_act4(f32x4 v) {
 //   consumer (PP_EP_BF16 / PP_EP_VT): A is that raw bf16 residual, W is gamma-folded; v = rstd[m] (acc - mean[m] colsum[n]) + bias
 //     with mean / rstd from the <= 4 partials per row (the two K halves of a lane pair load two slots each).
 template <int MODE, int ACT, bool DEQ, bool RES, bool IDENT = false, bool LN = false, typename HOOK>
-__device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& e, int bm0, int bn0, int M, int grp, int wn,
-                                            int lane, u32x4* stg, float2* lnred, float* colv, HOOK&& hook) {
+__device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& e, int bm0, int bn0, int M /* rows that exist FOR THIS UNIT: a row-split tail unit clips at the end of its slice */,
+                                            int Mfull /* rows of the matrix (leading dimension of the statistics) */, int grp, int wn,
+                                            int lane, u32x4* stg, float2* lnred, float* colv, HOOK&& hook,
+                                            bool skip_dead = false /* LN producer, LAST unit of a block only (nothing counts its stores afterwards): row blocks past M are skipped */) {
 #define PP_QUAD(I, J, Q4) (f32x4){acc[I][J][4 * (Q4) + 0], acc[I][J][4 * (Q4) + 1], acc[I][J][4 * (Q4) + 2], acc[I][J][4 * (Q4) + 3]}
     const int fl = lane & 31, kg = lane >> 5;
     const int rr = lane >> 3, rc = lane & 7;
@@ -242,6 +244,9 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
         static_for<8>([&](auto pc) {
             constexpr int p = decltype(pc)::value;
             constexpr int j = LN ? (p & 1) : (p >> 2), i = LN ? (p >> 1) : (p & 3);
+            // (LN order: the row block i grows with p, so once a block lies past M every later pass does too -- a row-split tail unit
+            //  runs 2-4 of its 8 passes; the tail round is a latency chain of dependent passes, not bandwidth: 38 CUs)
+            if (LN && skip_dead && wm0 + i * 32 >= M) return;
             static_for<4>([&](auto qc) {
                 constexpr int q4 = decltype(qc)::value;
                 f32x4 v = PP_QUAD(i, j, q4);
@@ -295,7 +300,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
 #pragma unroll
                     for (int w = 1; w < 4; ++w) { const float2 u = lnred[w * 128 + row]; t.x += u.x; t.y += u.y; }
                     const int m = wm0 + row;
-                    if (m < M) ((float2*)e.stats_out)[(long)(bn0 >> 8) * M + m] = t;
+                    if (m < M) ((float2*)e.stats_out)[(long)(bn0 >> 8) * Mfull + m] = t;
                 }
             }
         }
@@ -587,7 +592,7 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     int runA = 0, nA = 0, runB = 0, nB = 0;
     pp_run(xcd, tw, runA, nA);
     if constexpr (pp_kind_f32(KIND)) {
-        if (ink) { pp_run(xcd, tiles_m * tiles_n - tw, runB, nB); runB *= ks; nB *= ks; }
+        if (ink & 1) { pp_run(xcd, tiles_m * tiles_n - tw, runB, nB); runB *= ks; nB *= ks; }
         else pp_run(xcd, (tiles_m * tiles_n - tw) * ks, runB, nB);
     }
     const int ntl = nA + nB;
@@ -717,8 +722,15 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     }
 
     // ---- this block's units.  unit j of the list -> (tile, first K tile, K tiles, slab index or -1)
+    // (ink & 4: ROW-split tail for the short-K residual launches -- proj: a tail tile is cut into ks row slices of kps rows, each unit
+    //  runs the whole K loop on the 256-row window that STARTS at its slice and stores only its slice; slab = -2 - slice)
     auto unit_of = [&](int j, int& tm, int& tn, int& k0, int& nk, int& slab) {
         if (!pp_kind_f32(KIND) || j < nA) { pp_tile_of(runA + j, tiles_m, tiles_n, xn, tm, tn); k0 = 0; nk = nkt; slab = -1; }
+        else if (ink & 4) {
+            const int u = runB + (j - nA), tt = u / ks;
+            pp_tile_of(tw + tt, tiles_m, tiles_n, xn, tm, tn);
+            k0 = 0; nk = nkt; slab = -2 - (u - tt * ks);
+        }
         else {
             const int u = runB + (j - nA), tt = u / ks;
             pp_tile_of(tw + tt, tiles_m, tiles_n, xn, tm, tn);
@@ -727,12 +739,15 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
     };
     int tm_ = 0, tn_ = 0, nkt_u = nkt, slab_u = -1;
     unit_of(tl, tm_, tn_, kt0, nkt_u, slab_u);
-    PP_SET_TILE(tm_ * 256, tn_ * 256, lane)
+    auto row0_of = [&](int tm, int slab) { return tm * 256 + (slab <= -2 ? (-2 - slab) * kps : 0); };
+    PP_SET_TILE(row0_of(tm_, slab_u), tn_ * 256, lane)
     PP_PROLOGUE()
     pp_wait_vm<6>();                                // first tile: A_m0[0], W_n0[0], W_n1[0] of this wave have landed
     bool after_epi = false;
     while (true) {
-        const int bm0 = tm_ * 256, bn0 = tn_ * 256;
+        const int bm0 = row0_of(tm_, slab_u), bn0 = tn_ * 256;
+        int Mu = M;                                  // a row-split unit stores its slice only (clipped at the end of its tile)
+        if (slab_u <= -2) { Mu = bm0 + kps < tm_ * 256 + 256 ? bm0 + kps : tm_ * 256 + 256; Mu = Mu < M ? Mu : M; }
         float zero_ = 0.f;                           // opaque: a loop-invariant zero TUPLE gets hoisted out of the persistent loop and spilled
         asm volatile("" : "+v"(zero_));
 #pragma unroll
@@ -787,34 +802,34 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         float* colv = (float*)(lds + PP_STAGE + PP_WOFF + (wn * 64 + 32) * 8 + grp * 64);
         // the next segment's first twelve pieces leave from inside the epilogue (both stages are free: the last fragment
         // read returned before the barrier above), followed by >= PP_TAIL stores of this wave
-        auto hook = [&]() { if (more) { PP_SET_TILE(ntm * 256, ntn * 256, lane_e) PP_PROLOGUE() } };
+        auto hook = [&]() { if (more) { PP_SET_TILE(row0_of(ntm, nslab), ntn * 256, lane_e) PP_PROLOGUE() } };
         {
             if constexpr (pp_kind_f32(KIND)) {
                 if (slab_u >= 0) {                  // a K split of a tail tile: raw partial sums to the unit's slab
                     GemmEpi es = el;
                     es.out = (char*)e.part + (size_t)slab_u * (65536 * 4);
                     es.ldc = 256;
-                    pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, false, true>(acc, es, 0, 0, 256, grp, wn, lane_e, stg, lnred, colv, hook);
-                } else if constexpr (KIND == PP_K_F32_LN) pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, true, false, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
-                else if (e.res1) pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
-                else pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
+                    pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, false, true>(acc, es, 0, 0, 256, 256, grp, wn, lane_e, stg, lnred, colv, hook);
+                } else if constexpr (KIND == PP_K_F32_LN) pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, true, false, true>(acc, el, bm0, bn0, Mu, M, grp, wn, lane_e, stg, lnred, colv, hook, !more);
+                else if (e.res1) pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, true>(acc, el, bm0, bn0, Mu, M, grp, wn, lane_e, stg, lnred, colv, hook);
+                else pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, Mu, M, grp, wn, lane_e, stg, lnred, colv, hook);
             }
-            else if constexpr (KIND == PP_K_GELU) pp_epilogue<PP_EP_BF16, ACT_GELU, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
-            else if constexpr (KIND == PP_K_GELU_LN) pp_epilogue<PP_EP_BF16, ACT_GELU, DEQ, false, false, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
+            else if constexpr (KIND == PP_K_GELU) pp_epilogue<PP_EP_BF16, ACT_GELU, DEQ, false>(acc, el, bm0, bn0, M, M, grp, wn, lane_e, stg, lnred, colv, hook);
+            else if constexpr (KIND == PP_K_GELU_LN) pp_epilogue<PP_EP_BF16, ACT_GELU, DEQ, false, false, true>(acc, el, bm0, bn0, M, M, grp, wn, lane_e, stg, lnred, colv, hook);
             else if constexpr (KIND == PP_K_QKV) {
-                if (bn0 >= e.qk_cols) pp_epilogue<PP_EP_VT, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
-                else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
+                if (bn0 >= e.qk_cols) pp_epilogue<PP_EP_VT, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, M, grp, wn, lane_e, stg, lnred, colv, hook);
+                else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, M, grp, wn, lane_e, stg, lnred, colv, hook);
             } else if constexpr (KIND == PP_K_QKV_LN) {
-                if (bn0 >= e.qk_cols) pp_epilogue<PP_EP_VT, ACT_NONE, DEQ, false, false, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
-                else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false, false, true>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
-            } else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, grp, wn, lane_e, stg, lnred, colv, hook);
+                if (bn0 >= e.qk_cols) pp_epilogue<PP_EP_VT, ACT_NONE, DEQ, false, false, true>(acc, el, bm0, bn0, M, M, grp, wn, lane_e, stg, lnred, colv, hook);
+                else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false, false, true>(acc, el, bm0, bn0, M, M, grp, wn, lane_e, stg, lnred, colv, hook);
+            } else pp_epilogue<PP_EP_BF16, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, M, grp, wn, lane_e, stg, lnred, colv, hook);
         }
         PP_STAMP(stamp_ + 2)
         PP_WSTAMP(stamp_ + 2)
         if (!more) {
             // in-kernel tail reduce: a K-split unit is always the LAST unit of its block (the launcher keeps an XCD's tail units <= its
             // CUs), so the exchange runs here, outside the persistent loop -- nothing of the loop is live any more
-            if constexpr (pp_kind_f32(KIND)) { if (ink && slab_u >= 0) pp_tail_reduce_inkernel<T>(e, e.part, e.part_elems, M, N, tm_, tn_, slab_u, ks, tid, (volatile unsigned*)lds, (ink & 2) != 0); }
+            if constexpr (pp_kind_f32(KIND)) { if ((ink & 1) && slab_u >= 0) pp_tail_reduce_inkernel<T>(e, e.part, e.part_elems, M, N, tm_, tn_, slab_u, ks, tid, (volatile unsigned*)lds, (ink & 2) != 0); }
             break;
         }
         pp_wait_vm<6 + PP_TAIL>();                  // the first six pieces of the next segment have landed
@@ -936,12 +951,23 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
                 for (int s = 8; s >= 2; --s)
                     if (nkt % (2 * s) == 0 && per_xcd * s <= ncu / 8 && (size_t)rem * s * 65536 + 4 * PP_TAIL_MAX <= e.part_elems) { ks = s; kps = nkt / s; tw = tiles - rem; ink = ink_on.get() == 2 ? 3 : 1; break; }     // D2S_PP_INK=2 (test aid): nobody waits, the last arrival of a tile sums all of it
             }
+            // short K loops (proj: 12 K tiles): a K split costs more in slab traffic than the round it removes (section 3.1f); cut the
+            // tail tiles by ROWS instead -- every unit repeats the (short) K loop on a window that starts at its slice and runs 1 / rs of
+            // the bandwidth-bound residual epilogue.  No exchange, same MFMA sequence per output: bit-identical.  D2S_PP_RSPLIT=0: off
+            static EnvInt rsplit_on{"D2S_PP_RSPLIT", 1};
+            if (!ink && nkt < 24 && rsplit_on.get() && rem > 0) {
+                // (measured at batch 32, 38 tail tiles: proj 82.4 us unsplit, 78.4 / 78.1 / 76.6 / 78.8 with 2 / 3 / 4 / 6 slices -- every slice
+                //  unit re-reads its whole A window and W panel, so more slices buy shorter epilogues with more fill traffic)
+                int rs = ncu / rem; if (rs > 4) rs = 4;
+                if (rsplit_on.get() > 1) rs = std::min(ncu / rem, std::min(8, rsplit_on.get()));     // (tuning aid: D2S_PP_RSPLIT=n: n slices per tile)
+                if (rs >= 2) { ks = rs; kps = cdiv(256, rs); tw = tiles - rem; ink = 4; }
+            }
             if (!ink && nkt >= 24)
                 for (int s = 8; s >= 2; --s)
                     if (nkt % (2 * s) == 0 && nkt / s >= 4 && rem * s <= ncu && (size_t)rem * s * 65536 <= e.part_elems) { ks = s; kps = nkt / s; tw = tiles - rem; break; }
         }
     }
-    const int list_max = cdiv(tw, 8) + (ks > 1 ? (ink ? cdiv(tiles - tw, 8) * ks : cdiv((tiles - tw) * ks, 8)) : 0);      // longest XCD unit list
+    const int list_max = cdiv(tw, 8) + (ks > 1 ? ((ink & 1) ? cdiv(tiles - tw, 8) * ks : cdiv((tiles - tw) * ks, 8)) : 0);      // longest XCD unit list
     const unsigned grid = 8u * (unsigned)std::max(1, std::min(ncu / 8, list_max));
     GemmEpi e1 = e;
     e1.ksplit = 1;
@@ -965,7 +991,7 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
     }
 #undef PP_LAUNCH
     D2S_CHECK_LAUNCH();
-    if (ks > 1 && !ink) {
+    if (ks > 1 && !ink) {                          // (two-launch K-split path: D2S_PP_INK=0)
         GemmEpi e2 = e;
         e2.ksplit = 1;
         const unsigned rgrid = (unsigned)(tiles - tw) * 64u;

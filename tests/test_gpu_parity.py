@@ -670,6 +670,21 @@ def test_gemm_pp_in_kernel_tail_reduce_equals_two_launches(dev, monkeypatch, B):
     assert np.isfinite(outs["1"]).all()
     assert np.array_equal(outs["0"], outs["1"])
     assert np.array_equal(outs["0"], outs["2"])
+    # the row-split tail of the short-K residual launch (proj: every slice unit repeats the K loop on a window that starts at its slice
+    # and stores its slice only; D2S_PP_RSPLIT=0: whole tiles, 6: six slices of 43 rows -- unaligned, the last one clipped at its tile's end)
+    try:
+        for rs in ("0", "6"):
+            monkeypatch.setenv("D2S_PP_RSPLIT", rs)
+            ops.reload_env()
+            eng = ops.Engine(cfg, wts, h, w, B, "bf16")
+            o = eng(x).cpu().numpy()
+            for _ in range(10):
+                assert np.array_equal(o, eng(x).cpu().numpy()), rs
+            eng.close()
+            assert np.array_equal(o, outs["1"]), rs
+    finally:
+        monkeypatch.delenv("D2S_PP_RSPLIT", raising=False)
+        ops.reload_env()
 
 
 @pytest.mark.parametrize("name,model,res", [("tiny_r518", "tiny", 518), ("vits_r518", "vits", 518),
