@@ -814,6 +814,11 @@ static int launch_t(int tile, const GemmA& a, const void* W, int M, int N, int K
             int bm = 0, bn = 0;
             small_tile_of(M, N, bm, bn);
             tile = bm == 128 ? 1281288 : (bn == 128 ? 641288 : (bm == 64 ? 64648 : 3264));     // 3264: skinny launches (batch 1, N = 768)
+            // long-K implicit convolutions (tap 3's stride-2 768 -> 768: K = 6 912) from ~300 tiles of 128 x 128: the 64 x 128 tile falls off a
+            // cliff there (batch 28: 130 us, batch 32: 188 us for 1.14 x the work) where the 128 x 128 tile stays at 128-134 us at every batch from
+            // 16 to 32 -- below 300 tiles the smaller tile is 5-15 % faster.  D2S_CONV_B128: the threshold
+            static EnvInt conv_b128{"D2S_CONV_B128", 300};
+            if (a.mode == A_CONV3 && K >= 4096 && (long)cdiv(M, 128) * cdiv(N, 128) >= conv_b128.get()) tile = 1281288;
         }
     }
     // Latency regime (batch 1-2: every block of the launch is resident at once, 1-2 per CU).  In-kernel stamps (tools/glds_timeline.py)
