@@ -948,7 +948,8 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
             static EnvInt ink_mink{"D2S_PP_INK_MINK", 24};            // fewest K tiles per output tile for which the tail is split (proj, 12 K tiles, measured at batch 32: 82 -> 86-94 us split, the slab traffic costs more than its second round)
             if (ink_on.get() && nkt >= ink_mink.get() && rem <= PP_TAIL_MAX && (ncu & 7) == 0) {
                 const int per_xcd = cdiv(rem, 8);                     // tail tiles of the busiest XCD
-                for (int s = 8; s >= 2; --s)
+                static EnvInt ink_ks{"D2S_PP_INK_KS", 8};             // tuning aid: most K ranges per tail tile
+                for (int s = std::min(8, ink_ks.get()); s >= 2; --s)
                     if (nkt % (2 * s) == 0 && per_xcd * s <= ncu / 8 && (size_t)rem * s * 65536 + 4 * PP_TAIL_MAX <= e.part_elems) { ks = s; kps = nkt / s; tw = tiles - rem; ink = ink_on.get() == 2 ? 3 : 1; break; }     // D2S_PP_INK=2 (test aid): nobody waits, the last arrival of a tile sums all of it
             }
             // short K loops (proj: 12 K tiles): a K split costs more in slab traffic than the round it removes (section 3.1f); cut the
