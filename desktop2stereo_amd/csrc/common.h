@@ -37,6 +37,7 @@ struct KernargWarm { int d0, d1, d2, d3, d4, d5; };
 #ifdef D2S_NO_KERNARG_WARM                       // (A/B builds)
 #define KERNARG_WARM(ka) {}
 #define KERNARG_WARM_END(ka) {}
+#define KERNARG_WARM_BYTES 0                     // (nothing is read: the size asserts beside the kernels hold trivially)
 #else
 #define KERNARG_WARM(ka)                                                                                              \
     KernargWarm ka;                                                                                                   \

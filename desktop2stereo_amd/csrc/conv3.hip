@@ -1042,7 +1042,9 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
         if (a.ups && (no_headups.get() || a.usy > 0.6f || a.usx > 0.6f || a.relu)) return false;
         if (dry) return true;
         static EnvInt ups_v1{"D2S_HEADUPS_V1", 0};             // A/B aid: the lock-step kernel of round 3
-        const bool ups_fits = (long)nimg * a.Hs * a.Ws * a.C * 2 < (1L << 31);      // (the source map is read through one buffer descriptor)
+        // (the source map is read through one buffer descriptor; a tap's source-column byte offset travels in the low 16 bits of the
+        //  bpermute word of h_request: a source row must stay within 64 KiB, i.e. Ws <= 512 at C = 64 -- wider maps take <1>)
+        const bool ups_fits = (long)nimg * a.Hs * a.Ws * a.C * 2 < (1L << 31) && (long)a.Ws * a.C * 2 <= 65536;
         if (a.ups && !ups_v1.get() && ups_fits) hipLaunchKernelGGL(conv3_head_ups_kernel, dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         else if (a.ups) hipLaunchKernelGGL((conv3_head_kernel<1>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         else hipLaunchKernelGGL((conv3_head_kernel<0>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);

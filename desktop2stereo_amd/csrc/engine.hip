@@ -854,11 +854,12 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
     size_t scr_elems = std::max({(size_t)64 * gh * gw * F, (size_t)h * w * (F / 2), (size_t)h * w * d.head_hidden}) * B;
     for (int i = 0; i < 5; ++i) RC(dev_alloc(e, &e->scr[i], scr_elems * es));
     e->splitk_elems = (size_t)B * 16 * e->fH[2] * e->fW[2] * std::max(F, d.neck[3]);
-    RC(dev_alloc(e, (void**)&e->splitk_ws, e->splitk_elems * 4, true));      // (zeroed: the ping-pong kernel keeps its tail counters at the end)
+    // (+ GEMM_PART_CTR_WORDS zeroed words BEHIND the partials: the ping-pong kernel's tail counters, which no split-K launch can reach)
+    RC(dev_alloc(e, (void**)&e->splitk_ws, (e->splitk_elems + GEMM_PART_CTR_WORDS) * 4, true));
     // side stream of the neck branches (D2S_NO_OVERLAP=1 keeps everything on the caller's stream)
     for (int i = 0; i < 3; ++i) RC(dev_alloc(e, &e->r1[i], (size_t)B * e->fH[i] * e->fW[i] * F * es));
     RC(dev_alloc(e, &e->r1tmp, (size_t)B * e->fH[0] * e->fW[0] * F * es));
-    RC(dev_alloc(e, (void**)&e->splitk_ws_side, e->splitk_elems * 4, true));
+    RC(dev_alloc(e, (void**)&e->splitk_ws_side, (e->splitk_elems + GEMM_PART_CTR_WORDS) * 4, true));
     {
         const char* no = getenv("D2S_NO_OVERLAP");
         e->overlap = !(no && atoi(no) != 0);

@@ -31,6 +31,7 @@ struct GemmA {
     float usy, usx;       // linear_scale(Hs, Hi, true), linear_scale(Ws, Wi, true)
 };
 
+constexpr int GEMM_PART_CTR_WORDS = 256;   // counter words behind GemmEpi::part's part_elems partials (gemm_pp.hip: 4 per tail tile)
 struct GemmEpi {
     void* out;
     int out_type;         // OUT_T: same type as the operands; OUT_F32
@@ -48,7 +49,8 @@ struct GemmEpi {
     // MAP_QKV: row-major [M, 3D] for q | k; the v third goes TRANSPOSED to vt[B, heads, 64, npad]
     // (m = b*ntok + t, n - 2D = h*64 + d) so the attention kernel reads V^T rows with 16-byte chunks.
     void* vt; int ntok, npad, qk_cols, heads;
-    // split-K workspace (optional): fp32 partials [ksplit][M][N]; ksplit is chosen by the launcher
+    // split-K workspace (optional): fp32 partials [ksplit][M][N]; ksplit is chosen by the launcher.  The owner allocates
+    // part_elems + GEMM_PART_CTR_WORDS words: the words behind the partials are gemm_pp's tail-tile counters (zero between launches)
     float* part; size_t part_elems; int ksplit;
     // MAP_HEAD: out = float depth[M]; bias = conv2 bias, scale = conv3 weights [N], head_b3 = conv3 bias
     float head_b3;

@@ -78,6 +78,9 @@ template <int CPR> __device__ __forceinline__ int swz_row(int r) { return CPR ==
 // (An intra-block split-K variant -- several wave groups per block, each running the pipeline over every KG-th K tile,
 // accumulators summed through LDS -- was built and swept at batch 1: the batch-1 launches are L2->LDS-bandwidth-bound
 // (~10 TB/s aggregate), not latency-bound; it won 9 % on FC2 in isolation and lost 2 % in the pipeline.  Removed.)
+// both kernels of this file that warm their argument lines (KERNARG_WARM, common.h: one dword of every 64-byte line up to 0x140) carry
+// at least a GemmA and a GemmEpi by value behind >= 8 bytes of scalars
+static_assert(sizeof(GemmA) + sizeof(GemmEpi) + 8 >= KERNARG_WARM_BYTES, "KERNARG_WARM reads past the kernarg segment");
 template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, int STG = 0>
 __global__ void __launch_bounds__(64 * WM * WN)
 gemm_glds_kernel(const T* __restrict__ W, const void* a_ptr, long a_lda, int M, int N, int K, int Kpad, int xn, GemmA a, GemmEpi e) {

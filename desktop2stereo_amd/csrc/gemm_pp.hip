@@ -70,7 +70,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #ifndef PP_FP8_K64
 #define PP_FP8_K64 0
 #endif
-constexpr int PP_TAIL_MAX = 64;               // tail tiles an in-kernel tail reduce can count (4 counter words each)
+constexpr int PP_TAIL_MAX = GEMM_PART_CTR_WORDS / 4;   // tail tiles an in-kernel tail reduce can count (4 counter words each, BEHIND the part_elems partials: gemm.h)
+constexpr int PP_AUX_SC0_SC1 = 0x11;          // buffer-instruction cache policy on gfx950: bit 0 = sc0, bit 4 = sc1 (write-through / system scope)
 constexpr int PP_STAGE = 4096;                 // 16-byte chunks per stage: (256 + 256) rows x 8 chunks
 constexpr int PP_WOFF = 2048;                  // W rows start after the 256 A rows
 
@@ -259,7 +260,9 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
                 const int row = r * 8 + rr;
                 f32x4 x = __builtin_bit_cast(f32x4, stg[row * 8 + (rc ^ (row & 7))]);
                 if constexpr (RES) x += res[p % PP_RING][r];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rsO, vo + ((i * 32 + r * 8) * ldc + j * 32) * 4u, 0, 0);
+                // (IDENT = a K-split unit's slab: written through, sc0 sc1, so the partner units that sum it -- pp_tail_reduce_inkernel --
+                //  read it coherently wherever they run; the other kinds keep their lines in the XCD's L2 for the next launch)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rsO, vo + ((i * 32 + r * 8) * ldc + j * 32) * 4u, 0, IDENT ? PP_AUX_SC0_SC1 : 0);
                 if constexpr (LN) {
                     typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
                     const u32x2_ t = {pk_bf16(x[0], x[1]), pk_bf16(x[2], x[3])};
@@ -454,19 +457,18 @@ enum { PP_K_BF16 = 0, PP_K_GELU = 1, PP_K_QKV = 2, PP_K_F32 = 3,       // epilog
        PP_K_GELU_LN = 4, PP_K_QKV_LN = 5, PP_K_F32_LN = 6 };             // the same with LayerNorm folded in (consumer, consumer, producer)
 constexpr bool pp_kind_f32(int k) { return k == PP_K_F32 || k == PP_K_F32_LN; }
 
-// ---- in-kernel tail reduce (ink).  The ks K-split units of a tail tile run on CUs of ONE XCD (unit lists above) at the same time
-// (every block of the launch is resident: one per CU).  Each has just written its raw partial sums to its fp32 slab with plain
-// stores; a CU's vector L1 is write-through, so once the stores are acknowledged (vmcnt 0) the data sits in the XCD's L2, which
-// every CU of the XCD reads coherently.  The units meet at a counter that lives in the same L2 -- a NON-device-scope atomic executes
-// there, no write-back / invalidate of the L2 (the `buffer_wbl2` of an agent-scope release is what made the stream-K exchange of
-// round 2 slower than the rounding it removed) -- and then unit s sums rows [s R, (s + 1) R) of all ks slabs in slab order (the order
-// pp_tail_reduce_kernel used: results are bit-identical to the two-launch path) and runs the fused epilogue on them.  Slab loads carry
-// sc1 (they must not be served from this CU's L1, which may still hold the lines from an earlier launch ... no: the L1 is invalidated
-// at kernel start and this CU has not read them since; sc1 makes that independent of the argument).  blockIdx % 8 = XCC id is how
-// the hardware deals workgroups to XCDs (tools/chain/xcd_exchange_probe.hip checks it against HW_REG_XCC_ID and the exchange against
-// a two-kernel reduce: 0 mismatches; + 5 us for a 4 x 32 KB exchange where a second kernel costs + 12).
-// Counters: four words per tail tile at the end of the split-K workspace (arrivals, claimed shares, departures; zero between
-// launches: the last unit to leave clears them; the workspace belongs to one stream).
+// ---- in-kernel tail reduce (ink).  The ks K-split units of a tail tile run at the same time (every block of the launch is resident:
+// one per CU) and -- for speed only -- on CUs of ONE XCD (unit lists above).  The exchange itself is placement-independent (round 5,
+// ADVICE r4): a unit writes its raw partial sums to its fp32 slab with WRITE-THROUGH stores (sc0 sc1: the bytes leave the XCD's L2
+// for the fabric, pp_epilogue's IDENT path), waits for their acknowledgement (vmcnt 0), and counts itself with an AGENT-scope atomic;
+// whoever sums a share reads the slabs with sc1 loads (never served from a CU's L1) -- MI355X_MICROARCH.md's valid form
+// "{sc0 sc1 stores, sc1 loads, agent atomics}", no buffer_wbl2 / buffer_inv of a whole L2 (the `buffer_wbl2` of an agent-scope
+// release fence is what made the stream-K exchange of round 2 slower than the rounding it removed).  Unit s sums rows
+// [s R, (s + 1) R) of all ks slabs in slab order (the order pp_tail_reduce_kernel uses: bit-identical to the two-launch path) and
+// runs the fused epilogue on them.  Round 4 did the same with plain stores + workgroup-scope atomics, correct only while all ks
+// units really shared an L2 (blockIdx % 8 = XCC id under the default partition mode, tools/chain/xcd_exchange_probe.hip).
+// Counters: four words per tail tile in the engine's own counter block behind the split-K workspace (arrivals, claimed shares,
+// departures; zero between launches: the last unit to leave clears them; the workspace belongs to one stream).
 __device__ __forceinline__ f32x4 pp_load4_sc1(const float* p) {
     f32x4 v;
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
@@ -481,11 +483,11 @@ template <typename T>
 __device__ __forceinline__ void pp_tail_reduce_inkernel(const GemmEpi& e, float* part, size_t part_elems, int M, int N, int tm, int tn, int slab, int ks, int tid,
                                                         volatile unsigned* sh /* 4 words of LDS, free at this point */, bool no_wait /* test aid */) {
     const int tt = slab / ks, sl = slab - tt * ks;
-    unsigned* ctr = (unsigned*)(part + part_elems) - 4 * PP_TAIL_MAX + 4 * tt;       // [0] arrivals, [1] claimed shares (bit s), [2] departures
+    unsigned* ctr = (unsigned*)(part + part_elems) + 4 * tt;       // [0] arrivals, [1] claimed shares (bit s), [2] departures
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's slab stores are in L2
     __syncthreads();
     if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned old = __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool last = old == (unsigned)ks - 1;
         bool all = last;
         if (!last && !no_wait) {
@@ -502,7 +504,7 @@ __device__ __forceinline__ void pp_tail_reduce_inkernel(const GemmEpi& e, float*
     // clearing on "all shares finished" instead would let a slow owner claim its (already stolen and finished) share a second time
     auto depart = [&]() {
         if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(&ctr[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned old = __hip_atomic_fetch_add(&ctr[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == (unsigned)ks - 1) {
                 __hip_atomic_store(&ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&ctr[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -518,7 +520,7 @@ __device__ __forceinline__ void pp_tail_reduce_inkernel(const GemmEpi& e, float*
     for (int k = 0; k < (last ? ks : 1); ++k) {
         const int s_ = (sl + k) % ks;                                // own share first; the last arrival then sweeps the others
         __syncthreads();                                             // (sh[2] of the previous round has been read)
-        if (tid == 0) sh[2] = (__hip_atomic_fetch_or(&ctr[1], 1u << s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> s_) & 1u;
+        if (tid == 0) sh[2] = (__hip_atomic_fetch_or(&ctr[1], 1u << s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> s_) & 1u;
         __syncthreads();
         if (sh[2]) continue;                                         // somebody else has it
         const int r_lo = s_ * RW, r_hi = r_lo + RW < 256 ? r_lo + RW : 256;
@@ -950,7 +952,7 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
                 const int per_xcd = cdiv(rem, 8);                     // tail tiles of the busiest XCD
                 static EnvInt ink_ks{"D2S_PP_INK_KS", 8};             // tuning aid: most K ranges per tail tile
                 for (int s = std::min(8, ink_ks.get()); s >= 2; --s)
-                    if (nkt % (2 * s) == 0 && per_xcd * s <= ncu / 8 && (size_t)rem * s * 65536 + 4 * PP_TAIL_MAX <= e.part_elems) { ks = s; kps = nkt / s; tw = tiles - rem; ink = ink_on.get() == 2 ? 3 : 1; break; }     // D2S_PP_INK=2 (test aid): nobody waits, the last arrival of a tile sums all of it
+                    if (nkt % (2 * s) == 0 && per_xcd * s <= ncu / 8 && (size_t)rem * s * 65536 <= e.part_elems) { ks = s; kps = nkt / s; tw = tiles - rem; ink = ink_on.get() == 2 ? 3 : 1; break; }     // D2S_PP_INK=2 (test aid): nobody waits, the last arrival of a tile sums all of it
             }
             // short K loops (proj: 12 K tiles): a K split costs more in slab traffic than the round it removes (section 3.1f); cut the
             // tail tiles by ROWS instead -- every unit repeats the (short) K loop on a window that starts at its slice and runs 1 / rs of

@@ -271,7 +271,9 @@ extern "C" int d2s_process_area(const uint8_t* bgr, int channels, int H0, int W0
         return D2S_OK;
     }
     dim3 grid(cdiv(w, 256), h), block(256);
-    const double sx = (double)W0 / (double)w, sy = (double)H0 / (double)h;          // resize(): scale = 1 / inv_scale = ssize / dsize
+    // cv::resize forms inv_scale = dsize / ssize first and scale = 1. / inv_scale from it (1 ulp from ssize / dsize for some sizes, which
+    // can flip the is_area_fast test below or move a cell boundary of the tables)
+    const double sx = 1.0 / ((double)w / (double)W0), sy = 1.0 / ((double)h / (double)H0);
     const int ix = (int)nearbyint(sx), iy = (int)nearbyint(sy);                      // saturate_cast<int>(double)
     const bool fast = std::abs(sx - ix) < 2.220446049250313e-16 && std::abs(sy - iy) < 2.220446049250313e-16;
     if (fast && ix == 2 && iy == 2) hipLaunchKernelGGL(process_area_kernel<2>, grid, block, 0, st, bgr, channels, H0, W0, out, h, w, sy, sx, iy, ix);

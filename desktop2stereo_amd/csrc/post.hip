@@ -253,6 +253,158 @@ shape_blur_kernel(const float* __restrict__ depth_in, const float* __restrict__ 
     }
 }
 
+// ---- round 5: the whole post-process of a few frames in ONE launch (batch <= D2S_POST_FUSE_MAXB, relative models) --------------------
+// percentile_bounds_kernel (one 1024-thread block per frame, 18 us) + shape_blur_kernel (23 us) were 45 us at the END of the batch-1
+// critical path (3.8 % of the frame) for 0.6 MB of data.  Where the time went: (i) the select's four 8-bit passes are ~20 block barriers of
+// 16 waves with single-thread sections between them; (ii) shape_blur's window loop issued one global load per iteration behind the
+// previous iteration's two powf() -- eleven dependent memory round trips per thread.  Here every block of the (8 x 128)-tile grid
+//   * requests its window pixels FIRST (<= 6 per thread, all in flight at once),
+//   * derives the frame's bounds itself while they are in flight -- the same exact order statistics (any exact select returns the same
+//     two values): range-adaptive radix select with 2048 bins per target (<= 3 passes), two alternating histogram buffers so a pass
+//     costs two barriers, nothing done by one thread alone -- redundantly in every block (the subsample is 24 KB out of L2; 185 blocks
+//     on 256 CUs: no block waits for another, no second launch),
+//   * shapes the window (16 waves share the powf work a 256-thread block did alone), blurs horizontally and vertically out of LDS with
+//     the products in shape_hblur_kernel / vblur_kernel's order: bit-identical to the separate launches.
+constexpr int PF_THREADS = 1024, PF_TR = 8, PF_TC = 128, PF_MAXR = 8, PF_BITS = 11, PF_BINS = 1 << PF_BITS;
+constexpr int PF_HR = PF_TR + 2 * PF_MAXR, PF_WR = PF_TC + 2 * PF_MAXR;
+__global__ void __launch_bounds__(PF_THREADS)
+post_fused_kernel(const float* __restrict__ depth_in, float* __restrict__ out, float* __restrict__ bounds_out, int h, int w, int step, int m, int tail,
+                  float gamma, float fg_exp, int fg_on, GaussTaps taps) {
+    constexpr int PER = SORT_N / PF_THREADS;
+    __shared__ __attribute__((aligned(16))) unsigned lds_u[2 * 2 * PF_BINS];          // two buffers x two targets; the tile planes alias them afterwards
+    __shared__ unsigned red_min[PF_THREADS / 64], red_max[PF_THREADS / 64];
+    __shared__ unsigned sel_lo[2], sel_rank[2];
+    static_assert(sizeof(float) * (PF_HR * PF_WR + PF_HR * PF_TC) <= sizeof(unsigned) * 4 * PF_BINS, "tile planes alias the histograms");
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.z, y0 = blockIdx.y * PF_TR, x0 = blockIdx.x * PF_TC;
+    const int r = taps.k / 2, WR = PF_TC + 2 * r, HR = PF_TR + 2 * r;
+    const float* src = depth_in + (long)b * h * w;
+    // (1) window pixels: wave `wid` owns window rows wid and wid + 16, lanes the columns lane, lane + 64, lane + 128
+    float raw[2][3];
+    bool inside[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ry = wid + 16 * i, rx = lane + 64 * j;
+            const int y = y0 + ry - r, x = x0 + rx - r;
+            inside[i][j] = ry < HR && rx < WR && y >= 0 && y < h && x >= 0 && x < w;
+            raw[i][j] = inside[i][j] ? src[(long)y * w + x] : 0.f;
+        }
+    // (2) the frame's subsample
+    uint32_t key[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const int idx = tid + i * PF_THREADS; key[i] = idx < m ? f2key(src[(long)idx * step]) : 0u; }
+    // both histogram buffers start at zero
+    {
+        typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+        ((u4_*)lds_u)[tid] = (u4_){0u, 0u, 0u, 0u};
+        ((u4_*)lds_u)[tid + PF_THREADS] = (u4_){0u, 0u, 0u, 0u};
+    }
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+        if (tid + i * PF_THREADS < m) { kmin = min(kmin, key[i]); kmax = max(kmax, key[i]); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o)); kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o)); }
+    if (lane == 0) { red_min[wid] = kmin; red_max[wid] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w_ = 0; w_ < PF_THREADS / 64; ++w_) { kmin = min(kmin, red_min[w_]); kmax = max(kmax, red_max[w_]); }
+    const unsigned span = kmax - kmin;
+    const int bits = span ? 32 - __clz((int)span) : 0;                  // span < 2^bits
+    int shift = bits > PF_BITS ? bits - PF_BITS : 0;
+    const bool all = tail >= m;                                         // depth.py:790-791: (min, max)
+    unsigned lo0 = kmin, lo1 = kmin, rk0 = all ? 0u : (unsigned)(tail - 1), rk1 = all ? (unsigned)(m - 1) : (unsigned)(m - tail);
+    for (int pass = 0;; ++pass) {
+        unsigned* hist = lds_u + (pass & 1) * (2 * PF_BINS);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if (tid + i * PF_THREADS < m) {
+                const unsigned d0 = key[i] - lo0, d1 = key[i] - lo1;          // (unsigned: keys below lo wrap to huge values)
+                if (key[i] >= lo0 && (d0 >> shift) < (unsigned)PF_BINS) atomicAdd(&hist[d0 >> shift], 1u);
+                if (key[i] >= lo1 && (d1 >> shift) < (unsigned)PF_BINS) atomicAdd(&hist[PF_BINS + (d1 >> shift)], 1u);
+            }
+        }
+        if (pass >= 1) {                                                // the other buffer (pass - 1's, read for the last time before the barrier behind its scan)
+            typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+            ((u4_*)(lds_u + ((pass + 1) & 1) * (2 * PF_BINS)))[tid] = (u4_){0u, 0u, 0u, 0u};
+        }
+        __syncthreads();
+        if (wid < 2) {                                                  // wave t resolves target t: 32 consecutive bins per lane
+            typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+            const u4_* hp = (const u4_*)(hist + wid * PF_BINS + 32 * lane);
+            u4_ c[8];
+            unsigned s_ = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { c[q] = hp[q]; s_ += (c[q][0] + c[q][1]) + (c[q][2] + c[q][3]); }
+            unsigned incl = s_;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            const unsigned excl = incl - s_, target = wid == 0 ? rk0 : rk1;
+            if (target >= excl && target < incl) {
+                unsigned rr = target - excl, bin = 0;
+                bool found = false;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned cnt = c[q][k];
+                        if (!found) { if (rr < cnt) { found = true; bin = 4 * q + k; } else rr -= cnt; }
+                    }
+                sel_lo[wid] = (wid == 0 ? lo0 : lo1) + ((32u * lane + bin) << shift);
+                sel_rank[wid] = rr;
+            }
+        }
+        __syncthreads();
+        lo0 = sel_lo[0]; lo1 = sel_lo[1]; rk0 = sel_rank[0]; rk1 = sel_rank[1];
+        if (shift == 0) break;
+        shift = shift > PF_BITS ? shift - PF_BITS : 0;
+    }
+    float dmin = key2f(lo0), dmax = key2f(lo1);
+    if (h * w <= 10) { dmin = 0.f; dmax = 0.f; }                     // depth.py:852-854
+    if (bounds_out && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { bounds_out[2 * b] = dmin; bounds_out[2 * b + 1] = dmax; }
+    // (3) shape the window into LDS (zero outside the image: what the two-pass form's zero padding / skipped rows see)
+    float* shp = (float*)lds_u;                  // [HR][WR]
+    float* hb = shp + HR * WR;                   // [HR][PF_TC]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ry = wid + 16 * i, rx = lane + 64 * j;
+            if (ry < HR && rx < WR) shp[ry * WR + rx] = inside[i][j] ? shape_depth(raw[i][j], dmin, dmax, gamma, fg_exp, fg_on != 0) : 0.f;
+        }
+    __syncthreads();
+    // (4) horizontal pass: rows wid, wid + 16; columns lane, lane + 64
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ry = wid + 16 * i, cx = lane + 64 * j;
+            if (ry < HR) {
+                const float* row = shp + ry * WR + cx;
+                float acc = 0.f;
+                if (taps.k >= 3) { for (int t = 0; t < taps.k; ++t) acc += taps.w[t] * row[t]; }
+                else acc = row[r];
+                hb[ry * PF_TC + cx] = acc;
+            }
+        }
+    __syncthreads();
+    // (5) vertical pass: one output per thread
+    {
+        const int ty = wid >> 1, cx = (wid & 1) * 64 + lane;
+        const int y = y0 + ty, x = x0 + cx;
+        if (y < h && x < w) {
+            float acc = 0.f;
+            for (int t = 0; t < taps.k; ++t) {
+                const int yy = y + t - r;
+                if (yy >= 0 && yy < h) acc += taps.w[t] * hb[(ty + t) * PF_TC + cx];
+            }
+            out[((long)b * h + y) * w + x] = acc;
+        }
+    }
+}
+
 // EMA over `nframes` consecutive frames (recurrence in frame order); thread per pixel.
 __global__ void __launch_bounds__(256)
 ema_kernel(float* __restrict__ depth, float* __restrict__ state, int initialised, int nframes, int hw, float wgt) {
@@ -294,12 +446,14 @@ extern "C" int d2s_post_process_to(const float* depth_in, float* depth_out, int 
     int tail = (int)nearbyint(lo_q * (m - 1)) + 1;
     if (tail < 1) tail = 1;
     if (tail > m) tail = m;
-    if (p->metric)
-        hipLaunchKernelGGL(percentile_bounds_kernel<true>, dim3(batch), dim3(SORT_THREADS), 0, st, depth, n, step, m, tail,
-                           p->subsample_cap, lo_q, bounds);
-    else
-        hipLaunchKernelGGL(percentile_bounds_kernel<false>, dim3(batch), dim3(SORT_THREADS), 0, st, depth, n, step, m, tail,
-                           p->subsample_cap, lo_q, bounds);
+    auto launch_percentile = [&]() {
+        if (p->metric)
+            hipLaunchKernelGGL(percentile_bounds_kernel<true>, dim3(batch), dim3(SORT_THREADS), 0, st, depth, n, step, m, tail,
+                               p->subsample_cap, lo_q, bounds);
+        else
+            hipLaunchKernelGGL(percentile_bounds_kernel<false>, dim3(batch), dim3(SORT_THREADS), 0, st, depth, n, step, m, tail,
+                               p->subsample_cap, lo_q, bounds);
+    };
     // Gaussian taps: k = int(3 s) | 1, sigma = 0.5 s, float32 like the reference (depth.py:746-758)
     GaussTaps taps;
     int k = ((int)(3.0f * p->aa_strength)) | 1;
@@ -321,6 +475,15 @@ extern "C" int d2s_post_process_to(const float* depth_in, float* depth_out, int 
         const size_t nb = (size_t)batch * h * w * sizeof(float);
         D2S_REQUIRE(depth_out == depth_in || i0 + nb <= o0 || o0 + nb <= i0, "d2s_post_process_to: depth_in and depth_out overlap without being equal");
     }
+    // round 5: bounds + shape + both blurs in ONE launch (relative models, few frames): post_fused_kernel
+    static EnvInt one_launch{"D2S_POST_ONE", 1};
+    if (one_launch.get() && !p->metric && depth_out != depth_in && batch <= fuse_max.get() && r <= PF_MAXR && cdiv(h, PF_TR) <= 65535 && batch <= 65535) {
+        hipLaunchKernelGGL(post_fused_kernel, dim3(cdiv(w, PF_TC), cdiv(h, PF_TR), batch), dim3(PF_THREADS), 0, st,
+                           depth, depth_out, bounds, h, w, step, m, tail, p->gamma, fg_exp, fg_on, taps);
+        D2S_CHECK_LAUNCH();
+        return D2S_OK;
+    }
+    launch_percentile();
     if (depth_out != depth_in && batch <= fuse_max.get() && sb_bytes <= 64 * 1024 && cdiv(h, SB_TR) <= 65535 && batch <= 65535) {
         hipLaunchKernelGGL(shape_blur_kernel, dim3(cdiv(w, SB_TC), cdiv(h, SB_TR), batch), dim3(256), sb_bytes, st,
                            depth, bounds, depth_out, h, w, p->gamma, fg_exp, fg_on, p->metric != 0, taps);

@@ -672,7 +672,7 @@ def _area_tab(ssize: int, dsize: int):
     """OpenCV computeResizeAreaTab (modules/imgproc/src/resize.cpp; opencv-python 4.12.0.88 is the reference's pin,
     requirements.txt:4 -- third party, not under /root/reference, cv2 is not installed in this image): the source cells
     [sx] and float32 weights each destination index dx accumulates when scale = ssize / dsize (double) is not an integer."""
-    scale = float(ssize) / float(dsize)
+    scale = 1.0 / (float(dsize) / float(ssize))          # resize(): inv_scale = dsize / ssize, scale = 1. / inv_scale (not ssize / dsize: 1 ulp apart)
     tab = []
     for dx in range(dsize):
         fsx1 = dx * scale
@@ -699,7 +699,7 @@ def resize_area_u8(img: np.ndarray, dw: int, dh: int) -> np.ndarray:
     exact float64 area integral within 1 level in tests/test_oracle_golden.py."""
     img = np.asarray(img)
     H, W, C = img.shape
-    sx, sy = W / float(dw), H / float(dh)
+    sx, sy = 1.0 / (dw / float(W)), 1.0 / (dh / float(H))      # as cv::resize forms them (inv_scale first)
     ix, iy = int(round(sx)), int(round(sy))
     if abs(sx - ix) < np.finfo(np.float64).eps and abs(sy - iy) < np.finfo(np.float64).eps:
         blk = img[: dh * iy, : dw * ix].reshape(dh, iy, dw, ix, C).astype(np.int64).sum(axis=(1, 3))
