@@ -151,17 +151,43 @@ def parity_vs_reference(ops, synth, cfg, weights, p, engines, dev):
     return out
 
 
+_PMC_CACHE = {}
+
+
+def pmc_traffic_file():
+    """profiles/pmc_traffic.json + whether it describes THIS tree: the file records the sha256 of the kernel sources its rocprofv3 --pmc
+    passes ran on (tools/pmc_traffic.sh); a different digest here means the figures are of other code and are refused."""
+    if "doc" not in _PMC_CACHE:
+        doc, src = None, {"file": "profiles/pmc_traffic.json", "commit": None, "date": None, "status": "missing"}
+        try:
+            with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+                doc = json.load(f)
+            from desktop2stereo_amd.build import kernel_sources_digest
+            here = kernel_sources_digest()
+            src.update(commit=doc.get("commit"), date=doc.get("date_utc"), kernel_sources_sha256=doc.get("kernel_sources_sha256"))
+            if doc.get("kernel_sources_sha256") == here:
+                src["status"] = "ok: separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, calibrated) of this tree's kernel sources; not collected by this run"
+            else:
+                src["status"] = "stale: the kernel sources changed since the PMC passes -- figure withheld (re-run tools/profile_round.sh)"
+                doc = None
+        except (OSError, ValueError):
+            pass
+        _PMC_CACHE["doc"], _PMC_CACHE["src"] = doc, src
+    return _PMC_CACHE["doc"], _PMC_CACHE["src"]
+
+
 def pmc_traffic(kernel_class, B, default_workload):
     """HBM-side bytes per launch from the committed PMC profile: FETCH_SIZE / WRITE_SIZE are collected in separate
     rocprofv3 --pmc passes of tools/pmc_run.sh and reduced by tools/pmc_traffic.py (FETCH_SIZE doubled per the guide's gfx950
     correction, WRITE_SIZE scaled by the calibration copy) -- they cannot be read inside this process; only for the
-    workload the profile was taken on (ViT-B bf16, Depth Resolution 518), else None."""
+    workload the profile was taken on (ViT-B bf16, Depth Resolution 518) and only while the file's kernel-source digest is this
+    tree's (pmc_traffic_file), else None."""
     if not default_workload:
         return None
+    doc, _ = pmc_traffic_file()
     try:
-        with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["traffic_bytes_per_launch"][kernel_class].get(str(B))
-    except (OSError, KeyError, ValueError):
+        return doc["traffic_bytes_per_launch"][kernel_class].get(str(B)) if doc else None
+    except KeyError:
         return None
 
 

@@ -48,7 +48,10 @@ class DibrParams(C.Structure):
                 ("search_radius", C.c_float), ("depth_tolerance", C.c_float), ("blur_radius", C.c_float),
                 ("res_w", C.c_float), ("res_h", C.c_float), ("display_mode", C.c_int32),
                 ("feather_enabled", C.c_int32), ("feather_width", C.c_float), ("corner_radius", C.c_float),
-                ("viewport", C.c_float * 4)]
+                ("viewport", C.c_float * 4), ("alpha_mode", C.c_int32)]
+
+
+DIBR_ALPHA = {"window": 0, "premultiplied": 1, "rgba": 2}      # D2S_DIBR_ALPHA_*
 
 
 # every symbol include/d2s.h declares: (restype, argtypes)

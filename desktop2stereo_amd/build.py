@@ -49,6 +49,21 @@ def _deps_mtime() -> float:
     return t
 
 
+def kernel_sources_digest() -> str:
+    """sha256 over the kernel / C-ABI sources (csrc/*.hip, *.cpp, *.h + include/*.h, names and contents, sorted): the identity of the
+    code a measurement was taken on.  profiles/pmc_traffic.json records it (tools/pmc_traffic.sh on the GPU box) and bench.py refuses
+    that file's traffic figures when the tree it runs on has a different digest."""
+    import hashlib
+    h = hashlib.sha256()
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in sorted(os.listdir(root)):
+            if f.endswith((".hip", ".cpp", ".h")):
+                h.update(f.encode())
+                with open(os.path.join(root, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
@@ -81,4 +96,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    if "--digest" in sys.argv:
+        print(kernel_sources_digest())
+    else:
+        print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))

@@ -6,7 +6,7 @@
 // texture() is exact float32 GL_LINEAR filtering with texel centres at (i+0.5)/N and GL_REPEAT wrapping (moderngl's
 // defaults; the reference sets neither, viewer.py:2385-2386).  u_resolution is never assigned in the reference
 // (viewer.py:395, 413: pixel_size = 1/0), so the resolution is a parameter here (0 -> source size).  Colours are kept
-// in 0..255; the result is colour * alpha over the black clear colour (viewer.py:1304-1305, 2679).
+// in 0..255; frag_color.a follows d2s_dibr_params.alpha_mode (the reference draws these quads with blending off: WINDOW = rgb as written).
 // Line numbers in the comments below are viewer.py.
 #include "common.h"
 #include <math.h>
@@ -23,6 +23,7 @@ struct DibrGeom {
     float half_ipd, strength, conv;
     float tol, blur, feather_w;
     int search, feather;
+    int alpha_mode;        // D2S_DIBR_ALPHA_*
     float corner_r, vpx, vpy, vpw, vph;             // u_corner_radius; u_viewport in eye-image pixels (y up)
     float w1[16], w2[16];  // exp(-i*0.15), exp(-i*0.2)
 };
@@ -151,7 +152,7 @@ __device__ void push_pull(const uint8_t* __restrict__ rgb, const float* __restri
 
 // one output pixel of one eye: FRAGMENT_SHADER.main (:533-631) -> colour * alpha
 __device__ __forceinline__ void dibr_pixel(const uint8_t* __restrict__ rgb, const float* __restrict__ dep, const DibrGeom& g,
-                                           int x, int y, int eye, float outc[3]) {
+                                           int x, int y, int eye, float outc[4]) {
     const float eye_offset = eye ? g.half_ipd : -g.half_ipd;                          // :2701, 2714
     const float sg = eye_offset > 0.f ? 1.f : (eye_offset < 0.f ? -1.f : 0.f);
     const float parx = g.c * sg, pary = g.s * sg;                                     // :540
@@ -206,8 +207,11 @@ __device__ __forceinline__ void dibr_pixel(const uint8_t* __restrict__ rgb, cons
         const float sdf = sqrtf(mx * mx + my * my) + fminf(fmaxf(dx, dy), 0.f) - g.corner_r;
         alpha = fminf(alpha, 1.0f - smoothstepf(0.f, 0.01f, sdf));
     }
+    // frag_color = (col, alpha).  The reference's quads are drawn with blending off: its window shows col as written (WINDOW);
+    // PREMULTIPLIED = col * alpha (composited over black); RGBA hands out both (d2s.h)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) outc[k] = col[k] * alpha;
+    for (int k = 0; k < 3; ++k) outc[k] = g.alpha_mode == D2S_DIBR_ALPHA_PREMULTIPLIED ? col[k] * alpha : col[k];
+    outc[3] = alpha;
 }
 
 // one thread = one output pixel of one eye.  (4 pixels per thread with packed dword stores measured SLOWER -- 113 -> 120 us
@@ -223,13 +227,18 @@ dibr_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ dep_a
     const float* dep = dep_all + (long)b * g.H * g.W;
     const bool sbs = g.mode == D2S_MODE_HALF_SBS || g.mode == D2S_MODE_FULL_SBS;
     const int ox = sbs ? eye * g.ow + x : x, oy = sbs ? y : eye * g.oh + y;
-    const long o = (((long)b * g.out_h + oy) * g.out_w + ox) * 3;
-    float c[3];
+    const int nch = g.alpha_mode == D2S_DIBR_ALPHA_RGBA ? 4 : 3;
+    const long o = (((long)b * g.out_h + oy) * g.out_w + ox) * nch;
+    float c[4];
     dibr_pixel(rgb, dep, g, x, y, eye, c);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (OUT_FMT == D2S_FMT_U8_HWC) ((uint8_t*)out_all)[o + k] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(c[k], 0, 0);
         else ((float*)out_all)[o + k] = c[k];
+    }
+    if (nch == 4) {
+        if (OUT_FMT == D2S_FMT_U8_HWC) ((uint8_t*)out_all)[o + 3] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(c[3] * 255.0f, 0, 0);
+        else ((float*)out_all)[o + 3] = c[3];
     }
 }
 
@@ -268,6 +277,8 @@ extern "C" int d2s_dibr_warp(const uint8_t* rgb, const float* depth, int batch, 
     g.search = (int)p->search_radius; g.feather = p->feather_enabled != 0;
     D2S_REQUIRE(p->corner_radius >= 0.f && p->corner_radius <= 0.5f, "corner_radius must be in [0, 0.5]");
     g.corner_r = p->corner_radius;
+    D2S_REQUIRE(p->alpha_mode >= D2S_DIBR_ALPHA_WINDOW && p->alpha_mode <= D2S_DIBR_ALPHA_RGBA, "bad alpha_mode");
+    g.alpha_mode = p->alpha_mode;
     const bool vp0 = p->viewport[2] == 0.f && p->viewport[3] == 0.f;
     D2S_REQUIRE(vp0 || (p->viewport[2] > 0.f && p->viewport[3] > 0.f), "viewport width / height must be positive (or all zero)");
     g.vpx = vp0 ? 0.f : p->viewport[0]; g.vpy = vp0 ? 0.f : p->viewport[1];

@@ -142,15 +142,24 @@ percentile_bounds_kernel(const float* __restrict__ depth, int n, int step, int m
     }
 }
 
+// x^y for x in [0, 1] on the transcendental pipe: exp2(y log2 x), v_log_f32 / v_exp_f32 (1 ulp each).  On this domain the result is
+// <= 1 and |y log2 x| is small wherever the result is not: max |error| 1.0e-7 over [0, 1] for y in {1.45, 1/1.05, 2/3, 2, 1/2} against 5.9e-8
+// for a correctly rounded powf (float64 reference, 2 M points) -- two orders below the 5e-6 the post-process is held
+// to.  ocml's powf is ~200 instructions of double-float arithmetic; every pixel takes two, and the one-launch kernel re-shapes its
+// window borders (2.7 x the pixels): 8 us of a 24 us kernel at batch 1 (rocprofv3, profiles/r5_*).  x = 0 -> 0 (y = 0 -> 1), like powf.
+__device__ __forceinline__ float pow01(float x, float y) {
+    const float r = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+    return x > 0.f ? r : (y == 0.f ? 1.f : 0.f);
+}
 __device__ __forceinline__ float shape_depth(float d, float dmin, float dmax, float gamma, float fg_exp, bool fg_on) {
     float denom = fmaxf(dmax - dmin, 1e-6f);                                      // depth.py:865
     float nrm = fminf(fmaxf((d - dmin) / denom, 0.f), 1.f);
-    float g = powf(nrm, gamma);                                                   // depth.py:775-776
+    float g = pow01(nrm, gamma);                                                  // depth.py:775-776
     g = fminf(fmaxf(g, 0.f), 1.f);                                                // depth.py:729
     if (!fg_on) return g;
     float dist = g - 0.5f;
     float sgn = dist > 0.f ? 1.f : (dist < 0.f ? -1.f : 0.f);
-    float o = 0.5f + sgn * powf(fabsf(dist), fg_exp);                             // depth.py:733-735
+    float o = 0.5f + sgn * pow01(fabsf(dist), fg_exp);                            // depth.py:733-735
     return fminf(fmaxf(o, 0.f), 1.f);
 }
 
@@ -267,6 +276,8 @@ shape_blur_kernel(const float* __restrict__ depth_in, const float* __restrict__ 
 //     the products in shape_hblur_kernel / vblur_kernel's order: bit-identical to the separate launches.
 constexpr int PF_THREADS = 1024, PF_TR = 8, PF_TC = 128, PF_MAXR = 8, PF_BITS = 11, PF_BINS = 1 << PF_BITS;
 constexpr int PF_HR = PF_TR + 2 * PF_MAXR, PF_WR = PF_TC + 2 * PF_MAXR;
+template <int KT>      // taps known at compile time (13 = the reference's default Anti-aliasing 4: the tap loops unroll and the weights stay
+                        // in SGPRs -- with a run-time count every tap is an s_load from the kernarg segment inside the loop); 0 = run-time count
 __global__ void __launch_bounds__(PF_THREADS)
 post_fused_kernel(const float* __restrict__ depth_in, float* __restrict__ out, float* __restrict__ bounds_out, int h, int w, int step, int m, int tail,
                   float gamma, float fg_exp, int fg_on, GaussTaps taps) {
@@ -277,7 +288,8 @@ post_fused_kernel(const float* __restrict__ depth_in, float* __restrict__ out, f
     static_assert(sizeof(float) * (PF_HR * PF_WR + PF_HR * PF_TC) <= sizeof(unsigned) * 4 * PF_BINS, "tile planes alias the histograms");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.z, y0 = blockIdx.y * PF_TR, x0 = blockIdx.x * PF_TC;
-    const int r = taps.k / 2, WR = PF_TC + 2 * r, HR = PF_TR + 2 * r;
+    const int nt = KT ? KT : taps.k;
+    const int r = nt / 2, WR = PF_TC + 2 * r, HR = PF_TR + 2 * r;
     const float* src = depth_in + (long)b * h * w;
     // (1) window pixels: wave `wid` owns window rows wid and wid + 16, lanes the columns lane, lane + 64, lane + 128
     float raw[2][3];
@@ -311,6 +323,9 @@ post_fused_kernel(const float* __restrict__ depth_in, float* __restrict__ out, f
     __syncthreads();
 #pragma unroll
     for (int w_ = 0; w_ < PF_THREADS / 64; ++w_) { kmin = min(kmin, red_min[w_]); kmax = max(kmax, red_max[w_]); }
+#if defined(PF_CUT) && PF_CUT == 1              // (tuning aid, tools/build_variant.sh: the kernel ends after phase PF_CUT -- timing only, results wrong)
+    if (kmin == 0x12345u) out[tid] = raw[0][0] + raw[1][2]; return;
+#endif
     const unsigned span = kmax - kmin;
     const int bits = span ? 32 - __clz((int)span) : 0;                  // span < 2^bits
     int shift = bits > PF_BITS ? bits - PF_BITS : 0;
@@ -361,6 +376,9 @@ post_fused_kernel(const float* __restrict__ depth_in, float* __restrict__ out, f
         if (shift == 0) break;
         shift = shift > PF_BITS ? shift - PF_BITS : 0;
     }
+#if defined(PF_CUT) && PF_CUT == 2
+    if (lo0 == 0x12345u) out[tid] = raw[0][0] + raw[1][2]; return;
+#endif
     float dmin = key2f(lo0), dmax = key2f(lo1);
     if (h * w <= 10) { dmin = 0.f; dmax = 0.f; }                     // depth.py:852-854
     if (bounds_out && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { bounds_out[2 * b] = dmin; bounds_out[2 * b + 1] = dmax; }
@@ -375,6 +393,9 @@ post_fused_kernel(const float* __restrict__ depth_in, float* __restrict__ out, f
             if (ry < HR && rx < WR) shp[ry * WR + rx] = inside[i][j] ? shape_depth(raw[i][j], dmin, dmax, gamma, fg_exp, fg_on != 0) : 0.f;
         }
     __syncthreads();
+#if defined(PF_CUT) && PF_CUT == 3
+    if (shp[tid] == 123.f) out[tid] = 1.f; return;
+#endif
     // (4) horizontal pass: rows wid, wid + 16; columns lane, lane + 64
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -384,19 +405,25 @@ post_fused_kernel(const float* __restrict__ depth_in, float* __restrict__ out, f
             if (ry < HR) {
                 const float* row = shp + ry * WR + cx;
                 float acc = 0.f;
-                if (taps.k >= 3) { for (int t = 0; t < taps.k; ++t) acc += taps.w[t] * row[t]; }
-                else acc = row[r];
+                if (nt >= 3) {
+#pragma unroll
+                    for (int t = 0; t < nt; ++t) acc += taps.w[t] * row[t];
+                } else acc = row[r];
                 hb[ry * PF_TC + cx] = acc;
             }
         }
     __syncthreads();
+#if defined(PF_CUT) && PF_CUT == 4
+    if (hb[tid] == 123.f) out[tid] = 1.f; return;
+#endif
     // (5) vertical pass: one output per thread
     {
         const int ty = wid >> 1, cx = (wid & 1) * 64 + lane;
         const int y = y0 + ty, x = x0 + cx;
         if (y < h && x < w) {
             float acc = 0.f;
-            for (int t = 0; t < taps.k; ++t) {
+#pragma unroll
+            for (int t = 0; t < nt; ++t) {
                 const int yy = y + t - r;
                 if (yy >= 0 && yy < h) acc += taps.w[t] * hb[(ty + t) * PF_TC + cx];
             }
@@ -478,8 +505,10 @@ extern "C" int d2s_post_process_to(const float* depth_in, float* depth_out, int 
     // round 5: bounds + shape + both blurs in ONE launch (relative models, few frames): post_fused_kernel
     static EnvInt one_launch{"D2S_POST_ONE", 1};
     if (one_launch.get() && !p->metric && depth_out != depth_in && batch <= fuse_max.get() && r <= PF_MAXR && cdiv(h, PF_TR) <= 65535 && batch <= 65535) {
-        hipLaunchKernelGGL(post_fused_kernel, dim3(cdiv(w, PF_TC), cdiv(h, PF_TR), batch), dim3(PF_THREADS), 0, st,
-                           depth, depth_out, bounds, h, w, step, m, tail, p->gamma, fg_exp, fg_on, taps);
+        if (taps.k == 13) hipLaunchKernelGGL(post_fused_kernel<13>, dim3(cdiv(w, PF_TC), cdiv(h, PF_TR), batch), dim3(PF_THREADS), 0, st,
+                                             depth, depth_out, bounds, h, w, step, m, tail, p->gamma, fg_exp, fg_on, taps);
+        else hipLaunchKernelGGL(post_fused_kernel<0>, dim3(cdiv(w, PF_TC), cdiv(h, PF_TR), batch), dim3(PF_THREADS), 0, st,
+                                depth, depth_out, bounds, h, w, step, m, tail, p->gamma, fg_exp, fg_on, taps);
         D2S_CHECK_LAUNCH();
         return D2S_OK;
     }

@@ -203,8 +203,13 @@ def post_process_depth(depth: torch.Tensor) -> torch.Tensor:
 
 
 def predict_depth(image_rgb, return_tuple=False, use_temporal_smooth: bool = True, dtype=None):
-    """HWC uint8 RGB numpy frame or CHW tensor (0..255) -> [H,W] float32 depth in [0,1] on the
-    compute device, near ~ 1 (reference depth.py:1897-2025)."""
+    """HWC uint8 RGB numpy frame or CHW tensor (0..255) -> [H,W] depth in [0,1] on the compute device, near ~ 1 (reference
+    depth.py:1897-2025).  `dtype` (reference default: DTYPE = float16 with the FP16 setting, else float32; the reference only threads it
+    through its XPU retry, depth.py:1959, its result carries the model's dtype): None / float32 return the float32 map the kernels
+    produce, float16 / bfloat16 return it cast (what an FP16 reference hands its callers); anything else is a TypeError -- never
+    silently ignored."""
+    if dtype is not None and dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        raise TypeError(f"predict_depth(dtype=...) must be torch.float32, torch.float16 or torch.bfloat16, got {dtype!r}")
     p = _state["params"]
     if isinstance(image_rgb, torch.Tensor):
         rgb_tensor = image_rgb.to(device=_device())
@@ -222,6 +227,8 @@ def predict_depth(image_rgb, return_tuple=False, use_temporal_smooth: bool = Tru
     if use_temporal_smooth:
         depth = depth_stabilizer(depth)
     depth = ops.upsample_depth(depth, h, w)
+    if dtype is not None and dtype != torch.float32:
+        depth = depth.to(dtype)
     return (depth, rgb_tensor) if return_tuple else depth
 
 

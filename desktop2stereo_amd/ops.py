@@ -267,16 +267,20 @@ def make_sbs(frames: torch.Tensor, depth: torch.Tensor, sp: SbsParams, out_fmt: 
 
 def dibr_params(ipd_uv=0.064, depth_ratio=1.0, convergence=0.0, display_mode="Full-SBS", roll=0.0, feather=False,
                 viewer_depth_strength=0.1, search_radius=12.0, depth_tolerance=0.012, blur_radius=2.5,
-                feather_width=0.02, resolution=(0.0, 0.0), corner_radius=0.0, viewport=(0.0, 0.0, 0.0, 0.0)) -> _lib.DibrParams:
+                feather_width=0.02, resolution=(0.0, 0.0), corner_radius=0.0, viewport=(0.0, 0.0, 0.0, 0.0),
+                alpha="window") -> _lib.DibrParams:
     """Uniform block of the reference's DIBR shader with the viewer's defaults (viewer.py:1333-1343, 402-411).
     corner_radius: u_corner_radius (0 desktop viewer, 0.03 OpenXR screen); viewport: u_viewport (x, y, w, h) in pixels of
-    the eye image, y up -- zeros = the eye image itself."""
+    the eye image, y up -- zeros = the eye image itself.  alpha: "window" = frag_color.rgb as the reference's window shows it
+    (its stereo quads are drawn with blending off), "premultiplied" = rgb * a, "rgba" = four channels (include/d2s.h)."""
     if display_mode not in MODE:
         raise ValueError(f"display_mode must be one of {list(MODE)}")
+    if alpha not in _lib.DIBR_ALPHA:
+        raise ValueError(f"alpha must be one of {list(_lib.DIBR_ALPHA)}")
     return _lib.DibrParams(float(ipd_uv), float(viewer_depth_strength * depth_ratio), float(convergence), float(roll),
                            float(search_radius), float(depth_tolerance), float(blur_radius), float(resolution[0]),
                            float(resolution[1]), MODE[display_mode], int(bool(feather)), float(feather_width),
-                           float(corner_radius), (C.c_float * 4)(*[float(v) for v in viewport]))
+                           float(corner_radius), (C.c_float * 4)(*[float(v) for v in viewport]), _lib.DIBR_ALPHA[alpha])
 
 
 def dibr_warp(frames: torch.Tensor, depth: torch.Tensor, dp: "_lib.DibrParams", out_u8: bool = True) -> torch.Tensor:
@@ -296,7 +300,8 @@ def dibr_warp(frames: torch.Tensor, depth: torch.Tensor, dp: "_lib.DibrParams", 
     lib = _lib.load()
     oh, ow = C.c_int(), C.c_int()
     check(lib.d2s_dibr_shape(H, W, dp.display_mode, C.byref(oh), C.byref(ow)), "d2s_dibr_shape")
-    out = torch.empty((B, oh.value, ow.value, 3), dtype=torch.uint8 if out_u8 else torch.float32, device=f.device)
+    nch = 4 if dp.alpha_mode == _lib.DIBR_ALPHA["rgba"] else 3
+    out = torch.empty((B, oh.value, ow.value, nch), dtype=torch.uint8 if out_u8 else torch.float32, device=f.device)
     _same_device(f, d, "dibr_warp")
     with _on(f.device) as st:
         check(lib.d2s_dibr_warp(_ptr(f), _ptr(d), B, H, W, C.byref(dp), _ptr(out), FMT_U8_HWC if out_u8 else FMT_F32_HWC, st),

@@ -44,3 +44,18 @@ def smooth_depth(h: int, w: int, seed: int = 0) -> np.ndarray:
         r = g.uniform(0.08, 0.2)
         d = np.where((u - cx) ** 2 + (v - cy) ** 2 < r * r, g.uniform(0.6, 1.0), d)
     return np.clip(d, 0.0, 1.0).astype(np.float32)
+
+
+def dibr_scene(h: int, w: int, seed: int, kind: str = "boxes"):
+    """(rgb uint8 [h,w,3], depth float32 [h,w] in 0..1) for the viewer-shader warp (f1): structured_frame + a smooth depth map and,
+    for kind "boxes", three near rectangles with hard edges -- disocclusions on both sides, the in-painting's work; "smooth" stays
+    under the shader's 0.04 discontinuity threshold.  The recipe behind tests/golden/dibr.npz (make_golden_dibr.py)."""
+    img = structured_frame(h, w, seed)
+    dep = (0.35 + 0.6 * smooth_depth(h, w, seed)).astype(np.float32)
+    if kind == "boxes":
+        rng = np.random.default_rng(seed)
+        for k in range(3):
+            y0, x0 = int(rng.integers(0, h * 2 // 3)), int(rng.integers(0, w * 2 // 3))
+            hh, ww = int(rng.integers(h // 8, h // 3)), int(rng.integers(w // 10, w // 3))
+            dep[y0:y0 + hh, x0:x0 + ww] = np.float32(0.05 + 0.1 * k)
+    return img, np.clip(dep, 0, 1).astype(np.float32)

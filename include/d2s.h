@@ -138,7 +138,14 @@ typedef struct d2s_dibr_params {
     float   viewport[4];       /* u_viewport = (x, y, w, h) of the eye's viewport in pixels of the eye image, y up like
                                   gl_FragCoord (viewer.py:589: the feathering is relative to it); all 0: the eye image
                                   itself, (0, 0, out_w, out_h) */
+    int32_t alpha_mode;        /* what becomes of frag_color.a (screen-edge clip :582, rounded corners :617-624), D2S_DIBR_ALPHA_*:
+                                  the reference draws its stereo quads with GL_BLEND OFF (viewer.py:1304-1307 enable it around the
+                                  overlay quad only), so its window shows frag_color.rgb as written = WINDOW (0, default);
+                                  PREMULTIPLIED (1) = rgb * a, what an alpha-compositing consumer (the OpenXR layer) shows over
+                                  black; RGBA (2) = frag_color itself, FOUR channels per pixel (rgb 0..255, a 0..255 / 0..1 for
+                                  the u8 / f32 output formats) */
 } d2s_dibr_params;
+enum { D2S_DIBR_ALPHA_WINDOW = 0, D2S_DIBR_ALPHA_PREMULTIPLIED = 1, D2S_DIBR_ALPHA_RGBA = 2 };
 
 const char* d2s_last_error(void);
 int d2s_version(void);
@@ -250,8 +257,9 @@ int d2s_sbs_shape(int H, int W, const d2s_sbs_params* p, int* out_h, int* out_w)
 /* f1: the GLSL DIBR warp with disocclusion in-painting the reference's Viewer / OpenXR modes render
  * (FRAGMENT_SHADER, viewer.py:386-631): rgb uint8 HWC [batch,H,W,3], depth float [batch,H,W] (full resolution, as
  * uploaded to tex_depth, viewer.py:2386, 2456) -> both eyes, each rendered into an H x W viewport (Half modes:
- * W/2 columns resp. H/2 rows per eye) and packed left|right (SBS) or left over right (TAB); colour * alpha over
- * black.  out_fmt: D2S_FMT_U8_HWC (round-half-even) or D2S_FMT_F32_HWC (0..255); shape from d2s_dibr_shape. */
+ * W/2 columns resp. H/2 rows per eye) and packed left|right (SBS) or left over right (TAB); three channels per pixel
+ * (four with p->alpha_mode == D2S_DIBR_ALPHA_RGBA).  out_fmt: D2S_FMT_U8_HWC (round-half-even) or D2S_FMT_F32_HWC (0..255);
+ * shape from d2s_dibr_shape.  Pinned by tests/golden/dibr.npz: the reference's shader run off-screen (make_golden_dibr.py). */
 int d2s_dibr_shape(int H, int W, int display_mode, int* out_h, int* out_w);
 int d2s_dibr_warp(const uint8_t* rgb, const float* depth, int batch, int H, int W, const d2s_dibr_params* p,
                   void* out, int out_fmt, void* stream);

@@ -1,19 +1,26 @@
 """CPU restatement of the reference's GLSL DIBR fragment shader (viewer.py:386-631): the warp with disocclusion
 in-painting that the default Viewer / OpenXR modes show.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
-PARITY UNPINNED: there is no OpenGL here, so no output of the reference's shader exists to pin this file; it follows
-the shader text line by line (line numbers below are viewer.py).  Two facts of the reference matter for anyone
-comparing with a real GL run:
+PINNED (round 5) by tests/golden/dibr.npz: the reference's own shader text compiled and run off-screen here -- OpenGL ES 3.0 on
+the SwiftShader software renderer found inside this image's `kaleido` wheel (tests/golden/gl_harness.py, make_golden_dibr.py;
+four mechanical ES patches listed there) -- and tests/test_oracle_golden.py holds this file to those renders.  What a reader
+comparing with a GL run needs to know:
 
   * ``u_resolution`` is declared (viewer.py:395) but never assigned anywhere in the reference, so
     ``pixel_size = 1.0 / u_resolution`` (viewer.py:413) is a division by the default 0 -- undefined in the reference
     itself.  This restatement (and the HIP kernel) take the resolution as a parameter, default = source size, which is
-    what every ``pixel_size`` use in the shader evidently intends (offsets in texels).
+    what every ``pixel_size`` use in the shader evidently intends (offsets in texels); the fixtures set the uniform to that.
   * texture() is restated as exact float32 GL_LINEAR filtering with texel centres at (i+0.5)/N and GL_REPEAT wrapping
-    (moderngl's defaults; viewer.py:2385-2386 sets no filter / repeat flags); real GPUs filter with ~8-bit weights.
+    (moderngl's defaults; viewer.py:2385-2386 sets no filter / repeat flags); GL implementations filter RGB8 with ~8-bit
+    sub-texel weights, so a render differs from this file by up to ~1 level of 255 (measured against SwiftShader: max 0.73,
+    mean 0.016 on a scene with hard depth edges).
+  * BLENDING: the reference enables GL_BLEND only around its overlay quad (viewer.py:1304-1307) -- the stereo quads are drawn
+    with blending OFF, so the window shows ``frag_color.rgb`` as written and ``frag_color.a`` (screen-edge clip, rounded
+    corners) lands in the framebuffer's alpha channel, which a desktop window ignores; an alpha-compositing consumer (the
+    OpenXR layer) shows rgb * a over what lies behind.  ``dibr_eye(rgba=True)`` returns both, un-multiplied; the default
+    return value is rgb * a (composited over black), kept for the round 1-4 tests.
 
-Colours are carried in 0..255 instead of GL's normalised 0..1 (every colour operation is linear).  The framebuffer
-result is colour * alpha over the black clear colour (blend SRC_ALPHA / ONE_MINUS_SRC_ALPHA, viewer.py:1304-1305, 2679).
+Colours are carried in 0..255 instead of GL's normalised 0..1 (every colour operation is linear).
 """
 from __future__ import annotations
 
@@ -94,7 +101,7 @@ def _inpaint(rgb, dep, u, v, cdi, par, sweep_sign, ps, search_radius, tol, blur)
 
 def dibr_eye(rgb_u8_hwc: np.ndarray, depth: np.ndarray, eye_offset: float, depth_strength: float, convergence: float = 0.0,
              out_h: int = 0, out_w: int = 0, roll: float = 0.0, res=None, search_radius=12.0, tol=0.012, blur=2.5,
-             feather=False, feather_width=0.02, corner_radius=0.0, viewport=None) -> np.ndarray:
+             feather=False, feather_width=0.02, corner_radius=0.0, viewport=None, rgba=False) -> np.ndarray:
     """One eye of FRAGMENT_SHADER.main (viewer.py:533-631) rendered into an out_h x out_w viewport -> float32
     [out_h,out_w,3] in 0..255 (colour * alpha over black).  eye_offset: -ipd_uv/2 left, +ipd_uv/2 right
     (viewer.py:2701, 2714); depth_strength = viewer.depth_strength (0.1) * depth_ratio (viewer.py:1334, 2686)."""
@@ -149,17 +156,24 @@ def dibr_eye(rgb_u8_hwc: np.ndarray, depth: np.ndarray, eye_offset: float, depth
         dx, dy = np.abs(u - F32(0.5)) - F32(0.5) + r, np.abs(v - F32(0.5)) - F32(0.5) + r
         sdf = np.sqrt(np.maximum(dx, 0) ** 2 + np.maximum(dy, 0) ** 2).astype(F32) + np.minimum(np.maximum(dx, dy), 0) - r
         alpha = np.minimum(alpha, F32(1) - _smoothstep(0.0, 0.01, sdf.astype(F32)))
+    if rgba:        # frag_color as the shader writes it: rgb (0..255 here) and alpha, un-multiplied
+        return np.concatenate([color.astype(F32), alpha[..., None].astype(F32)], -1)
     return (color * alpha[..., None]).astype(F32)
 
 
 def dibr_sbs(rgb_u8_hwc, depth, ipd_uv=0.064, depth_ratio=1.0, convergence=0.0, display_mode="Full-SBS",
-             viewer_depth_strength=0.1, **kw) -> np.ndarray:
+             viewer_depth_strength=0.1, alpha="window", **kw) -> np.ndarray:
     """Both eyes packed like the viewer lays out its viewports for an undistorted window (viewer.py:2688-2830):
-    Full-SBS [H,2W], Half-SBS [H,W] (each eye W/2 columns), Full-TAB [2H,W], Half-TAB [H,W] (each eye H/2 rows)."""
+    Full-SBS [H,2W], Half-SBS [H,W] (each eye W/2 columns), Full-TAB [2H,W], Half-TAB [H,W] (each eye H/2 rows).
+    alpha: "window" = frag_color.rgb as the reference's window shows it (blending off), "premultiplied" = rgb * a,
+    "rgba" = four channels (rgb 0..255, a 0..1)."""
     H, W = depth.shape
     eh = H // 2 if display_mode == "Half-TAB" else H
     ew = W // 2 if display_mode == "Half-SBS" else W
     ds = viewer_depth_strength * depth_ratio
-    left = dibr_eye(rgb_u8_hwc, depth, -ipd_uv / 2.0, ds, convergence, eh, ew, **kw)
-    right = dibr_eye(rgb_u8_hwc, depth, ipd_uv / 2.0, ds, convergence, eh, ew, **kw)
-    return np.concatenate([left, right], 1 if display_mode.endswith("SBS") else 0)
+    left = dibr_eye(rgb_u8_hwc, depth, -ipd_uv / 2.0, ds, convergence, eh, ew, rgba=True, **kw)
+    right = dibr_eye(rgb_u8_hwc, depth, ipd_uv / 2.0, ds, convergence, eh, ew, rgba=True, **kw)
+    out = np.concatenate([left, right], 1 if display_mode.endswith("SBS") else 0)
+    if alpha == "rgba":
+        return out
+    return (out[..., :3] * out[..., 3:4]).astype(F32) if alpha == "premultiplied" else np.ascontiguousarray(out[..., :3])

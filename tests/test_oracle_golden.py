@@ -256,3 +256,38 @@ def test_warp_all_cases(golden_dir, fixture):
         tol = (0.08 if c["kind"] == "S1" else 0.03) * max(1.0, c["w"] / 1920.0)
         assert np.abs(got - ref).max() <= tol, (c["key"], np.abs(got - ref).max())
         assert np.abs(O.to_u8(got).astype(int) - O.to_u8(ref).astype(int)).max() <= 1
+
+
+def test_dibr_oracle_matches_reference_shader_renders(golden_dir):
+    """f1, pinned (round 5): oracle/dibr_oracle.py against renders of the REFERENCE's own fragment shader (viewer.py:386-631) --
+    tests/golden/dibr.npz, produced by compiling the shader text as OpenGL ES 3.0 and running it off-screen on SwiftShader in the
+    build container (tests/golden/gl_harness.py, make_golden_dibr.py).  frag_color.rgb and frag_color.a separately, both eyes:
+    hard depth edges, convergence, roll, feathering + rounded corners, a Half-SBS viewport, a smooth scene (small cases, every
+    pixel), 1080p Full and Half-TAB viewports (every 45th row).  Tolerance: GL_LINEAR filters RGB8 with 8-bit sub-texel weights
+    (<= 255/512 of a level per lerp axis) where the restatement filters in float32 -> <= 1 level on the small cases (measured max
+    0.48); at 1920 columns the shader's hard thresholds flip isolated pixels on a 1-ulp coordinate difference -> >= 99.9 % within
+    1 level (measured 3e-4..6e-4 beyond), mean <= 0.06; alpha within 1e-3 everywhere (measured 1e-4; min alpha 0.69 at the 1080p
+    screen edge and 0 in the rounded corners, so the comparison is not vacuous)."""
+    from desktop2stereo_amd import synth
+    from oracle import dibr_oracle as DO
+    z = np.load(os.path.join(golden_dir, "dibr.npz"))
+    with open(os.path.join(golden_dir, "dibr.json")) as f:
+        meta = json.load(f)
+    assert "SwiftShader" in meta["gl"]["renderer"] and len(meta["cases"]) >= 8
+    saw_alpha = False
+    for c in meta["cases"]:
+        img, dep = synth.dibr_scene(c["h"], c["w"], c["seed"], c["scene"])
+        for eye, sg in (("left", -1.0), ("right", 1.0)):
+            o = DO.dibr_eye(img, dep, sg * c["ipd_uv"] / 2.0, 0.1 * c["depth_ratio"], c["convergence"], c["eye_h"], c["eye_w"],
+                            roll=c.get("roll", 0.0), feather=c.get("feather", False), feather_width=c.get("feather_width", 0.02),
+                            corner_radius=c.get("corner_radius", 0.0), rgba=True)[::c["row_stride"]]
+            rgb = z[f"{c['name']}_{eye}_rgb"].astype(np.float32) / 256.0
+            a = z[f"{c['name']}_{eye}_a"].astype(np.float32) / 65535.0
+            d = np.abs(o[..., :3] - rgb)
+            assert np.abs(o[..., 3] - a).max() <= 1e-3, (c["name"], eye)
+            saw_alpha |= bool(a.min() < 0.9)
+            if c["w"] <= 320:
+                assert d.max() <= 1.0, (c["name"], eye, float(d.max()))
+            else:
+                assert (d <= 1.0).mean() >= 0.999 and d.mean() <= 0.06, (c["name"], eye, float((d > 1).mean()), float(d.mean()))
+    assert saw_alpha

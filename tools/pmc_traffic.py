@@ -32,6 +32,18 @@ def read(d, counter):
 def main():
     root = sys.argv[1]
     out = {"source": root, "calibration": {}, "traffic_bytes_per_launch": {}}
+    # provenance: the digest of the kernel sources the passes ran on (written on the GPU box by pmc_traffic.sh), the
+    # date of the run, and the commit this file is rebuilt at -- bench.py compares the digest with the tree it runs on
+    for key, fn in (("kernel_sources_sha256", "kernel_sources.sha256"), ("date_utc", "date_utc.txt")):
+        try:
+            out[key] = open(os.path.join(root, fn)).read().strip()
+        except OSError:
+            out[key] = None
+    try:
+        import subprocess
+        out["commit"] = subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD"], cwd=os.path.dirname(os.path.abspath(__file__)), text=True).strip()
+    except Exception:
+        out["commit"] = None
     for B in sorted({os.path.basename(p).split("_b")[-1] for p in glob.glob(os.path.join(root, "bench_b*")) if os.path.isdir(p)}, key=int):
         d = os.path.join(root, f"bench_b{B}")
         fetch, write = read(d, "FETCH_SIZE"), read(d, "WRITE_SIZE")          # counter units are calibrated below, not assumed

@@ -4,6 +4,9 @@
 set -u
 OUT=$(realpath -m $1); mkdir -p $OUT
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+# identity of the code these passes ran on (bench.py refuses the figures for any other tree) + when
+(cd $R && python -m desktop2stereo_amd.build --digest) > $OUT/kernel_sources.sha256
+date -u +%Y-%m-%dT%H:%M:%SZ > $OUT/date_utc.txt
 cd /tmp && export TMPDIR=/tmp
 hipcc --offload-arch=gfx950 -O2 $R/tools/ubench/copy_calib.hip -o /tmp/copy_calib || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do

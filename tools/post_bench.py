@@ -19,6 +19,7 @@ from desktop2stereo_amd.config import PipelineParams      # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batches", type=int, nargs="+", default=[1, 2, 4])
 ap.add_argument("--hw", type=int, nargs=2, default=[294, 518])
+ap.add_argument("--no-check", action="store_true", help="timing-only library variants (PF_CUT builds): skip the bit-identity assertion")
 a = ap.parse_args()
 dev = torch.device("cuda")
 h, w = a.hw
@@ -50,6 +51,6 @@ for B in a.batches:
     same = bool(torch.equal(res["0"][0], res["1"][0]))
     print(f"post-process B={B} {w}x{h}: separate launches {res['0'][1]:7.1f} us | one launch {res['1'][1]:7.1f} us | bit-identical: {same}"
           f"  [incl. output alloc]", flush=True)
-    assert same
+    assert same or a.no_check
 os.environ.pop("D2S_POST_ONE", None)
 ops.reload_env()
