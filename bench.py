@@ -732,8 +732,11 @@ def rank_body(args, engine_factory=None, device=None):
         p3 = PipelineParams(depth_resolution=518, display_mode="Full-TAB")
         sp3 = ops.sbs_params(p3.ipd, p3.depth_strength, p3.convergence, "Full-TAB", p3.fill_16_9)
         oh3, ow3 = ops.sbs_shape(H3, W3, sp3)
+        B3 = 8                                               # config 3 at batch 1 is latency-bound: the throughput row is batch 8 (both reported)
         pool3 = [torch.from_numpy(synth.noise_frame(H3, W3, 9000 + j)[None]).to(dev) for j in range(2)]
+        pool3b = torch.cat([pool3[j & 1] for j in range(B3)])
         out3 = torch.empty((1, oh3, ow3, 3), dtype=torch.uint8, device=dev)
+        out3b = torch.empty((B3, oh3, ow3, 3), dtype=torch.uint8, device=dev)
         ref3 = None
         try:
             z3 = np.load(os.path.join(REPO, "tests", "golden", "vitl_r518_4k.npz"))
@@ -742,23 +745,66 @@ def rank_body(args, engine_factory=None, device=None):
             ref3 = (z3["f0_post_depth"], synth.structured_frame(fr3["h"], fr3["w"], fr3["seed"]))
         except OSError:
             pass
+        emu3 = None
+        try:
+            with open(os.path.join(REPO, "tests", "golden", "fp8_frontier_vitl_4k.json")) as f:
+                emu3 = json.load(f)["rows"]
+        except OSError:
+            pass
         rows3 = {}
-        for prec3 in ("bf16", "fp8"):
-            e3 = ops.Engine(cfg3, w3, h3, w3_, max_batch=1, precision=prec3, device=local_rank)
-            if prec3 == "fp8":
+        for prec3 in ("bf16", "fp8", "fp8_mlp"):
+            e3 = ops.Engine(cfg3, w3, h3, w3_, max_batch=B3, precision=prec3, device=local_rank)
+            if prec3 != "bf16":
                 e3.calibrate(ops.preprocess(torch.from_numpy(synth.structured_frame(H3, W3, 0)).to(dev), 518))
             dt3 = timed(lambda i: e3.pipeline(pool3[i & 1], p3, sp3, use_ema=False, out=out3), 5, 40)
-            row = {"value": 40 / dt3, "unit": "stereo frames/s", "ms_per_step": 1e3 * dt3 / 40}
+            dt3b = timed(lambda i: e3.pipeline(pool3b, p3, sp3, use_ema=False, out=out3b), 3, 10)
+            row = {"value": 40 / dt3, "unit": "stereo frames/s", "ms_per_step": 1e3 * dt3 / 40,
+                   "batch8": {"value": 10 * B3 / dt3b, "unit": "stereo frames/s", "ms_per_step": 1e3 * dt3b / 10, "frames_per_step": B3}}
             if ref3 is not None:
                 post = ops.post_process_depth(e3(ops.preprocess(torch.from_numpy(ref3[1]).to(dev), 518)), p3).cpu().numpy()[0]
                 dd = np.abs(post - ref3[0])
                 row.update(depth_l1_vs_ref=float(dd.mean()), depth_max_vs_ref=float(dd.max()))
+            if prec3 != "bf16":
+                # the encoder linears of this engine against the MFMA rate they actually issue at (non-scaled e4m3 = the bf16 rate, 2.5 PF)
+                pr = profile_pass(e3, lambda i: e3.pipeline(pool3b, p3, sp3, use_ema=False, out=out3b), 4, B3, "fp8", sync)
+                row["roofline"] = dict(pr["roofline"], note="batch 8; e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8 (non-scaled: bf16 issue rate, priced against 2.5 PF)")
+                if emu3 is not None:
+                    row["reference_emulation"] = emu3["all four e4m3" if prec3 == "fp8" else "MLP only (FC1 + FC2)"]
             rows3[prec3] = row
             e3.close()
-        result["config3_vitl_4k_full_tab"] = dict(rows3, fp8_over_bf16=rows3["fp8"]["value"] / rows3["bf16"]["value"],
-                                                  workload="DepthAnything-v2-vitl, 3840x2160 uint8 noise frames, batch 1, Depth Resolution 518 (CPU-branch ::3 "
-                                                           "decimation, model input 294x518), Full-TAB uint8 output 3840x4320 (BASELINE configs[2]); depth error vs "
-                                                           "tests/golden/vitl_r518_4k (structured frame); fp8 = non-scaled e4m3 MFMA (bf16 issue rate), per-tensor scales")
+        result["config3_vitl_4k_full_tab"] = dict(
+            rows3, fp8_over_bf16=rows3["fp8"]["value"] / rows3["bf16"]["value"],
+            fp8_over_bf16_batch8=rows3["fp8"]["batch8"]["value"] / rows3["bf16"]["batch8"]["value"],
+            fp8_mlp_over_bf16_batch8=rows3["fp8_mlp"]["batch8"]["value"] / rows3["bf16"]["batch8"]["value"],
+            workload="DepthAnything-v2-vitl, 3840x2160 uint8 noise frames, batch 1 (and batch 8), Depth Resolution 518 (CPU-branch ::3 decimation, model "
+                     "input 294x518), Full-TAB uint8 output 3840x4320 (BASELINE configs[2]); depth error vs tests/golden/vitl_r518_4k (structured frame); "
+                     "fp8 = e4m3 operands on all four encoder linears, fp8_mlp = on FC1 / FC2 only (QKV / proj bf16); non-scaled e4m3 MFMA (bf16 issue "
+                     "rate), static per-tensor activation scales; reference_emulation = the reference's own model under the same operand quantisation "
+                     "(tests/golden/fp8_frontier_vitl_4k.json)")
+    if rank == 0 and world == 1 and not fake and default_run and not args.no_config3:
+        # BASELINE configs[3]: one Video-Depth-Anything stream (window 32, ring of projected K' / V' rows) per GPU through d2s_pipeline,
+        # 1080p frames, Full-SBS; the two sizes the reference's settings select (Depth Resolution 336 / 518).  One stream never shards:
+        # 8 GPUs = 8 independent streams (shard.stream_owner) -- `python bench.py --vda --gpus N` times that; this sub-object is the
+        # per-stream rate on this GPU so that the driver's default run sees it.
+        from desktop2stereo_amd.config import MODELS as _M4
+        from desktop2stereo_amd.vda_weights import make_vda_weights as _mv4
+        rows4 = {}
+        for name4, res4 in (("vits", 336), ("vitb", 518)):
+            cfg4 = _M4[name4]
+            h4, w4, _ = engine_shape(H, W, res4)
+            p4 = PipelineParams(depth_resolution=res4, display_mode="Full-SBS")
+            sp4 = ops.sbs_params(p4.ipd, p4.depth_strength, p4.convergence, "Full-SBS", p4.fill_16_9)
+            oh4, ow4 = ops.sbs_shape(H, W, sp4)
+            e4 = ops.Engine(cfg4, _mv4(cfg4, 0), h4, w4, 1, "bf16", device=local_rank, temporal=True)
+            pool4 = [torch.from_numpy(synth.noise_frame(H, W, 7000 + j)[None]).to(dev) for j in range(4)]
+            out4 = torch.empty((1, oh4, ow4, 3), dtype=torch.uint8, device=dev)
+            dt4 = timed(lambda i: e4.pipeline(pool4[i & 3], p4, sp4, use_ema=False, out=out4), 40, 150)      # (40 warm-up frames fill the 32-frame window)
+            pr4 = profile_pass(e4, lambda i: e4.pipeline(pool4[i & 3], p4, sp4, use_ema=False, out=out4), 4, 1, "bf16", sync)
+            rows4[f"{name4}_r{res4}"] = {"value": 150 / dt4, "unit": "stereo frames/s per stream", "ms_per_step": 1e3 * dt4 / 150,
+                                         "launches_per_step": pr4["launches_per_step"], "model_input": [h4, w4]}
+            e4.close()
+        result["config4_vda"] = dict(rows4, workload="VideoDepthAnything streaming forward (32-frame window) + post-process + Full-SBS warp through d2s_pipeline, "
+                                                      "1920x1080 uint8 noise frames, one stream on this GPU, bf16 engine, EMA off")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("D2S_LIB") or os.path.join(HERE, "libd2s_hip.so")     
 OK = 0
 MODE = {"Half-SBS": 0, "Full-SBS": 1, "Half-TAB": 2, "Full-TAB": 3}
 FMT_U8_HWC, FMT_F32_CHW, FMT_F32_HWC, FMT_U8_CHW = 0, 1, 2, 3
-PREC_FP32, PREC_BF16, PREC_FP8, PREC_BF16X3 = 0, 1, 2, 3
+PREC_FP32, PREC_BF16, PREC_FP8, PREC_BF16X3, PREC_FP8_MLP = 0, 1, 2, 3, 4
 
 
 class ModelDesc(C.Structure):

@@ -95,7 +95,13 @@ struct d2s_engine {
         PackedW proj_in, proj_out, kvq[2], to_out[2], ff1, ff2;     // kvq: fused to_k | to_v | to_q, [3C][C]
         float* ptab[2] = {nullptr, nullptr};       // [32][3C] = pe @ kvq^T: the positional encoding's share of k | v | q
         void* cache[2] = {nullptr, nullptr};       // ring [31][sites][2C] T per attention block: projected k' | v' rows
+        // round 5 (bf16 engine): the three LayerNorms of a module folded into the linears that consume them, like the ViT's (DESIGN.md
+        // section 3.1b): W' = W diag(gamma), bias' = b + W beta, colsum over the bf16-rounded W'
+        PackedW kvq_ln[2], ff1_ln;
+        float *csum_kvq[2] = {nullptr, nullptr}, *csum_ff1 = nullptr;
     } tm[4];
+    float* tm_stats = nullptr;                     // (sum, sum of squares) partials per (row, column block) of the folded LayerNorms
+    bool tm_fold = false;
     int tm_head = 0, tm_init = 0;                  // oldest ring slot; 0 until the first frame has filled the rings
     float* tm_hs = nullptr;                        // [sites_max, C_max] fp32 residual of the temporal transformer
     void *tm_a = nullptr, *tm_kv = nullptr, *tm_u = nullptr, *tm_g = nullptr, *tm_out = nullptr;
@@ -111,6 +117,7 @@ struct d2s_engine {
     int last_batch = 0;
     // D2S_PREC_FP8 (BASELINE config 3): encoder linears on e4m3 operands once calibrated
     bool fp8 = false, fp8_ready = false, calib = false;
+    bool fp8_mlp = false;             // D2S_PREC_FP8_MLP: e4m3 on FC1 / FC2 only (60 % of the encoder FLOPs), QKV / proj stay bf16
     bool lnf = false;                 // LayerNorm folded into the producing / consuming linears (bf16, not fp8)
     bool attn_prescaled = false;      // softmax scale folded into W_q / b_q (bf16 and fp8 engines)
     float* lnstats = nullptr;         // [slots][M][2] partial row sums written by the residual-update GEMMs
@@ -346,34 +353,69 @@ int run_temporal(d2s_engine* e, int m, const void* x, void* out, hipStream_t st,
     d2s_engine::TMod& t = e->tm[m];
     const int C = t.C, S = t.sites, prec = e->prec;
     const int Tw = e->tm_init ? 32 : 1;                 // first frame: a window of one (the frame itself at position 0)
-    PROF(PC_ELT, 0, 0, launch_groupnorm(prec, x, t.gn_g, t.gn_b, e->tm_a, S, C, 32, 1e-6f, st));
-    RC(gemm(e, plainA(e->tm_a, C), t.proj_in, S, rowsE(e->tm_hs, OUT_F32, C, t.proj_in.bias), st));
+    // Round 5, bf16 engine (D2S_VDA_FUSE=0 restores round 4's 18 launches per module): (i) the three LayerNorms live in the linears
+    // either side of them -- the residual-update GEMM (proj_in, to_out) also leaves the raw residual as bf16 in tm_a and the row
+    // statistics in tm_stats, the consumer (kvq, ff1) runs on gamma-folded weights (section 3.1b's algebra, eps 1e-5); (ii) the ring
+    // store of a frame's k' | v' rows happens inside the attention kernel (the lanes that read the oldest slot's segment overwrite it
+    // once both of their passes over it are done); (iii) ff2's epilogue leaves the bf16 copy proj_out reads (no cast kernel).
+    // 18 -> 11 launches per module.
+    const bool fold = e->tm_fold && prec == D2S_PREC_BF16 && e->wprec != D2S_PREC_BF16X3;
+    int slots = 0;
+    auto producer = [&](GemmEpi& ep) { if (fold) { ep.out2 = e->tm_a; ep.stats_out = e->tm_stats; ep.stats_slots = &slots; } };
+    auto consumer = [&](GemmEpi& ep, const float* csum) { ep.ln_stats = e->tm_stats; ep.ln_slots = slots; ep.ln_csum = csum; ep.ln_eps = 1e-5f; ep.ln_dim = C; };
+    // (folded: proj_in leaves its bf16 copy in tm_a, so the GroupNorm output it reads goes to tm_out -- free until the attention writes it)
+    void* gn_out = fold ? e->tm_out : e->tm_a;
+    PROF(PC_ELT, 0, 0, launch_groupnorm(prec, x, t.gn_g, t.gn_b, gn_out, S, C, 32, 1e-6f, st));
+    {
+        GemmEpi ep = rowsE(e->tm_hs, OUT_F32, C, t.proj_in.bias);
+        producer(ep);
+        RC(gemm(e, plainA(gn_out, C), t.proj_in, S, ep, st));
+    }
     for (int a = 0; a < 2; ++a) {
-        PROF(PC_LN, 0, 0, launch_layernorm(prec, e->tm_hs, t.ln_g[a], t.ln_b[a], e->tm_a, S, C, 1e-5f, 0, 0, 0, st));
+        const bool folded = fold && slots >= 1 && slots <= 16;
+        if (!folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->tm_hs, t.ln_g[a], t.ln_b[a], e->tm_a, S, C, 1e-5f, 0, 0, 0, st));
         // project THIS frame only (k' | v' | q'); the window's other 31 positions are already projected in the ring
-        RC(gemm(e, plainA(e->tm_a, C), t.kvq[a], S, rowsE(e->tm_kv, OUT_T, 3 * C, nullptr), st));
-        PROF(PC_ATTN, 4.0 * S * Tw * C, 0, launch_temporal_attn(prec, e->tm_kv, t.cache[a], t.ptab[a], e->tm_out, S, C, Tw, 31, e->tm_head, st));
+        {
+            GemmEpi ep = rowsE(e->tm_kv, OUT_T, 3 * C, folded ? t.kvq_ln[a].bias : nullptr);
+            if (folded) consumer(ep, t.csum_kvq[a]);
+            RC(gemm(e, plainA(e->tm_a, C), folded ? t.kvq_ln[a] : t.kvq[a], S, ep, st));
+        }
+        // the frame's projected rows join the window: the first frame fills all 31 slots (its own launch); later frames replace the
+        // oldest slot -- inside the attention kernel when fused
+        const int store_slot = (fold && e->tm_init) ? e->tm_head : -1;
+        PROF(PC_ATTN, 4.0 * S * Tw * C, 0, launch_temporal_attn(prec, e->tm_kv, t.cache[a], t.ptab[a], e->tm_out, S, C, Tw, 31, e->tm_head, st, store_slot));
         {
             GemmEpi ep = rowsE(e->tm_hs, OUT_F32, C, t.to_out[a].bias);
             ep.res1 = e->tm_hs;
+            producer(ep);
             RC(gemm(e, plainA(e->tm_out, C), t.to_out[a], S, ep, st));
         }
-        // the frame's projected rows join the window: first frame fills all 31 slots, later frames replace the oldest
-        PROF(PC_ELT, 0, 0, launch_cache_store(prec, t.cache[a], e->tm_kv, S, C, e->tm_init ? e->tm_head : 0, e->tm_init ? 1 : 31, st));
+        if (store_slot < 0)
+            PROF(PC_ELT, 0, 0, launch_cache_store(prec, t.cache[a], e->tm_kv, S, C, e->tm_init ? e->tm_head : 0, e->tm_init ? 1 : 31, st));
     }
-    PROF(PC_LN, 0, 0, launch_layernorm(prec, e->tm_hs, t.ffn_g, t.ffn_b, e->tm_a, S, C, 1e-5f, 0, 0, 0, st));
-    RC(gemm(e, plainA(e->tm_a, C), t.ff1, S, rowsE(e->tm_u, OUT_T, 8 * C, t.ff1.bias), st));
+    {
+        const bool folded = fold && slots >= 1 && slots <= 16;
+        if (!folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->tm_hs, t.ffn_g, t.ffn_b, e->tm_a, S, C, 1e-5f, 0, 0, 0, st));
+        GemmEpi ep = rowsE(e->tm_u, OUT_T, 8 * C, folded ? t.ff1_ln.bias : t.ff1.bias);
+        if (folded) consumer(ep, t.csum_ff1);
+        RC(gemm(e, plainA(e->tm_a, C), folded ? t.ff1_ln : t.ff1, S, ep, st));
+    }
     PROF(PC_ELT, 0, 0, launch_geglu(prec, e->tm_u, e->tm_g, S, 4 * C, st));
     {
         GemmEpi ep = rowsE(e->tm_hs, OUT_F32, C, t.ff2.bias);
         ep.res1 = e->tm_hs;
+        if (fold) ep.out2 = e->tm_a;                    // the bf16 copy proj_out multiplies (no statistics: nothing normalises it)
         RC(gemm(e, plainA(e->tm_g, 4 * C), t.ff2, S, ep, st));
     }
-    PROF(PC_ELT, 0, 0, launch_cast_f32(prec, e->tm_hs, e->tm_a, (long)S * C, st));
+    const void* a_out = e->tm_a;
+    if (!fold) {
+        if (prec == D2S_PREC_BF16) PROF(PC_ELT, 0, 0, launch_cast_f32(prec, e->tm_hs, e->tm_a, (long)S * C, st));
+        else a_out = e->tm_hs;                          // fp32 activations: the residual itself is the operand (round 4 copied it)
+    }
     {
         GemmEpi ep = rowsE(out, OUT_T, C, t.proj_out.bias);
         ep.res1 = x; ep.res2 = add;
-        RC(gemm(e, plainA(e->tm_a, C), t.proj_out, S, ep, st));
+        RC(gemm(e, plainA(a_out, C), t.proj_out, S, ep, st));
     }
     return D2S_OK;
 }
@@ -450,6 +492,9 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
     // D2S_PREC_FP8: the producers of the four linears' A operands write e4m3 (x / s_act, saturated); the linears run on
     // e4m3 operands and de-quantise in their epilogue (deq[n] = s_act * s_w[n]); QKV still emits bf16 for the attention
     const bool f8 = e->fp8 && !e->calib;
+    // D2S_PREC_FP8_MLP (round 5): only FC1 / FC2 take e4m3 operands; LN-1 output / attention output stay bf16 and QKV / proj run the bf16
+    // kernels.  f8a = "the attention-side linears are e4m3 too" (the all-four scheme)
+    const bool f8a = f8 && !e->fp8_mlp;
     // bf16x3 engines: the A operands of the four encoder linears are written PRE-SPLIT (bf16 hi | lo units, common.h) by their
     // producers -- LayerNorm, attention, the GELU epilogue -- so that they travel by LDS-DMA like the bf16 engine's; every other
     // GEMM / conv reads fp32 activations and splits them between its staging registers and LDS
@@ -485,25 +530,25 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         float* am = e->calib ? e->amax + (size_t)l * NSITE : nullptr;
         // lnf: the previous layer's FC2 epilogue left the raw bf16 residual in lnbuf and the row statistics in lnstats;
         // LN1 then happens inside the QKV linear (layer 0 has no such producer and runs the LN kernel)
-        const bool ln1_folded = lnf && l > 0 && ln_slots <= 16;
-        if (!ln1_folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln1g, ly.ln1b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8 ? 1.0f / sa[0] : 0.f, x3));
+        const bool ln1_folded = lnf && l > 0 && ln_slots <= 16 && !(f8 && !f8a);     // (MLP-only e4m3: LN-1 stays a kernel, bf16 out)
+        if (!ln1_folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->resid, ly.ln1g, ly.ln1b, e->lnbuf, M, D, d.ln_eps, 0, 0, 0, st, f8a ? 1.0f / sa[0] : 0.f, x3));
         if (am) RC(launch_amax(prec, e->lnbuf, (long)M * D, am + 0, st));
         {
-            GemmEpi ep = rowsE(e->qkv, f8 ? OUT_BF16 : (x3 ? OUT_BX3 : OUT_T), 3 * D, ln1_folded ? (f8 ? ly.w8_ln[0].bias : ly.qkv_ln.bias) : ly.qkv.bias);
+            GemmEpi ep = rowsE(e->qkv, f8 ? OUT_BF16 : (x3 ? OUT_BX3 : OUT_T), 3 * D, ln1_folded ? (f8a ? ly.w8_ln[0].bias : ly.qkv_ln.bias) : ly.qkv.bias);
             ep.map = MAP_QKV; ep.vt = e->vt; ep.ntok = N; ep.npad = e->Npad; ep.qk_cols = 2 * D; ep.heads = d.heads;
-            if (ln1_folded) { ep.ln_stats = e->lnstats; ep.ln_slots = ln_slots; ep.ln_csum = f8 ? ly.csum8[0] : ly.csum_qkv; ep.ln_eps = d.ln_eps; ep.ln_dim = D; }
-            if (f8) { ep.deq = ln1_folded ? ly.deq_ln[0] : ly.deq[0]; RC(gemm8(e, plainA(e->lnbuf, D), ln1_folded ? ly.w8_ln[0] : ly.w8[0], M, ep, st)); }
+            if (ln1_folded) { ep.ln_stats = e->lnstats; ep.ln_slots = ln_slots; ep.ln_csum = f8a ? ly.csum8[0] : ly.csum_qkv; ep.ln_eps = d.ln_eps; ep.ln_dim = D; }
+            if (f8a) { ep.deq = ln1_folded ? ly.deq_ln[0] : ly.deq[0]; RC(gemm8(e, plainA(e->lnbuf, D), ln1_folded ? ly.w8_ln[0] : ly.w8[0], M, ep, st)); }
             else RC(gemm(e, splitA(e->lnbuf, D, x3), ln1_folded ? ly.qkv_ln : ly.qkv, M, ep, st));
         }
         PROF(PC_ATTN, 4.0 * B * d.heads * (double)N * N * 64, 0,
-             launch_attention(x3 ? D2S_PREC_BF16X3 : prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st, f8 ? 1.0f / sa[1] : 0.f, e->attn_prescaled));
+             launch_attention(x3 ? D2S_PREC_BF16X3 : prec, e->qkv, e->vt, e->attn, B, N, e->Npad, d.heads, st, f8a ? 1.0f / sa[1] : 0.f, e->attn_prescaled));
         if (am) RC(launch_amax(prec, e->attn, (long)M * D, am + 1, st));
         {
             if (pending_ln >= 0) { D2S_HIP(hipStreamWaitEvent(st, e->ev_ln[pending_ln], 0)); pending_ln = -1; }
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.proj.bias);
             ep.scale = ly.ls1; ep.res1 = e->resid;
             if (lnf) { ep.out2 = e->lnbuf; ep.out2_bx3 = x3; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[4] : 0.f; }
-            if (f8) { ep.deq = ly.deq[1]; RC(gemm8(e, plainA(e->attn, D), ly.w8[1], M, ep, st)); }
+            if (f8a) { ep.deq = ly.deq[1]; RC(gemm8(e, plainA(e->attn, D), ly.w8[1], M, ep, st)); }
             else RC(gemm(e, splitA(e->attn, D, x3), ly.proj, M, ep, st));
         }
         const bool ln2_folded = lnf && ln_slots <= 16;              // (more than 16 column blocks: the LN kernel runs instead)
@@ -521,7 +566,7 @@ int forward(d2s_engine* e, const float* x, float* depth, int B, hipStream_t st) 
         {
             GemmEpi ep = rowsE(e->resid, OUT_F32, D, ly.fc2.bias);
             ep.scale = ly.ls2; ep.res1 = e->resid;
-            if (lnf && (l + 1 < d.layers || tap_fold)) { ep.out2 = e->lnbuf; ep.out2_bx3 = x3; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[5] : 0.f; }
+            if (lnf && (l + 1 < d.layers || tap_fold) && !(f8 && !f8a)) { ep.out2 = e->lnbuf; ep.out2_bx3 = x3; ep.stats_out = e->lnstats; ep.stats_slots = &ln_slots; ep.out2_qscale = f8 ? 1.0f / sa[5] : 0.f; }
             if (f8) { ep.deq = ly.deq[3]; RC(gemm8(e, plainA(e->mlp, d.mlp), ly.w8[3], M, ep, st)); }
             else RC(gemm(e, splitA(e->mlp, d.mlp, x3), ly.fc2, M, ep, st));
         }
@@ -638,7 +683,7 @@ extern "C" int d2s_engine_create(const d2s_model_desc* desc, int device_id, d2s_
     D2S_REQUIRE(desc->hidden > 0 && desc->heads > 0 && desc->hidden == desc->heads * 64, "head_dim must be 64");
     D2S_REQUIRE(desc->layers > 0 && desc->patch > 0 && desc->pos_grid > 0 && desc->fusion % 8 == 0, "bad model desc");
     D2S_REQUIRE(desc->precision == D2S_PREC_FP32 || desc->precision == D2S_PREC_BF16 || desc->precision == D2S_PREC_FP8 ||
-                desc->precision == D2S_PREC_BF16X3, "bad precision");
+                desc->precision == D2S_PREC_BF16X3 || desc->precision == D2S_PREC_FP8_MLP, "bad precision");
     for (int i = 0; i < 4; ++i) D2S_REQUIRE(desc->neck[i] % 8 == 0 && desc->out_indices[i] >= 1 && desc->out_indices[i] <= desc->layers, "bad neck / out_indices");
     D2S_REQUIRE(desc->head_hidden % 4 == 0 && desc->mlp % 8 == 0, "bad head_hidden / mlp");
     D2S_REQUIRE(desc->max_depth >= 0.f && !(desc->temporal && desc->max_depth > 0.f),
@@ -646,7 +691,8 @@ extern "C" int d2s_engine_create(const d2s_model_desc* desc, int device_id, d2s_
     D2S_ON_DEVICE(device_id);
     d2s_engine* e = new d2s_engine();
     e->d = *desc; e->device = device_id;
-    e->fp8 = desc->precision == D2S_PREC_FP8;
+    e->fp8 = desc->precision == D2S_PREC_FP8 || desc->precision == D2S_PREC_FP8_MLP;
+    e->fp8_mlp = desc->precision == D2S_PREC_FP8_MLP;
     {   // LayerNorm fusion: bf16 and bf16x3 engines (not the plain fp32 engine; the e4m3 path quantises the LN output itself)
         const char* no = getenv("D2S_NO_LNFUSE");
         e->lnf = (desc->precision == D2S_PREC_BF16 || desc->precision == D2S_PREC_BF16X3) && !(no && atoi(no) != 0);
@@ -874,10 +920,30 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
         // ---- Video-Depth-Anything temporal modules (reference dpt_temporal.py:50-60): layer_3, layer_4, path_4, path_3
         const int tC[4] = {d.neck[2], d.neck[3], F, F};
         const int tS[4] = {e->fH[2] * e->fW[2], e->fH[3] * e->fW[3], e->fH[2] * e->fW[2], e->fH[1] * e->fW[1]};
-        size_t sc_max = 0;
+        size_t sc_max = 0, max_sites = 0;
+        {
+            const char* nf = getenv("D2S_VDA_FUSE");
+            e->tm_fold = e->prec == D2S_PREC_BF16 && e->wprec != D2S_PREC_BF16X3 && !(nf && atoi(nf) == 0);
+        }
+        // LN(x) W^T + b  =  rstd * (x W'^T - mean * colsum(W')) + (b + W beta),  W' = W diag(gamma): colsum over the bf16-rounded W'
+        auto fold_ln = [&](const float* g, const float* bt, int Nn, int K, auto at, const float* bias, PackedW& out, float** csum) -> int {
+            std::vector<float> b2(Nn), cs(Nn);
+            for (int n = 0; n < Nn; ++n) {
+                double sb = bias ? bias[n] : 0.0, sc = 0.0;
+                for (int k = 0; k < K; ++k) { sb += (double)bt[k] * at(n, k); sc += (double)bf2f(f2bf(g[k] * at(n, k))); }
+                b2[n] = (float)sb; cs[n] = (float)sc;
+            }
+            int rc = pack_matrix(e, Nn, K, [&](int n, int k) { return g[k] * at(n, k); }, b2.data(), out);
+            if (rc) return rc;
+            rc = dev_alloc(e, (void**)csum, (size_t)Nn * sizeof(float));
+            if (rc) return rc;
+            D2S_HIP(hipMemcpy(*csum, cs.data(), (size_t)Nn * sizeof(float), hipMemcpyHostToDevice));
+            return D2S_OK;
+        };
         for (int m = 0; m < 4; ++m) {
             d2s_engine::TMod& t = e->tm[m];
             t.C = tC[m]; t.sites = tS[m];
+            max_sites = std::max(max_sites, (size_t)t.sites);
             const int C = t.C;
             D2S_REQUIRE(C % 32 == 0 && C <= 1024, "temporal module channels must be a multiple of 32 (GroupNorm) and <= 1024");
             sc_max = std::max(sc_max, (size_t)t.sites * C);
@@ -914,11 +980,25 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
                 D2S_HIP(hipMemcpy(t.ptab[a], pt.data(), pt.size() * 4, hipMemcpyHostToDevice));
                 RC(pack_linear(e, q + "to_out.0.weight", q + "to_out.0.bias", C, C, t.to_out[a]));
                 RC(dev_alloc(e, &t.cache[a], (size_t)31 * t.sites * 2 * C * es, true));
+                if (e->tm_fold) {
+                    const HostT *g = find(e, b + "norms." + std::to_string(a) + ".weight"), *bt = find(e, b + "norms." + std::to_string(a) + ".bias");
+                    if (!g || !bt) return D2S_E_MISSING;
+                    RC(fold_ln(g->data.data(), bt->data.data(), 3 * C, C, [&](int n, int k) { return kvq[n / C][(size_t)(n % C) * C + k]; }, nullptr,
+                               t.kvq_ln[a], &t.csum_kvq[a]));
+                }
             }
             RC(upload_f32(e, b + "ff_norm.weight", C, &t.ffn_g)); RC(upload_f32(e, b + "ff_norm.bias", C, &t.ffn_b));
             RC(pack_linear(e, b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", 8 * C, C, t.ff1));
             RC(pack_linear(e, b + "ff.net.2.weight", b + "ff.net.2.bias", C, 4 * C, t.ff2));
+            if (e->tm_fold) {
+                const HostT *g = find(e, b + "ff_norm.weight"), *bt = find(e, b + "ff_norm.bias"), *w1 = find(e, b + "ff.net.0.proj.weight"),
+                            *b1 = find(e, b + "ff.net.0.proj.bias");
+                if (!g || !bt || !w1 || !b1) return D2S_E_MISSING;
+                const float* w1p = w1->data.data();
+                RC(fold_ln(g->data.data(), bt->data.data(), 8 * C, C, [&](int n, int k) { return w1p[(size_t)n * C + k]; }, b1->data.data(), t.ff1_ln, &t.csum_ff1));
+            }
         }
+        if (e->tm_fold) RC(dev_alloc(e, (void**)&e->tm_stats, (size_t)17 * max_sites * 2 * sizeof(float)));
         RC(dev_alloc(e, (void**)&e->tm_hs, sc_max * 4));
         RC(dev_alloc(e, &e->tm_a, sc_max * es)); RC(dev_alloc(e, &e->tm_out, sc_max * es));
         RC(dev_alloc(e, &e->tm_kv, sc_max * 3 * es));                  // k' | v' | q' of the current frame

@@ -601,7 +601,11 @@ __device__ __forceinline__ void wl_gload1(float& d, const void* p) { asm volatil
 // LDS-only block barrier.  __syncthreads() is a workgroup release / acquire fence over ALL address spaces: the compiler puts
 // s_waitcnt vmcnt(0) in front of it, which drains the prefetched rows and every global store of the row just written --
 // once per row.  The rows exchanged here live in LDS only.
+#ifdef WL_CUT_BARRIER       // (tuning aid, tools/build_variant.sh: timing only, results wrong -- what the per-row block barrier costs)
+__device__ __forceinline__ void wl_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 __device__ __forceinline__ void wl_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 template <int MODE>
 __global__ void __launch_bounds__(256, 4)
@@ -759,8 +763,12 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
                         const float w1 = sx - fl, w0 = 1.0f - w1;
                         const float* p = sp + (int)fl;
                         const wl_f2 ww = {w0, w1};
+#ifdef WL_CUT_TAPS          // (timing only: no LDS tap reads)
+                        const wl_f2 vr = (wl_f2){fl, w1} * ww, vg = (wl_f2){w0, fl} * ww, vb = (wl_f2){w1, w0} * ww; (void)p;
+#else
                         const wl_f2 vr = (wl_f2){p[0], p[1]} * ww, vg = (wl_f2){p[WL_PLANE], p[WL_PLANE + 1]} * ww,
                                     vb = (wl_f2){p[2 * WL_PLANE], p[2 * WL_PLANE + 1]} * ww;
+#endif
                         px[k][0] = vr[0] + vr[1]; px[k][1] = vg[0] + vg[1]; px[k][2] = vb[0] + vb[1];
                     }
                 } else {
@@ -830,6 +838,9 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
                     w3.x = (v.x & 0x00ffffffu) | (v.y << 24);
                     w3.y = ((v.y >> 8) & 0x0000ffffu) | (v.z << 16);
                     w3.z = ((v.z >> 16) & 0x000000ffu) | (v.w << 8);
+#ifdef WL_CUT_STORE         // (timing only: no global stores; one conditional store keeps the values alive)
+                    if (w3.x == 0x12345678u && w3.y == 0x9abcdef0u)
+#endif
                     *(uint3*)(out + (b * per + row * g.out_w + col) * 3) = w3;
                 }
             }

@@ -90,8 +90,8 @@ template <int CH> __device__ __forceinline__ void load_ch(const bf16_t* p, float
 // current frame (reference motion_module.py:259-300: q from the last position, k / v from all).  out [S, C].
 template <typename T, int CH>
 __global__ void __launch_bounds__(256)
-temporal_attn_ring_kernel(const T* __restrict__ cur, const T* __restrict__ ring, const float* __restrict__ ptab, T* __restrict__ out,
-                          int sites, int C, int Tw, int slots, int head, float scale, int lpu) {
+temporal_attn_ring_kernel(const T* __restrict__ cur, T* __restrict__ ring, const float* __restrict__ ptab, T* __restrict__ out,
+                          int sites, int C, int Tw, int slots, int head, float scale, int lpu, int store_slot) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int unit = gid / lpu, li = gid % lpu;
     const bool live = unit < sites * 8;                            // (no early return: the shuffles below need every lane)
@@ -160,6 +160,14 @@ temporal_attn_ring_kernel(const T* __restrict__ cur, const T* __restrict__ ring,
     if (act) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) out[(long)s * C + c + i] = tcvt<T>(acc[i]);
+        // round 5: the frame's k' | v' rows join the window HERE (cache_store_kernel's launch is gone for every frame but the first):
+        // this lane alone reads and writes the segment [c, c + CH) of site s in any ring slot, and both of its passes over the oldest
+        // slot (keys above, values just now) are behind it -- program order within one thread is all the ordering needed
+        if (store_slot >= 0) {
+            T* dst = ring + ((long)store_slot * sites + s) * C2 + c;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { dst[i] = cur_row[c + i]; dst[C + i] = cur_row[C + c + i]; }
+        }
     }
 }
 
@@ -204,8 +212,8 @@ int launch_cache_store(int prec, void* cache, const void* cur, int sites, int C,
     return D2S_OK;
 }
 
-int launch_temporal_attn(int prec, const void* cur, const void* ring, const float* ptab, void* out, int sites, int C, int Tw, int slots,
-                         int head, hipStream_t st) {
+int launch_temporal_attn(int prec, const void* cur, void* ring, const float* ptab, void* out, int sites, int C, int Tw, int slots,
+                         int head, hipStream_t st, int store_slot) {
     if (C % 32 || Tw < 1 || Tw > 32) { set_error("temporal_attn: C % 32 == 0 and 1 <= window <= 32 required"); return D2S_E_INVALID; }
     const float scale = 1.0f / sqrtf((float)(C / 8));
     const bool ch8 = (C / 8) % 8 == 0;                 // head dim multiple of 8: 16-byte bf16 chunks
@@ -213,8 +221,8 @@ int launch_temporal_attn(int prec, const void* cur, const void* ring, const floa
     while (lpu * (ch8 ? 8 : 4) < C / 8) lpu <<= 1;
     if (lpu > 64) { set_error("temporal_attn: head dim too large"); return D2S_E_UNSUPPORTED; }
     const dim3 grid(cdiv((long)sites * 8 * lpu, 256)), block(256);
-#define D2S_TATT(TT, CH) hipLaunchKernelGGL((temporal_attn_ring_kernel<TT, CH>), grid, block, 0, st, (const TT*)cur, (const TT*)ring, ptab, (TT*)out, \
-                                            sites, C, Tw, slots, head, scale, lpu)
+#define D2S_TATT(TT, CH) hipLaunchKernelGGL((temporal_attn_ring_kernel<TT, CH>), grid, block, 0, st, (const TT*)cur, (TT*)ring, ptab, (TT*)out, \
+                                            sites, C, Tw, slots, head, scale, lpu, store_slot)
     if (prec == D2S_PREC_BF16) { if (ch8) D2S_TATT(bf16_t, 8); else D2S_TATT(bf16_t, 4); }
     else { if (ch8) D2S_TATT(float, 8); else D2S_TATT(float, 4); }
 #undef D2S_TATT

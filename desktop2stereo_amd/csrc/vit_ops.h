@@ -35,8 +35,8 @@ int launch_attention(int prec, const void* qkv, const void* vt, void* out, int B
 int launch_groupnorm(int prec, const void* x, const float* g, const float* b, void* out, int sites, int C, int groups, float eps, hipStream_t st);
 // cur [S, 3C] = k' | v' | q' of this frame; ring [slots][S][2C] = k' | v' of the past frames; ptab [32][3C] = pe @ W^T
 int launch_cache_store(int prec, void* ring, const void* cur, int sites, int C, int slot0, int nslots, hipStream_t st);
-int launch_temporal_attn(int prec, const void* cur, const void* ring, const float* ptab, void* out, int sites, int C, int Tw, int slots,
-                         int head, hipStream_t st);
+int launch_temporal_attn(int prec, const void* cur, void* ring, const float* ptab, void* out, int sites, int C, int Tw, int slots,
+                         int head, hipStream_t st, int store_slot = -1 /* >= 0: also write this frame's k' | v' rows into that ring slot */);
 int launch_geglu(int prec, const void* u, void* g, long rows, int C4, hipStream_t st);
 int launch_cast_f32(int prec, const float* in, void* out, long n, hipStream_t st);
 

@@ -105,7 +105,7 @@ def _ensure_engine_built(engine_h: int, engine_w: int, first_x: Optional[torch.T
         _state["engine"] = ops.Engine(_state["cfg"], _state["weights"], engine_h, engine_w, _state["max_batch"],
                                       _state["precision"], _state["device"], temporal=_state.get("temporal", False),
                                       max_depth=_state.get("max_depth", 0.0))
-        if _state["precision"] == "fp8":
+        if _state["precision"] in ("fp8", "fp8_mlp"):
             if first_x is None:
                 raise _lib.D2SError("fp8 engine: no model inputs to calibrate on")
             _state["engine"].calibrate(first_x[: _state["max_batch"]])
@@ -118,8 +118,8 @@ def calibrate(frames) -> None:
     tensor, all of one size; up to max_batch of them are used) instead of whatever frame happened to arrive first -- a black
     or splash first desktop frame gives ranges later frames saturate.  Builds the engine for that frame size if needed.
     D2S_FP8_HEADROOM (>= 1) widens every range.  No reference counterpart (the reference has FP16 only)."""
-    if _state["precision"] != "fp8":
-        raise _lib.D2SError("calibrate(): the engine is not configured with precision='fp8'")
+    if _state["precision"] not in ("fp8", "fp8_mlp"):
+        raise _lib.D2SError("calibrate(): the engine is not configured with precision='fp8' / 'fp8_mlp'")
     t = torch.from_numpy(np.ascontiguousarray(frames)) if isinstance(frames, np.ndarray) else frames
     if t.dim() == 3:
         t = t.unsqueeze(0)
@@ -132,7 +132,7 @@ def calibrate(frames) -> None:
 
 def _fp8_first_inputs(frames_u8: torch.Tensor, key) -> Optional[torch.Tensor]:
     """Model inputs of the first batch, only when an fp8 engine is about to be built (calibration data)."""
-    if _state["precision"] != "fp8" or (_state["engine"] is not None and _state["engine_key"] == key):
+    if _state["precision"] not in ("fp8", "fp8_mlp") or (_state["engine"] is not None and _state["engine_key"] == key):
         return None
     p = _state["params"]
     return ops.preprocess(frames_u8, p.depth_resolution, _state["cfg"].patch, p.mean, p.std, p.resample, p.square_input)

@@ -371,10 +371,10 @@ class Engine:
         self.device = torch.device("cuda", device)
         desc = ModelDesc(cfg.hidden, cfg.heads, cfg.layers, (C.c_int32 * 4)(*cfg.out_indices), (C.c_int32 * 4)(*cfg.neck),
                          cfg.fusion, cfg.head_hidden, cfg.mlp, cfg.patch, cfg.pos_grid, cfg.ln_eps,
-                         {"bf16": PREC_BF16, "fp32": PREC_FP32, "fp8": _lib.PREC_FP8, "bf16x3": _lib.PREC_BF16X3}.get(precision, -1),
+                         {"bf16": PREC_BF16, "fp32": PREC_FP32, "fp8": _lib.PREC_FP8, "bf16x3": _lib.PREC_BF16X3, "fp8_mlp": _lib.PREC_FP8_MLP}.get(precision, -1),
                          int(bool(temporal)), float(max_depth))
-        if precision not in ("bf16", "fp32", "fp8", "bf16x3"):
-            raise ValueError("precision must be 'bf16', 'fp32', 'fp8' or 'bf16x3'")
+        if precision not in ("bf16", "fp32", "fp8", "bf16x3", "fp8_mlp"):
+            raise ValueError("precision must be 'bf16', 'fp32', 'fp8', 'fp8_mlp' or 'bf16x3'")
         self._h = C.c_void_p()
         with _on(self.device):
             check(self.lib.d2s_engine_create(C.byref(desc), device, C.byref(self._h)), "d2s_engine_create")

@@ -57,6 +57,10 @@ extern "C" {
                                    into LDS, the weights once at engine build) and the product is three bf16 MFMAs
                                    hi*hi + hi*lo + lo*hi with fp32 accumulation: ~16 mantissa bits per operand at 3/16 of the
                                    fp32-MFMA cost.  Attention, LayerNorm, softmax, residual stream: exactly the fp32 engine's. */
+#define D2S_PREC_FP8_MLP    4   /* round 5: as D2S_PREC_FP8 with e4m3 operands on FC1 / FC2 ONLY (60 % of the encoder FLOPs); QKV and the
+                                   attention-out projection stay on bf16 operands.  The error / throughput frontier of the e4m3 schemes
+                                   (profiles/r5_fp8_frontier.md): all four linears 0.0202 mean |depth error| on BASELINE configs[2]'s
+                                   frame, MLP only 0.0120 */
 
 typedef struct d2s_engine d2s_engine;     /* opaque: weights + workspaces + per-stream state */
 

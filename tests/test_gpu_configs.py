@@ -96,7 +96,8 @@ def test_config2_bench_step_vitb_bf16_1080p_full_sbs(dev, golden_dir):
 def test_config3_vitl_fp8_4k_tab(dev, golden_dir):
     """ViT-L fp8 engine (e4m3 encoder linears) on the 3840x2160 frame, Full-TAB 4320x3840 and Half-TAB 2160x3840 through
     d2s_pipeline, against the reference's fp32 depth (vitl_r518_4k: CPU branch, ::3 decimation) and the oracle warp.
-    fp8 depth is reported, not gated; the bound only catches breakage."""
+    Both e4m3 schemes (all four encoder linears / FC1 + FC2 only) are gated on mean AND max against the reference's own model under
+    the same operand quantisation (tests/golden/fp8_frontier_vitl_4k.json)."""
     from desktop2stereo_amd import ops, synth
     from desktop2stereo_amd.config import MODELS, PipelineParams, engine_shape
     from desktop2stereo_amd.weights import make_weights
@@ -112,10 +113,17 @@ def test_config3_vitl_fp8_4k_tab(dev, golden_dir):
     wts = make_weights(cfg, 0)
     ref_full = O.upsample_depth(z["f0_post_depth"], H, W)
     ft = _t(frame[None], dev)
-    for prec in ("bf16", "fp8"):
+    # e4m3 gates (round 5): REFERENCE-DERIVED -- tests/golden/fp8_frontier_vitl_4k.json holds what the reference's
+    # own model loses on this very frame when the same linears' operands are quantised the same way (fp8_scheme_study.py --frontier
+    # --4k --json: torch float8_e4m3fn emulation, fp32 accumulation); the HIP engine must stay within 1.25 x its mean and 1.5 x its max
+    # (the max of a 152 k-pixel map is one pixel: noisier than the mean), for BOTH schemes
+    with open(os.path.join(golden_dir, "fp8_frontier_vitl_4k.json")) as f:
+        emu = json.load(f)["rows"]
+    emu = {"fp8": emu["all four e4m3"], "fp8_mlp": emu["MLP only (FC1 + FC2)"]}
+    for prec in ("bf16", "fp8", "fp8_mlp"):
         eng = ops.Engine(cfg, wts, h, w, 1, prec)
-        if prec == "fp8":
-            eng.calibrate(torch.cat([ops.preprocess(_t(synth.structured_frame(H, W, s), dev), 518) for s in (0, 5)])[:1])
+        if prec != "bf16":
+            eng.calibrate(ops.preprocess(_t(synth.structured_frame(H, W, 0), dev), 518))
         for mode, shape in (("Full-TAB", (4320, 3840, 3)), ("Half-TAB", (2160, 3840, 3))):
             p = PipelineParams(depth_resolution=518, display_mode=mode)
             sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, mode, p.fill_16_9)
@@ -134,9 +142,9 @@ def test_config3_vitl_fp8_4k_tab(dev, golden_dir):
                 gap = np.abs(zb["f0_post_depth"].astype(np.float32) - z["f0_post_depth"])
                 assert d.max() <= gap.max() and d.mean() <= gap.mean(), (d.max(), d.mean(), gap.max(), gap.mean())
             else:
-                # e4m3 has 3 mantissa bits: no reference counterpart to derive a bound from (the reference has FP16 only); gate =
-                # 1.5 x the measured mean 0.0206 (MI355X, round 2-4) so that breakage shows; the max is reported only
-                assert d.mean() <= 0.031, d.mean()
+                b = emu[prec]
+                print(f"[config 3, {prec}] the reference's model under the same operand quantisation (emulated): mean {b['mean']:.5f} max {b['max']:.4f}")
+                assert d.mean() <= 1.25 * b["mean"] and d.max() <= 1.5 * b["max"], (prec, float(d.mean()), float(d.max()), b)
         eng.close()
 
 
