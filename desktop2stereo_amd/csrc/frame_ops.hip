@@ -596,8 +596,13 @@ constexpr int WL_PLANE = SW_LDS_PX;                    // floats per channel pla
 constexpr int WL_DN = 2;                               // depth-row values per thread (depth grid columns under a tile <= 512)
 
 typedef uint32_t wl_u3 __attribute__((ext_vector_type(3)));
+#ifdef WL_CUT_LOAD          // (tuning aid, timing only: no global loads at all -- what remains is issue / LDS time)
+__device__ __forceinline__ void wl_gload3(wl_u3& d, const void* p) { d = (wl_u3){(uint32_t)(size_t)p, 0x01020304u, 0x05060708u}; }
+__device__ __forceinline__ void wl_gload1(float& d, const void* p) { d = 0.5f + 1e-9f * (float)(uint32_t)(size_t)p; }
+#else
 __device__ __forceinline__ void wl_gload3(wl_u3& d, const void* p) { asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 __device__ __forceinline__ void wl_gload1(float& d, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+#endif
 // LDS-only block barrier.  __syncthreads() is a workgroup release / acquire fence over ALL address spaces: the compiler puts
 // s_waitcnt vmcnt(0) in front of it, which drains the prefetched rows and every global store of the row just written --
 // once per row.  The rows exchanged here live in LDS only.
@@ -739,6 +744,10 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
         has1 = has2; has2 = step + 2 < nsteps;                                                \
     }
     auto wl_compute = [&](int buf, int b, int y) {
+#ifdef WL_CUT_COMPUTE       // (timing only: load + stage, no per-pixel work)
+        if (drow[buf][tid] == 123.456f) out[tid] = 1;
+        return;
+#endif
         if (nk > 0) {
             const float* dr = drow[buf];
             const float* sp = &splane[buf][0][0] - wx0;          // plane R indexed by frame x

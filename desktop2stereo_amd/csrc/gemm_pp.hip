@@ -927,6 +927,14 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
     unsigned vgrid = 0;
     int xn = pick_xn(tiles_m, tiles_n, 256, Kpad, elem_size(precision), vgrid);
     if (xn == 0) xn = 1;
+    // Residual-update launches (N = D: 3-4 tile columns): ONE column group.  With a column group per XCD set every set reads the whole
+    // A panel -- FC2 at batch 32 fetched 629 MB for 234 MB of operands + residual (PMC, profiles/r4_04) -- while a single group walks
+    // m-slow / n-fast, so the 3 column tiles of a row block run on neighbouring CUs of one XCD at the same time and the A panel comes in
+    // once; the W panel (<= 4.7 MB) is then read by all eight XCDs, a tenth of what is saved.  Round 4 measured the launch time unchanged
+    // (FC2 159 -> 157 us, proj 74.5 -> 76.4: the K loop runs at the LDS-fill ceiling either way) and dropped it; it is the default now
+    // because it halves the launch's fabric traffic for the same time.  D2S_PP_F32_XN1=0 restores the column groups.
+    static EnvInt f32_xn1{"D2S_PP_F32_XN1", 1};
+    if (e.out_type == OUT_F32 && f32_xn1.get()) xn = 1;
     // one 160-KiB block per CU, cpx blocks per XCD (blocks beyond an XCD's list exit at once)
     static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
     const int lxn = xn <= 1 ? 0 : (xn == 2 ? 1 : (xn == 4 ? 2 : 3));

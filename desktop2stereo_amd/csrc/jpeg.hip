@@ -10,12 +10,14 @@
 // Stages (all HBM-/latency-bound byte work; one grid dimension = frame; no single-block pass, no host sync):
 //   1 jpeg_dct_kernel            16 MCUs (256x16 px) per block: RGB -> YCbCr (+h2v2), FDCT, quantise, zigzag, dummy
 //                                blocks; writes int16 coefficients [mcu][6][64] and the DCs [mcu][8]
-//   2 jpeg_entropy_kernel<false> one LANE per 8x8 block: code lengths -> bits per block, bits per 256-block tile
+//   2 jpeg_count_kernel          (round 5) the AC bit count of a block is taken in stage 1 while the block is in LDS; this pass adds the
+//                                DC term (needs the predecessor's DC) -> bits per block, bits per 256-block tile
 //   3 jpeg_zero_kernel           zero the words of the (unstuffed) bit stream that will be used; publish the total
 //   4 jpeg_entropy_kernel<true>  same walk, emitting: offset = tile prefix + in-block scan; whole words are plain
 //                                stores, the two edge words of a block are atomic ORs
 //   5 jpeg_ffcount_kernel        0xFF bytes per 64-byte chunk and per 256-chunk tile
-//   6 jpeg_stuff_kernel          byte-stuffed copy behind the header (+ header, EOI, size from block 0)
+//   6 jpeg_stuff_kernel          byte-stuffed copy behind the header (+ header, EOI, size from block 0), staged through LDS so that
+//                                global memory sees aligned 16-byte stores (round 5)
 #include "common.h"
 #include <string.h>
 #include <initializer_list>
@@ -214,6 +216,7 @@ jpeg_dct_kernel(const void* __restrict__ frames, uint8_t* __restrict__ ws, JpegG
     __shared__ uint16_t sQ8[2][64];
     __shared__ uint32_t sMagic[2][64];
     __shared__ uint8_t sN2Z[64];
+    __shared__ uint8_t sAcLen[2][256];         // code length of every AC symbol (round 5: the AC bit count happens here)
 
     const int tid = threadIdx.x;
     const int mrow = blockIdx.y, mcol0 = blockIdx.x * DCT_MCUS, f = blockIdx.z;
@@ -223,6 +226,7 @@ jpeg_dct_kernel(const void* __restrict__ frames, uint8_t* __restrict__ ws, JpegG
 
     if (tid < 128) { sQ8[tid >> 6][tid & 63] = tb.q8[tid >> 6][tid & 63]; sMagic[tid >> 6][tid & 63] = tb.magic[tid >> 6][tid & 63]; }
     if (tid < 64) sN2Z[tid] = tb.nat2zig[tid];
+    for (int i = tid; i < 512; i += 256) sAcLen[i >> 8][i & 255] = (uint8_t)(tb.ac[i >> 8][i & 255] >> 16);
 
     // colour conversion + h2v2: 4 pixels x 2 rows (two 2x2 quads) per step.  Columns are edge-replicated on the INPUT
     // (expand_right_edge); rows: luma replicates the last row, chroma replicates its last DOWNSAMPLED row (jcprepct.c),
@@ -285,9 +289,60 @@ jpeg_dct_kernel(const void* __restrict__ frames, uint8_t* __restrict__ ws, JpegG
     }
     __syncthreads();
 
+    // Round 5: the AC half of jchuff.c's bit count, here, while the quantised block is still in LDS -- the COUNT pass used to re-read
+    // all 12.5 MB of coefficients (one lane per block, eight 16-byte loads at a 128-byte lane stride) just to add code lengths.  Eight
+    // lanes per block, eight zigzag positions each: a non-zero coefficient at position k after a run r of zeros costs
+    // (r >> 4) len(ZRL) + len(ac[(r & 15) << 4 | nbits]) + nbits, r = k - 1 - (last non-zero position before k, or 0 = the DC slot);
+    // the run crosses lanes through a max-scan of "last non-zero position" over the block's eight lanes; + len(EOB) unless
+    // position 63 is non-zero.  The DC term needs the previous block's DC (another thread block's): jpeg_count_kernel adds it.
+    uint16_t* acbits = (uint16_t*)(wsf + g.off_blkbits);
+    const bool row1 = (2 * mrow + 1) < g.ybh;
+    for (int task = tid; task < ((nm * 6 * 8 + 63) & ~63); task += 256) {          // (whole waves: the shuffles need every lane)
+        const bool live = task < nm * 6 * 8;
+        const int blk = live ? task >> 3 : 0, seg = task & 7, m = blk / 6, b = blk % 6, tbl = b >= 4;
+        const uint4 c4 = *(const uint4*)&sZ[blk][8 * seg];
+        const uint32_t cw[4] = {c4.x, c4.y, c4.z, c4.w};
+        int v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = (int)(short)(cw[i] & 0xffffu); v[2 * i + 1] = (int)(short)(cw[i] >> 16); }
+        if (seg == 0) v[0] = 0;                                                     // position 0 is the DC
+        int last = 0;                                                               // last non-zero position of this segment (0: none)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (v[i] != 0) last = 8 * seg + i;
+        int prev = last;                                                            // inclusive max-scan over the 8 lanes of the block
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { const int t = __shfl_up(prev, o, 8); if (seg >= o) prev = max(prev, t); }
+        int before = __shfl_up(prev, 1, 8);                                         // exclusive: last non-zero position before this segment
+        if (seg == 0) before = 0;
+        uint32_t bits = 0;
+        const uint32_t zrl = sAcLen[tbl][0xF0];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (v[i] != 0) {
+                const int k = 8 * seg + i, run = k - 1 - before;
+                const int a = v[i] < 0 ? -v[i] : v[i], nb = 32 - __builtin_clz(a);
+                bits += (uint32_t)(run >> 4) * zrl + sAcLen[tbl][((run & 15) << 4) | nb] + (uint32_t)nb;
+                before = k;
+            }
+        }
+        if (seg == 7 && before != 63) bits += sAcLen[tbl][0];                       // end of block
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) bits += __shfl_xor(bits, o, 8);
+        if (live && seg == 0) {
+            // dummy blocks (below) carry the DC of their source and no AC: EOB only
+            const bool col1 = (2 * (mcol0 + m) + 1) < g.ybw;
+            const int s1 = col1 ? 1 : 0;
+            int src = b;
+            if (b == 1) src = s1;
+            else if (b == 2) src = row1 ? 2 : s1;
+            else if (b == 3) src = row1 ? (col1 ? 3 : 2) : s1;
+            const long mcu = (long)mrow * g.mc + mcol0 + m;
+            acbits[mcu * 6 + b] = (uint16_t)(src == b ? bits : (uint32_t)sAcLen[tbl][0]);
+        }
+    }
+
     // dummy blocks (jccoefct.c compress_data) + coefficient store: 32 threads per block, two zigzag positions each
     uint32_t* coefs = (uint32_t*)wsf;
-    const bool row1 = (2 * mrow + 1) < g.ybh;
     for (int task = tid; task < nm * 6 * 32; task += 256) {
         const int blk = task >> 5, k2 = task & 31, m = blk / 6, b = blk % 6;
         const bool col1 = (2 * (mcol0 + m) + 1) < g.ybw;
@@ -452,6 +507,32 @@ jpeg_entropy_kernel(uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
     if (s.fill > 0 && s.acc) atomicOr(&s.stream[s.w], s.acc);
 }
 
+// stage 2 (round 5): bits per block = the AC bits jpeg_dct_kernel left in blkbits[] + the DC term (needs the predecessor's DC, which
+// may belong to another thread block of stage 1); bits per 256-block tile.  Reads 2 + 2 bytes per block instead of 128.
+__global__ void __launch_bounds__(256)
+jpeg_count_kernel(uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
+    __shared__ uint32_t s_w[8];
+    const int tid = threadIdx.x;
+    uint8_t* wsf = ws + (long)blockIdx.y * g.ws_frame;
+    const long nblk = (long)g.nmcu * 6;
+    const long gb = (long)blockIdx.x * 256 + tid;
+    const bool active = gb < nblk;
+    uint32_t bits = 0;
+    uint16_t* blkbits = (uint16_t*)(wsf + g.off_blkbits);
+    if (active) {
+        const long m = gb / 6;
+        const int b = (int)(gb % 6), tbl = b >= 4;
+        const short* dcs = (const short*)(wsf + g.off_dcs);
+        const int dcdiff = (int)dcs[m * 8 + b] - dc_pred(dcs, m, b);
+        const int a = dcdiff < 0 ? -dcdiff : dcdiff;
+        const int nb = a ? 32 - __builtin_clz(a) : 0;
+        bits = (uint32_t)blkbits[gb] + (tb.dc[tbl][nb] >> 16) + (uint32_t)nb;
+        blkbits[gb] = (uint16_t)bits;
+    }
+    const uint32_t sum = block256_sum(bits, s_w);
+    if (tid == 0) ((uint32_t*)(wsf + g.off_tiles))[blockIdx.x] = sum;
+}
+
 // stage 3: zero the words of the stream that will be used; block 0 publishes the (byte-padded) total bit count
 __global__ void __launch_bounds__(256)
 jpeg_zero_kernel(uint8_t* __restrict__ ws, JpegGeom g) {
@@ -502,11 +583,18 @@ jpeg_ffcount_kernel(uint8_t* __restrict__ ws, JpegGeom g) {
     if (threadIdx.x == 0) ((uint32_t*)(wsf + g.off_fftiles))[blockIdx.x] = sum;
 }
 
-// byte-stuffed copy behind the header; block 0 also writes the header, the EOI marker and the size
+// byte-stuffed copy behind the header; block 0 also writes the header, the EOI marker and the size.
+// Round 5: through LDS.  A thread's 64 stream bytes land at an arbitrary byte offset of the output (header + chunk + the 0xFF count
+// before it), so the per-byte global stores of rounds 1-4 were the whole cost of this pass (21 us of an 88 us encode).  A block's 256
+// chunks form ONE contiguous output span (<= 32 KiB: every byte a 0xFF); the threads stuff into an LDS image of that span laid out with
+// the span's own 16-byte phase, and the block then copies the image out as aligned 16-byte stores (the ragged first / last 16-byte
+// group, which the neighbouring blocks share, byte by byte).
+constexpr int STUFF_LDS = 256 * 128 + 32;
 __global__ void __launch_bounds__(256)
 jpeg_stuff_kernel(const uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb, uint8_t* __restrict__ out, long out_stride,
                   int* __restrict__ sizes) {
     __shared__ uint32_t s_w[8];
+    __shared__ __attribute__((aligned(16))) uint8_t img[STUFF_LDS];
     const uint8_t* wsf = ws + (long)blockIdx.y * g.ws_frame;
     const uint32_t nbytes = *(const uint32_t*)(wsf + g.off_total) >> 3;
     if ((long)blockIdx.x * 256 * 64 >= nbytes) return;
@@ -527,20 +615,42 @@ jpeg_stuff_kernel(const uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb, uin
     const bool live = chunk * 64 < nbytes;
     const uint32_t mine = live ? ((const uint32_t*)(wsf + g.off_ffcnt))[chunk] : 0u;
     const uint32_t before = prefix + block256_exscan(mine, s_w);
-    if (!live || !fits) return;                                       // output too small: nothing but the size (-1) is written
-    o += HDR_LEN + chunk * 64 + before;
-    const uint4* p = (const uint4*)(wsf + g.off_stream + chunk * 64);
-    const int n = (int)min((long)64, (long)nbytes - chunk * 64);
-    for (int i = 0; i < 4; ++i) {
-        uint4 v = p[i];
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        for (int k = 0; k < 4; ++k)
-            for (int q = 0; q < 4; ++q) {
-                if (i * 16 + k * 4 + q >= n) return;
-                uint8_t byte = (uint8_t)(w[k] >> (24 - 8 * q));
-                *o++ = byte;
-                if (byte == 0xff) *o++ = 0;                           // jchuff.c emit_byte: stuff a zero after 0xFF
-            }
+    const uint32_t block_ff = block256_sum(mine, s_w);                // (every thread takes part in the block sums)
+    if (!fits) return;                                                // output too small: nothing but the size (-1) is written
+    // this block's output span [lo, hi) in bytes of the frame's output buffer
+    const long c0 = (long)blockIdx.x * 256;
+    const long in_bytes = min((long)256 * 64, (long)nbytes - c0 * 64);
+    const long lo = (long)HDR_LEN + c0 * 64 + prefix, hi = lo + in_bytes + block_ff;
+    const uint8_t* dst0 = o + lo;
+    const int phase = (int)((uintptr_t)dst0 & 15);                    // img[phase + i] <-> dst0[i]
+    if (live) {
+        int p = phase + (int)((chunk - c0) * 64 + (before - prefix));
+        const uint4* src = (const uint4*)(wsf + g.off_stream + chunk * 64);
+        const int n = (int)min((long)64, (long)nbytes - chunk * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 v = src[i];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (i * 16 + k * 4 + q < n) {
+                        const uint8_t byte = (uint8_t)(w[k] >> (24 - 8 * q));
+                        img[p++] = byte;
+                        if (byte == 0xff) img[p++] = 0;               // jchuff.c emit_byte: stuff a zero after 0xFF
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    const int span = (int)(hi - lo);
+    uint8_t* base = o + lo - phase;                                   // 16-byte aligned; img[i] <-> base[i] for i in [phase, phase + span)
+    const int groups = (phase + span + 15) >> 4;
+    for (int gi = threadIdx.x; gi < groups; gi += 256) {
+        const int b0 = gi * 16;
+        if (b0 >= phase && b0 + 16 <= phase + span) *(uint4*)(base + b0) = *(const uint4*)(img + b0);
+        else for (int q = max(b0, phase); q < min(b0 + 16, phase + span); ++q) base[q] = img[q];
     }
 }
 
@@ -575,7 +685,7 @@ extern "C" int d2s_jpeg_encode(const void* frames, int fmt, int batch, int H, in
     if (fmt == D2S_FMT_U8_HWC) hipLaunchKernelGGL(jpeg_dct_kernel<D2S_FMT_U8_HWC>, g1, dim3(256), 0, st, frames, ws, g, tb);
     else hipLaunchKernelGGL(jpeg_dct_kernel<D2S_FMT_F32_HWC>, g1, dim3(256), 0, st, frames, ws, g, tb);
     const dim3 ge(cdiv((long)g.nmcu * 6, 256), batch), gc(cdiv(g.n_chunks, 256), batch);
-    hipLaunchKernelGGL(jpeg_entropy_kernel<false>, ge, dim3(256), 0, st, ws, g, tb);
+    hipLaunchKernelGGL(jpeg_count_kernel, ge, dim3(256), 0, st, ws, g, tb);
     hipLaunchKernelGGL(jpeg_zero_kernel, dim3(cdiv(g.cap_words, 4096), batch), dim3(256), 0, st, ws, g);
     hipLaunchKernelGGL(jpeg_entropy_kernel<true>, ge, dim3(256), 0, st, ws, g, tb);
     hipLaunchKernelGGL(jpeg_ffcount_kernel, gc, dim3(256), 0, st, ws, g);
