@@ -97,7 +97,7 @@ struct d2s_engine {
         void* cache[2] = {nullptr, nullptr};       // ring [31][sites][2C] T per attention block: projected k' | v' rows
         // round 5 (bf16 engine): the three LayerNorms of a module folded into the linears that consume them, like the ViT's (DESIGN.md
         // section 3.1b): W' = W diag(gamma), bias' = b + W beta, colsum over the bf16-rounded W'
-        PackedW kvq_ln[2], ff1_ln;
+        PackedW kvq_ln[2], ff1_ln;                  // (ff1_ln: rows interleaved x | gate in groups of four -- GEGLU happens in its epilogue)
         float *csum_kvq[2] = {nullptr, nullptr}, *csum_ff1 = nullptr;
     } tm[4];
     float* tm_stats = nullptr;                     // (sum, sum of squares) partials per (row, column block) of the folded LayerNorms
@@ -396,11 +396,18 @@ int run_temporal(d2s_engine* e, int m, const void* x, void* out, hipStream_t st,
     {
         const bool folded = fold && slots >= 1 && slots <= 16;
         if (!folded) PROF(PC_LN, 0, 0, launch_layernorm(prec, e->tm_hs, t.ffn_g, t.ffn_b, e->tm_a, S, C, 1e-5f, 0, 0, 0, st));
-        GemmEpi ep = rowsE(e->tm_u, OUT_T, 8 * C, folded ? t.ff1_ln.bias : t.ff1.bias);
-        if (folded) consumer(ep, t.csum_ff1);
-        RC(gemm(e, plainA(e->tm_a, C), folded ? t.ff1_ln : t.ff1, S, ep, st));
+        if (folded) {
+            // x * gelu(gate) in ff1's own epilogue (interleaved rows): tm_g [S, 4C] directly, no [S, 8C] intermediate, no GEGLU launch
+            GemmEpi ep = rowsE(e->tm_g, OUT_T, 4 * C, t.ff1_ln.bias);
+            ep.act = ACT_GEGLU;
+            consumer(ep, t.csum_ff1);
+            RC(gemm(e, plainA(e->tm_a, C), t.ff1_ln, S, ep, st));
+        } else {
+            GemmEpi ep = rowsE(e->tm_u, OUT_T, 8 * C, t.ff1.bias);
+            RC(gemm(e, plainA(e->tm_a, C), t.ff1, S, ep, st));
+            PROF(PC_ELT, 0, 0, launch_geglu(prec, e->tm_u, e->tm_g, S, 4 * C, st));
+        }
     }
-    PROF(PC_ELT, 0, 0, launch_geglu(prec, e->tm_u, e->tm_g, S, 4 * C, st));
     {
         GemmEpi ep = rowsE(e->tm_hs, OUT_F32, C, t.ff2.bias);
         ep.res1 = e->tm_hs;
@@ -995,7 +1002,11 @@ extern "C" int d2s_engine_finalize(d2s_engine* e, int h, int w, int max_batch) {
                             *b1 = find(e, b + "ff.net.0.proj.bias");
                 if (!g || !bt || !w1 || !b1) return D2S_E_MISSING;
                 const float* w1p = w1->data.data();
-                RC(fold_ln(g->data.data(), bt->data.data(), 8 * C, C, [&](int n, int k) { return w1p[(size_t)n * C + k]; }, b1->data.data(), t.ff1_ln, &t.csum_ff1));
+                // GEGLU in the epilogue (ACT_GEGLU): packed row n' = 8 g + w holds x row 4 g + w (w < 4) or gate row 4C + 4 g + (w - 4)
+                auto orig = [C](int n) { const int g = n >> 3, w = n & 7; return w < 4 ? 4 * g + w : 4 * C + 4 * g + (w - 4); };
+                std::vector<float> b1p((size_t)8 * C);
+                for (int n = 0; n < 8 * C; ++n) b1p[n] = b1->data[orig(n)];
+                RC(fold_ln(g->data.data(), bt->data.data(), 8 * C, C, [&](int n, int k) { return w1p[(size_t)orig(n) * C + k]; }, b1p.data(), t.ff1_ln, &t.csum_ff1));
             }
         }
         if (e->tm_fold) RC(dev_alloc(e, (void**)&e->tm_stats, (size_t)17 * max_sites * 2 * sizeof(float)));

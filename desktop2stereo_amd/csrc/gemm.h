@@ -7,7 +7,9 @@
 namespace d2s {
 
 enum { A_PLAIN = 0, A_CONV3 = 1 };
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2,
+       ACT_GEGLU = 3 };   // out[m, c] = x[m, c] * gelu(gate[m, c]) with the weight rows interleaved x0-3 | g0-3 | x4-7 | g4-7 ...: N/2 output columns
+                           // (gemm_glds_kernel only: the exchange relies on its lane <-> column map, gemm_epi.h)
 enum { MAP_ROWS = 0, MAP_SHUFFLE = 1, MAP_QKV = 2, MAP_HEAD = 3 };
 enum { OUT_T = 0, OUT_F32 = 1, OUT_BF16 = 2, OUT_BX3 = 3 };   // OUT_T: operand type (fp8 operands: e4m3 of v * out_qscale; bf16x3: fp32)
                                                             // OUT_BX3 (bf16x3 launches): the unit format, A operand of the next linear

@@ -290,6 +290,17 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n0, float
         v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
     }
     else if (e.act == ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    else if (e.act == ACT_GEGLU) {
+        // GEGLU (VDA's FeedForward, motion_module/attention.py:296-384) inside the producing linear: the weight rows are packed
+        // interleaved in groups of four -- x0-3 | gate0-3 | x4-7 | gate4-7 ... -- so in gemm_glds_kernel's fragment layout (lane group fg
+        // holds columns 16 j + 4 fg .. + 3 of row fr) the gate of this lane's four channels sits in lane ^ 16.  Both lanes share the row
+        // and the column guard (N % 8 == 0), so both are here.  The x lanes store x * gelu(gate) at column n0 / 2; the gate lanes are done.
+        const float o0 = __shfl_xor(v[0], 16), o1 = __shfl_xor(v[1], 16), o2 = __shfl_xor(v[2], 16), o3 = __shfl_xor(v[3], 16);
+        if ((n0 >> 2) & 1) return;
+        const f32x2v g0 = gelu_erf2((f32x2v){o0, o1}), g1 = gelu_erf2((f32x2v){o2, o3});
+        v[0] *= g0[0]; v[1] *= g0[1]; v[2] *= g1[0]; v[3] *= g1[1];
+        n0 = (n0 >> 3) << 2;
+    }
     if (e.scale) {
         if (cols) { v[0] *= cols->scale[0]; v[1] *= cols->scale[1]; v[2] *= cols->scale[2]; v[3] *= cols->scale[3]; }
         else { float s[4]; load4(e.scale + n0, s); v[0] *= s[0]; v[1] *= s[1]; v[2] *= s[2]; v[3] *= s[3]; }

@@ -146,9 +146,9 @@ def test_vda_vitb_stream_at_the_quoted_size(dev, golden_dir, prec, tol):
     """ViT-B VDA at 294 x 518 on 1080p frames -- the size BASELINE config 4's stream throughput is quoted on -- 3 frames of the
     REFERENCE's own streaming model (tests/golden/vda_vitb, make_golden_vda.py): fp32 and split-precision engines within 3e-4
     of the range.  The bf16 engine's bound is REFERENCE-DERIVED (round 5): tests/golden/vda_vitb_bf16 is the reference on the same
-    frames with its autocast on (forward(fp32=False), the `FP16: true` setting, vda2_s.py:193 -- bf16 on the CPU); over the
-    three frames the HIP bf16 engine must be no further from the reference's fp32 result than the reference's own reduced-precision
-    path is in the worst max, and within 5 % of its average mean (per-frame values printed; the strict form fails on the mean by 0.6 %), as tests/test_gpu_parity.py::test_bf16_engine_within_reference_bf16_class does for DA-v2."""
+    frames with its autocast on (forward(fp32=False), the `FP16: true` setting, vda2_s.py:193 -- bf16 on the CPU); on every
+    frame the HIP bf16 engine must be no further from the reference's fp32 result than the reference's own reduced-precision path is
+    (max and mean), as tests/test_gpu_parity.py::test_bf16_engine_within_reference_bf16_class does for DA-v2."""
     path = os.path.join(golden_dir, "vda_vitb.npz")
     assert os.path.exists(path), "tests/golden/vda_vitb.npz is part of the repo (python tests/golden/make_golden_vda.py vda_vitb)"
     from desktop2stereo_amd import ops, synth
@@ -180,10 +180,11 @@ def test_vda_vitb_stream_at_the_quoted_size(dev, golden_dir, prec, tol):
         assert worst <= tol, (prec, worst)
     else:       # over the three frames: worst max and average mean, HIP against the reference's own reduced-precision path
         a = np.array(pooled)
-        # measured (MI355X, round 5): HIP worst max 0.0148 <= the reference's 0.0154; HIP average mean 0.002521 against the reference's
-        # 0.002507 -- 0.6 % ABOVE it (the temporal modules' bf16 GEMMs have no counterpart in the DA-v2 engine, which passes the strict
-        # form of this gate).  The max is held strictly; the mean gets 5 % on top of the reference's own figure, stated here, not hidden.
-        assert a[:, 0].max() <= a[:, 2].max() and a[:, 1].mean() <= 1.05 * a[:, 3].mean(), pooled
+        # measured (MI355X, end of round 5, LayerNorm / GEGLU folded into the temporal linears): per frame HIP max 0.0133 / 0.0139 / 0.0120,
+        # mean 0.00225 / 0.00260 / 0.00231 against the reference's 0.0154 / 0.0153 / 0.0146 and 0.00242 / 0.00269 / 0.00241 -- inside
+        # the reference's own envelope on every frame, so the gate is the strict one, per frame (round 4's engine sat 0.6 % above on the mean)
+        for fi, (hmax, hmean, rmax, rmean) in enumerate(pooled):
+            assert hmax <= rmax and hmean <= rmean, (fi, hmax, hmean, rmax, rmean)
     eng.close()
 
 
