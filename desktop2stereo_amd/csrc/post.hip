@@ -168,12 +168,14 @@ struct GaussTaps { int k; float w[MAX_TAPS]; };
 
 // normalise + gamma + foreground-scale fused with the horizontal Gaussian pass: one block per row,
 // shaped row staged in LDS (zero padded), k taps out of LDS.
+template <int KT>      // taps known at compile time (13 = the reference's default): unrolled tap loops, weights in SGPRs; 0 = run-time count
 __global__ void __launch_bounds__(256)
 shape_hblur_kernel(const float* __restrict__ depth, const float* __restrict__ bounds, float* __restrict__ tmp,
                    int h, int w, float gamma, float fg_exp, int fg_on, int metric, GaussTaps taps) {
     extern __shared__ float row[];                       // w + 2r
     int y = blockIdx.x % h, b = blockIdx.x / h;
-    int r = taps.k / 2;
+    const int nt = KT ? KT : taps.k;
+    int r = nt / 2;
     float dmin = bounds[2 * b], dmax = bounds[2 * b + 1];
     const float* src = depth + ((long)b * h + y) * w;
     for (int i = threadIdx.x; i < w + 2 * r; i += 256) {
@@ -190,12 +192,15 @@ shape_hblur_kernel(const float* __restrict__ depth, const float* __restrict__ bo
     float* dst = tmp + ((long)b * h + y) * w;
     for (int x = threadIdx.x; x < w; x += 256) {
         float acc = 0.f;
-        if (taps.k >= 3) { for (int t = 0; t < taps.k; ++t) acc += taps.w[t] * row[x + t]; }
-        else acc = row[x + r];
+        if (nt >= 3) {
+#pragma unroll
+            for (int t = 0; t < nt; ++t) acc += taps.w[t] * row[x + t];
+        } else acc = row[x + r];
         dst[x] = acc;
     }
 }
 
+template <int KT>
 __global__ void __launch_bounds__(256)
 vblur_kernel(const float* __restrict__ tmp, float* __restrict__ out, int B, int h, int w, GaussTaps taps) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,11 +209,20 @@ vblur_kernel(const float* __restrict__ tmp, float* __restrict__ out, int B, int 
     int y = (int)((idx / w) % h);
     int b = (int)(idx / ((long)w * h));
     const float* p = tmp + (long)b * h * w + x;
-    int r = taps.k / 2;
+    const int nt = KT ? KT : taps.k;
+    int r = nt / 2;
+    // (compile-time tap count: all column loads are issued before the first product -- with a run-time count every tap was a scalar
+    //  load of its weight plus a dependent global load, 13 round trips per pixel)
+    float v[KT ? KT : 1];
+    if constexpr (KT != 0) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t) { const int yy = y + t - r; v[t] = (yy >= 0 && yy < h) ? p[(long)yy * w] : 0.f; }
+    }
     float acc = 0.f;
-    for (int t = 0; t < taps.k; ++t) {
+#pragma unroll
+    for (int t = 0; t < nt; ++t) {
         int yy = y + t - r;
-        if (yy >= 0 && yy < h) acc += taps.w[t] * p[(long)yy * w];
+        if (yy >= 0 && yy < h) acc += taps.w[t] * (KT ? v[KT ? t : 0] : p[(long)yy * w]);
     }
     out[idx] = acc;
 }
@@ -284,7 +298,7 @@ post_fused_kernel(const float* __restrict__ depth_in, float* __restrict__ out, f
     constexpr int PER = SORT_N / PF_THREADS;
     __shared__ __attribute__((aligned(16))) unsigned lds_u[2 * 2 * PF_BINS];          // two buffers x two targets; the tile planes alias them afterwards
     __shared__ unsigned red_min[PF_THREADS / 64], red_max[PF_THREADS / 64];
-    __shared__ unsigned sel_lo[2], sel_rank[2];
+    __shared__ unsigned sel_lo[2], sel_rank[2], sel_n[2], sel_cnt[2], sel_res[2];
     static_assert(sizeof(float) * (PF_HR * PF_WR + PF_HR * PF_TC) <= sizeof(unsigned) * 4 * PF_BINS, "tile planes alias the histograms");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.z, y0 = blockIdx.y * PF_TR, x0 = blockIdx.x * PF_TC;
@@ -331,6 +345,99 @@ post_fused_kernel(const float* __restrict__ depth_in, float* __restrict__ out, f
     int shift = bits > PF_BITS ? bits - PF_BITS : 0;
     const bool all = tail >= m;                                         // depth.py:790-791: (min, max)
     unsigned lo0 = kmin, lo1 = kmin, rk0 = all ? 0u : (unsigned)(tail - 1), rk1 = all ? (unsigned)(m - 1) : (unsigned)(m - tail);
+    // ---- fast path (round 5): ONE value-linear histogram pass + ranking of the target bins' few candidates.  The radix passes below bin
+    // key BITS: a depth map's keys share their exponent bits, so the first pass piles 6 000 keys on ~50 bins (serialised LDS atomics) and
+    // three passes are needed (6.8 us of the 16 us kernel, profiles/r5_01).  Binning floor((v - vmin) * (BINS - 1) / (vmax - vmin)) is monotone
+    // non-decreasing in the key order too (rounding is monotone), so the keys of lower bins are strictly smaller than those of the target's
+    // bin and the order statistic is the (rank - lower count)-th smallest KEY of that bin: the same element the radix select returns.
+    // Both targets share the histogram.  Taken when the value range is finite and both target bins hold <= PF_CAND keys (a map with
+    // thousands of identical values -- ReLU zeros -- falls through to the radix passes).
+    constexpr int PF_CAND = 512;
+    bool done = false;
+    {
+        const float vmin = key2f(kmin), vmax = key2f(kmax), rng = vmax - vmin;
+        if (kmin != kmax && rng > 0.f && rng < 3.0e38f && fabsf(vmin) < 3.0e38f) {                 // (block-uniform; NaN / Inf keys fail it)
+            // bins 0 and BINS-1 hold ONLY the values equal to the minimum / maximum (a ReLU head leaves hundreds of exact zeros in the
+            // subsample, a sigmoid head saturates at the top): a target that lands there is the minimum / maximum itself, no candidates
+            const float bscale = (float)(PF_BINS - 2) / rng;
+            auto bin_of = [&](uint32_t k) {
+                const float v = key2f(k);
+                if (v <= vmin) return 0u;
+                if (v >= vmax) return (unsigned)(PF_BINS - 1);
+                return 1u + (unsigned)min(max((int)((v - vmin) * bscale), 0), PF_BINS - 3);
+            };
+            unsigned* hist = lds_u;                                     // buffer 0, target-0 half: zero since the start of the kernel
+            unsigned* cand = lds_u + 2 * PF_BINS;                       // buffer 1: 2 x PF_CAND candidate keys
+            unsigned mybin[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                mybin[i] = 0xffffffffu;
+                if (tid + i * PF_THREADS < m) { mybin[i] = bin_of(key[i]); atomicAdd(&hist[mybin[i]], 1u); }
+            }
+            if (tid < 2) sel_cnt[tid] = 0u;
+            __syncthreads();
+            if (wid < 2) {                                              // wave t resolves target t: 32 consecutive bins per lane
+                typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+                const u4_* hp = (const u4_*)(hist + 32 * lane);
+                u4_ c[8];
+                unsigned s_ = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { c[q] = hp[q]; s_ += (c[q][0] + c[q][1]) + (c[q][2] + c[q][3]); }
+                unsigned incl = s_;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+                const unsigned excl = incl - s_, target = wid == 0 ? rk0 : rk1;
+                if (target >= excl && target < incl) {
+                    unsigned rr = target - excl, bin = 0, cnt_b = 0;
+                    bool found = false;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned cnt = c[q][k];
+                            if (!found) { if (rr < cnt) { found = true; bin = 4 * q + k; cnt_b = cnt; } else rr -= cnt; }
+                        }
+                    const unsigned tb = 32u * lane + bin;
+                    const bool edge = tb == 0u || tb == (unsigned)(PF_BINS - 1);
+                    sel_lo[wid] = tb;                                   // (here: the target's BIN)
+                    sel_rank[wid] = rr;
+                    sel_n[wid] = edge ? 0u : cnt_b;                     // an edge bin's keys all equal the minimum / maximum value
+                    sel_res[wid] = tb == 0u ? kmin : kmax;              // (overwritten by the ranking unless the bin is an edge bin)
+                }
+            }
+            __syncthreads();
+            const unsigned b0 = sel_lo[0], b1 = sel_lo[1], r0 = sel_rank[0], r1 = sel_rank[1], n0 = sel_n[0], n1 = sel_n[1];
+            if (n0 <= (unsigned)PF_CAND && n1 <= (unsigned)PF_CAND) {   // (block-uniform)
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    if (n0 && mybin[i] == b0) cand[atomicAdd(&sel_cnt[0], 1u)] = key[i];
+                    if (n1 && mybin[i] == b1) cand[PF_CAND + atomicAdd(&sel_cnt[1], 1u)] = key[i];
+                }
+                __syncthreads();
+                // threads 0 .. n0-1 rank list 0, threads 512 .. 512+n1-1 rank list 1: the element with  #{u < v} <= r < #{u <= v}
+                const int li = tid >> 9, ti = tid & 511;
+                const unsigned nn = li ? n1 : n0, rr = li ? r1 : r0;
+                if ((unsigned)ti < nn) {
+                    const unsigned* L = cand + li * PF_CAND;
+                    const unsigned v = L[ti];
+                    unsigned less = 0, leq = 0;
+                    for (unsigned u = 0; u < nn; ++u) { const unsigned x = L[u]; less += x < v; leq += x <= v; }
+                    if (less <= rr && rr < leq) sel_res[li] = v;        // (equal keys write the same value)
+                }
+                __syncthreads();
+                lo0 = sel_res[0]; lo1 = sel_res[1];
+                done = true;
+            } else {
+                // fall through to the radix passes: they expect both histogram buffers at zero
+                __syncthreads();
+                typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+                ((u4_*)lds_u)[tid] = (u4_){0u, 0u, 0u, 0u};
+                ((u4_*)lds_u)[tid + PF_THREADS] = (u4_){0u, 0u, 0u, 0u};
+                __syncthreads();
+            }
+        }
+    }
+    if (!done)
     for (int pass = 0;; ++pass) {
         unsigned* hist = lds_u + (pass & 1) * (2 * PF_BINS);
 #pragma unroll
@@ -519,9 +626,15 @@ extern "C" int d2s_post_process_to(const float* depth_in, float* depth_out, int 
         D2S_CHECK_LAUNCH();
         return D2S_OK;
     }
-    hipLaunchKernelGGL(shape_hblur_kernel, dim3(batch * h), dim3(256), (w + 2 * r) * sizeof(float), st,
-                       depth, bounds, tmp, h, w, p->gamma, fg_exp, fg_on, p->metric != 0, taps);
-    hipLaunchKernelGGL(vblur_kernel, dim3(cdiv((long)batch * h * w, 256)), dim3(256), 0, st, tmp, depth_out, batch, h, w, taps);
+    if (taps.k == 13) {
+        hipLaunchKernelGGL(shape_hblur_kernel<13>, dim3(batch * h), dim3(256), (w + 2 * r) * sizeof(float), st,
+                           depth, bounds, tmp, h, w, p->gamma, fg_exp, fg_on, p->metric != 0, taps);
+        hipLaunchKernelGGL(vblur_kernel<13>, dim3(cdiv((long)batch * h * w, 256)), dim3(256), 0, st, tmp, depth_out, batch, h, w, taps);
+    } else {
+        hipLaunchKernelGGL(shape_hblur_kernel<0>, dim3(batch * h), dim3(256), (w + 2 * r) * sizeof(float), st,
+                           depth, bounds, tmp, h, w, p->gamma, fg_exp, fg_on, p->metric != 0, taps);
+        hipLaunchKernelGGL(vblur_kernel<0>, dim3(cdiv((long)batch * h * w, 256)), dim3(256), 0, st, tmp, depth_out, batch, h, w, taps);
+    }
     D2S_CHECK_LAUNCH();
     return D2S_OK;
 }
