@@ -38,10 +38,11 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-# dense MFMA peaks, MI355X_MICROARCH.md.  "fp8": the engine's e4m3 linears run v_mfma_f32_16x16x32_fp8_fp8, the NON-scaled
-# form, which issues at the bf16 rate (guide: "non-scaled fp8 = BF16 rate") -- so it is priced against 2.5 PF, not the 5 PF
-# of the MX-scaled K=128 instruction it does not use.
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp8": 2500.0, "bf16x3": 2500.0 / 3}      # bf16x3: three bf16 MFMAs per product
+# dense MFMA peaks, MI355X_MICROARCH.md.  "fp8": from round 5 the batched e4m3 linears (gemm_pp) run the scaled K=64 instruction
+# v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales), which issues at twice the bf16 rate -> priced against the 5 PF dense fp8 peak.
+# (The small-batch tiles of gemm_glds still use the non-scaled v_mfma_f32_16x16x32_fp8_fp8 = the bf16 rate; pricing them against
+# 5 PF too is the conservative side.)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp8": 5000.0, "bf16x3": 2500.0 / 3}      # bf16x3: three bf16 MFMAs per product
 PEAK_HBM_GBS = 8000.0                          # HBM3E spec
 SURVEY_GF_PER_FRAME = {("vitb", 518): 176.9, ("vits", 518): 45.8, ("vitl", 518): 635.9,
                        ("vitb", 336): 76.5, ("vits", 336): 19.8, ("vitl", 336): 275.2}
@@ -765,9 +766,9 @@ def rank_body(args, engine_factory=None, device=None):
                 dd = np.abs(post - ref3[0])
                 row.update(depth_l1_vs_ref=float(dd.mean()), depth_max_vs_ref=float(dd.max()))
             if prec3 != "bf16":
-                # the encoder linears of this engine against the MFMA rate they actually issue at (non-scaled e4m3 = the bf16 rate, 2.5 PF)
+                # the encoder linears of this engine against the dense fp8 peak (5 PF): the 256 x 256 tiles run the scaled K = 64 MFMA
                 pr = profile_pass(e3, lambda i: e3.pipeline(pool3b, p3, sp3, use_ema=False, out=out3b), 4, B3, "fp8", sync)
-                row["roofline"] = dict(pr["roofline"], note="batch 8; e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8 (non-scaled: bf16 issue rate, priced against 2.5 PF)")
+                row["roofline"] = dict(pr["roofline"], note="batch 8; e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (256 x 256 tiles) / v_mfma_f32_16x16x32_fp8_fp8 (smaller tiles); priced against the 5 PF dense fp8 peak")
                 if emu3 is not None:
                     row["reference_emulation"] = emu3["all four e4m3" if prec3 == "fp8" else "MLP only (FC1 + FC2)"]
             rows3[prec3] = row
@@ -778,7 +779,7 @@ def rank_body(args, engine_factory=None, device=None):
             fp8_mlp_over_bf16_batch8=rows3["fp8_mlp"]["batch8"]["value"] / rows3["bf16"]["batch8"]["value"],
             workload="DepthAnything-v2-vitl, 3840x2160 uint8 noise frames, batch 1 (and batch 8), Depth Resolution 518 (CPU-branch ::3 decimation, model "
                      "input 294x518), Full-TAB uint8 output 3840x4320 (BASELINE configs[2]); depth error vs tests/golden/vitl_r518_4k (structured frame); "
-                     "fp8 = e4m3 operands on all four encoder linears, fp8_mlp = on FC1 / FC2 only (QKV / proj bf16); non-scaled e4m3 MFMA (bf16 issue "
+                     "fp8 = e4m3 operands on all four encoder linears, fp8_mlp = on FC1 / FC2 only (QKV / proj bf16); scaled K = 64 e4m3 MFMA in the 256 x 256 tiles (2 x the bf16 issue "
                      "rate), static per-tensor activation scales; reference_emulation = the reference's own model under the same operand quantisation "
                      "(tests/golden/fp8_frontier_vitl_4k.json)")
     if rank == 0 and world == 1 and not fake and default_run and not args.no_config3:

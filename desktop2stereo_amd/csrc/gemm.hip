@@ -773,8 +773,8 @@ static void small_tile_of(int M, int N, int& bm, int& bn) {
 //  count (descriptor addressing: +2 %), the K-tile size (256-byte tiles: +-0) and split-K for FC2 (-5 %), cold weights are not
 //  what paces the batch-1 launches.)
 int gemm_pp_min_tiles() {
-    static const int v = getenv("D2S_GEMM_PP") ? atoi(getenv("D2S_GEMM_PP")) : 100;
-    return v;
+    static EnvInt v{"D2S_GEMM_PP", 100};                  // (re-read after d2s_debug_reload_env: the tests switch regimes inside one process)
+    return v.get();
 }
 
 template <typename T>

@@ -62,13 +62,19 @@ namespace d2s {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-// e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 (mma64 / PPFrag<true> below; D2S_HIPCC_DEFS=-DPP_FP8_K64=1): the fragment
-// chunks become 8-register operand tuples and a quadrant is 4 MFMAs of 64 cycles instead of 16 of 32.  Correct (pp_check
-// --prec fp8), and the 48-K-tile FC2 runs at 1 219 TFLOP/s (96 us at batch 32) -- but the last two K tiles of every
-// tile spill ~90 dwords around the tuples, and with 6 K tiles per tile (K = 768) that costs more than the faster MFMAs give:
-// batch 32 fp8 2 820 vs 3 000 frames/s.  Off.
+// e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 (mma64 / PPFrag<true> below): the fragment chunks become 8-register operand
+// tuples and a quadrant is 4 MFMAs of 64 cycles instead of 16 of 32 (twice the e4m3 rate of v_mfma_f32_32x32x16_fp8_fp8, which
+// issues at the bf16 rate).  History: built in round 3 and left off because "the last two K tiles of every tile spill ~90 dwords
+// around the tuples" (batch 32 fp8: 2 820 vs 3 000 frames/s).  Round 5 read the ISA: nothing to do with the tuples -- the results of
+// the last two K tiles are only read by the epilogue, and the compiler SANK their 32 MFMAs below the phase barriers into the
+// epilogue's block (operands spilled on the way); one empty asm per quadrant pins them in place (PP_MFMA): 0 spills in kinds 0-2,
+// QKV 955 -> 1 112, FC1 888 -> 1 006, proj 643 -> 768, FC2 1 042 -> 1 375 TFLOP/s at batch 32 (tools/pp_check.py --prec fp8 --bench),
+// same bits.  On by default; -DPP_FP8_K64=0 builds the non-scaled path.
 #ifndef PP_FP8_K64
-#define PP_FP8_K64 0
+#define PP_FP8_K64 1
+#endif
+#ifndef PP_CV_DEQ
+#define PP_CV_DEQ 1                            // (bisecting aid) e4m3 residual launches keep their column vectors in LDS
 #endif
 constexpr int PP_TAIL_MAX = GEMM_PART_CTR_WORDS / 4;   // tail tiles an in-kernel tail reduce can count (4 counter words each, BEHIND the part_elems partials: gemm.h)
 constexpr int PP_AUX_SC0_SC1 = 0x11;          // buffer-instruction cache policy on gfx950: bit 0 = sc0, bit 4 = sc1 (write-through / system scope)
@@ -178,7 +184,7 @@ __device__ __forceinline__ f32x4 pp_act4(f32x4 v) {
 //     in fixed order (bit-reproducible): one float2 per (row, 256-column tile) in stats_out[tile column][M];
 //   consumer (PP_EP_BF16 / PP_EP_VT): A is that raw bf16 residual, W is gamma-folded; v = rstd[m] (acc - mean[m] colsum[n]) + bias
 //     with mean / rstd from the <= 4 partials per row (the two K halves of a lane pair load two slots each).
-template <int MODE, int ACT, bool DEQ, bool RES, bool IDENT = false, bool LN = false, typename HOOK>
+template <int MODE, int ACT, bool DEQ, bool RES, bool IDENT = false, bool LN = false, bool OUT8 = false /* PP_EP_BF16 only: e4m3 output (v * out_qscale), 64-byte row segments */, typename HOOK>
 __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& e, int bm0, int bn0, int M /* rows that exist FOR THIS UNIT: a row-split tail unit clips at the end of its slice */,
                                             int Mfull /* rows of the matrix (leading dimension of the statistics) */, int grp, int wn,
                                             int lane, u32x4* stg, float2* lnred, float* colv, HOOK&& hook,
@@ -190,6 +196,9 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
     // quad (j, q4) of this lane = columns wn0 + j * 32 + 8 * q4 + 4 * kg .. + 3
     if constexpr (MODE == PP_EP_F32) {
         // out = res + scale * (deq * acc + bias) = res + ca * acc + cc  with  ca = scale * deq,  cc = scale * bias
+        // CV: the two column vectors live in LDS (`colv`) instead of 64 pinned VGPRs -- the LN producer, and every e4m3 launch
+        // (kind 3 with DEQ spilled 86 registers around its three epilogue variants)
+        constexpr bool CV = LN || (DEQ && !IDENT && PP_CV_DEQ);
         f32x4 ca[2][4], cc[2][4];                    // per column half j
         f32x4 res[PP_RING][4];                       // residual prefetch ring: pass p = j * 4 + i
         // raw buffers over [M][ldc]: one per-lane byte offset serves every row of every pass (+ a wave-uniform term), and
@@ -219,8 +228,8 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
                 res[p % PP_RING][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo + ((i * 32 + r * 8) * ldc + j * 32) * 4u, 0, 0));
         };
         // IDENT: raw accumulators (the partial sums of a K split go to their slab untouched)
-        if constexpr (!IDENT && !LN) col_load(std::integral_constant<int, 0>{});
-        if constexpr (LN) {                          // ca | cc of the wave's 64 columns -> colv[0..63] | colv[64..127]
+        if constexpr (!IDENT && !CV) col_load(std::integral_constant<int, 0>{});
+        if constexpr (CV) {                          // ca | cc of the wave's 64 columns -> colv[0..63] | colv[64..127]
             if (lane < 32) {
                 const int c = (lane & 15) * 4;
                 const f32x4 sc = pp_col4(e.scale, wn0 + c);
@@ -231,7 +240,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
             }
         }
         if constexpr (RES) static_for<PP_RING>([&](auto pc) { res_load(pc); });
-        if constexpr (!IDENT && !LN) {
+        if constexpr (!IDENT && !CV) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { PP_PIN4(ca[0][q]); PP_PIN4(cc[0][q]); }
         }
@@ -251,7 +260,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
             static_for<4>([&](auto qc) {
                 constexpr int q4 = decltype(qc)::value;
                 f32x4 v = PP_QUAD(i, j, q4);
-                if constexpr (LN) v = v * *(const f32x4*)(colv + j * 32 + 8 * q4 + 4 * kg) + *(const f32x4*)(colv + 64 + j * 32 + 8 * q4 + 4 * kg);
+                if constexpr (CV) v = v * *(const f32x4*)(colv + j * 32 + 8 * q4 + 4 * kg) + *(const f32x4*)(colv + 64 + j * 32 + 8 * q4 + 4 * kg);
                 else if constexpr (!IDENT) v = v * ca[j][q4] + cc[j][q4];
                 stg[fl * 8 + ((2 * q4 + kg) ^ (fl & 7))] = __builtin_bit_cast(u32x4, v);
             });
@@ -288,7 +297,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
             }
             asm volatile("" ::: "memory");                        // (keeps the ring PP_RING passes deep: no hoisting of later loads)
             if constexpr (RES && p + PP_RING < 8) res_load(std::integral_constant<int, p + PP_RING>{});
-            if constexpr (p == 1 && !IDENT && !LN) col_load(std::integral_constant<int, 1>{});     // two more passes until the other column half
+            if constexpr (p == 1 && !IDENT && !CV) col_load(std::integral_constant<int, 1>{});     // two more passes until the other column half
         });
         if constexpr (LN) {
             // the four N-quarter waves of this M half -> one partial per row and tile column.  One block barrier (every wave of the
@@ -375,8 +384,10 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
                 for (int q = 0; q < 2; ++q) { asm volatile("" : "+v"(lst[i][q].x), "+v"(lst[i][q].y)); }
         }
         const unsigned ldc = (unsigned)e.ldc;
-        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, (unsigned)M * ldc * 2u, 0x00020000);
-        const unsigned vo = ((unsigned)(wm0 + rr) * ldc + (unsigned)(wn0 + rc * 8)) * 2u;
+        constexpr unsigned OB = OUT8 ? 1u : 2u;     // bytes per output element
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, (unsigned)M * ldc * OB, 0x00020000);
+        const unsigned vo = ((unsigned)(wm0 + rr) * ldc + (unsigned)(wn0 + rc * 8)) * OB;
+        const float qs = e.out_qscale;
         hook();
         if constexpr (LN && !CBREG) ln_rows();
         static_for<4>([&](auto ic) {
@@ -418,14 +429,26 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmEpi& 
                         if constexpr (LN && CBREG) v = pp_act4<ACT>(v * lrstd[i] + (*(const f32x4*)(colv + j * 32 + 8 * q4 + 4 * kg) * lmean[i] + cb[j][q4]));
                         else if constexpr (LN) v = pp_act4<ACT>((v - *(const f32x4*)(colv + j * 32 + 8 * q4 + 4 * kg) * lmean[i]) * lrstd[i] + *(const f32x4*)(colv + 64 + j * 32 + 8 * q4 + 4 * kg));
                         else v = pp_act4<ACT>(v + cb[j][q4]);
-                        uint2 t;
-                        t.x = pk_bf16(v[0], v[1]); t.y = pk_bf16(v[2], v[3]);
-                        ((uint2*)stg)[(fl * 8 + ((j * 4 + q4) ^ (fl & 7))) * 2 + kg] = t;
+                        if constexpr (OUT8) {
+                            // the same patch geometry at half the element size: row pitch 64 bytes, 8-byte pieces (8 columns), piece index
+                            // XOR (row & 7); a pass still issues four stores (8 rows x 64 bytes each): PP_TAIL holds
+                            v *= qs;
+                            ((uint32_t*)stg)[fl * 16 + 2 * ((j * 4 + q4) ^ (fl & 7)) + kg] = pk_fp8x4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            uint2 t;
+                            t.x = pk_bf16(v[0], v[1]); t.y = pk_bf16(v[2], v[3]);
+                            ((uint2*)stg)[(fl * 8 + ((j * 4 + q4) ^ (fl & 7))) * 2 + kg] = t;
+                        }
                     });
                 });
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = r * 8 + rr;
+                    if constexpr (OUT8) {
+                        typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+                        const uint2 t = ((const uint2*)stg)[row * 8 + (rc ^ (row & 7))];
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2s){t.x, t.y}, rsO, vo + (i * 32 + r * 8) * ldc, 0, 0);
+                    } else
                     __builtin_amdgcn_raw_buffer_store_b128(stg[row * 8 + (rc ^ (row & 7))], rsO, vo + (i * 32 + r * 8) * ldc * 2u, 0, 0);
                 }
             }
@@ -689,6 +712,9 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
         if constexpr (K64) {                                                                                                 \
             _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) mma64(acc[(QM) * 2 + 0][QN], FW.t[s_], FA0.t[s_]);              \
             _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) mma64(acc[(QM) * 2 + 1][QN], FW.t[s_], FA1.t[s_]);              \
+            /* (pinned in place: the results of the LAST two K tiles are only read by the epilogue, and machine sinking moved  \
+                their 32 MFMAs -- operands spilled, ~90 dwords -- below the barriers into the epilogue's block) */              \
+            asm volatile("" : "+v"(acc[(QM) * 2 + 0][QN]), "+v"(acc[(QM) * 2 + 1][QN]));                                       \
         } else {                                                                                                             \
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) mma32(acc[(QM) * 2 + 0][QN], FW.c[ks], FA0.c[ks], T());         \
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) mma32(acc[(QM) * 2 + 1][QN], FW.c[ks], FA1.c[ks], T());         \
@@ -816,7 +842,9 @@ gemm_pp_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, int M
                 else if (e.res1) pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, true>(acc, el, bm0, bn0, Mu, M, grp, wn, lane_e, stg, lnred, colv, hook);
                 else pp_epilogue<PP_EP_F32, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, Mu, M, grp, wn, lane_e, stg, lnred, colv, hook);
             }
-            else if constexpr (KIND == PP_K_GELU) pp_epilogue<PP_EP_BF16, ACT_GELU, DEQ, false>(acc, el, bm0, bn0, M, M, grp, wn, lane_e, stg, lnred, colv, hook);
+            // (e4m3 operands: the GELU kind writes e4m3 only -- FC1 hands e4m3 to FC2, OUT_T; one epilogue per kernel instance: with a
+            //  bf16 variant beside it the two sets of pinned column vectors spill 58 registers)
+            else if constexpr (KIND == PP_K_GELU) pp_epilogue<PP_EP_BF16, ACT_GELU, DEQ, false, false, false, ES == 1>(acc, el, bm0, bn0, M, M, grp, wn, lane_e, stg, lnred, colv, hook);
             else if constexpr (KIND == PP_K_GELU_LN) pp_epilogue<PP_EP_BF16, ACT_GELU, DEQ, false, false, true>(acc, el, bm0, bn0, M, M, grp, wn, lane_e, stg, lnred, colv, hook);
             else if constexpr (KIND == PP_K_QKV) {
                 if (bn0 >= e.qk_cols) pp_epilogue<PP_EP_VT, ACT_NONE, DEQ, false>(acc, el, bm0, bn0, M, M, grp, wn, lane_e, stg, lnred, colv, hook);
@@ -892,7 +920,10 @@ bool pp_supported(int precision, const GemmA& a, int M, int N, int K, int Kpad, 
         if (ln_prod && !(e.stats_out && e.out2 && e.stats_slots && e.out_type == OUT_F32 && e.res1 && e.res1 == e.out && !e.out2_bx3 && e.out2_qscale == 0.f && N <= 1024)) return false;
     }
     if (e.rows_per_img || e.res1_mod || (e.ldc & 7) || e.res2 || N > PP_MAXN) return false;
-    const bool out_bf16 = e.out_type == OUT_BF16 || (e.out_type == OUT_T && precision == D2S_PREC_BF16);
+    bool out_bf16 = e.out_type == OUT_BF16 || (e.out_type == OUT_T && precision == D2S_PREC_BF16);
+    // e4m3 operands: the GELU kind writes e4m3 and nothing else (FC1 -> FC2 of the e4m3 schemes), 8-byte aligned rows
+    static EnvInt no_out8{"D2S_PP_NO_OUT8", 0};                         // (bisecting aid: FC1 of the e4m3 schemes back on the 128 x 128 tiles)
+    if (precision == D2S_PREC_FP8_OPERANDS && e.act == ACT_GELU) out_bf16 = e.out_type == OUT_T && e.map == MAP_ROWS && e.out_qscale > 0.f && !no_out8.get();
     if (e.out_type == OUT_F32) { if (e.act != ACT_NONE || e.map != MAP_ROWS) return false; }
     else if (!(out_bf16 && !e.res1 && !e.res2 && !e.scale && (e.act == ACT_NONE || (e.act == ACT_GELU && e.map == MAP_ROWS)))) return false;
     if (e.map == MAP_QKV && (e.qk_cols & 255)) return false;            // a block tile is entirely q|k or entirely v

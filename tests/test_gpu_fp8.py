@@ -99,3 +99,46 @@ def test_fp8_through_the_call_surface(dev):
         assert np.abs(d2 - ref).mean() <= 0.05
     finally:
         D.configure("tiny", params=PipelineParams(depth_resolution=140), precision="fp32", max_batch=4)
+
+
+def test_fp8_batched_tiles_agree_with_small_tiles(dev, golden_dir, monkeypatch):
+    """The batched e4m3 regime -- 256 x 256 ping-pong tiles on v_mfma_scale_f32_32x32x64_f8f6f4, FC1 writing e4m3 from the ping-pong
+    epilogue, the proj / FC2 column vectors through LDS (round 5) -- against the SAME engine on the SAME 12 frames with the ping-pong
+    kernel switched off (D2S_GEMM_PP=0: 128 x 128 tiles on v_mfma_f32_16x16x32_fp8_fp8): same static scales, same quantisation points,
+    only the fp32 summation order differs.  Both schemes; 12 frames of ViT-B = 9 336 rows = 111 / 333 / 444 tiles per launch.
+    What "agree" can mean here was measured first: this random-weight network turns ANY rounding-level change into a fresh sample of
+    its precision's noise -- perturbing the input by 1e-7 relative moves the e4m3 engine's post-processed depth by 0.0085 mean / 0.06
+    max (bf16 engine: 0.0024 / 0.02), the same for 1e-4.  So the yardstick is taken in the test: the small-tile engine against itself
+    on an input perturbed by 1e-6; the two kernels must not differ by more than that floor (x 1.25 / 1.5), and the batched result must
+    be as close to the reference's fp32 depth as the small-tile one (x 1.15).  A layout or scale error in the new epilogues is not
+    rounding-sized: it fails all three.  (Batch <= 3 is a different scheme -- LayerNorm folded, the raw residual quantised.)"""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS, PipelineParams, engine_shape
+    from desktop2stereo_amd.weights import make_weights
+    z = np.load(os.path.join(golden_dir, "vitb_r518.npz"))
+    fr = json.load(open(os.path.join(golden_dir, "vitb_r518.json")))["frames"][0]
+    cfg = MODELS["vitb"]
+    h, w, _ = engine_shape(fr["h"], fr["w"], 518)
+    B = 12
+    frames = [synth.structured_frame(fr["h"], fr["w"], fr["seed"])] + [synth.structured_frame(fr["h"], fr["w"], 300 + i) for i in range(B - 1)]
+    x = torch.cat([ops.preprocess(torch.from_numpy(f).to(dev), 518) for f in frames])
+    xn = x * (1 + 1e-6 * torch.randn(x.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1)))
+    p = PipelineParams()
+    try:
+        for prec in ("fp8", "fp8_mlp"):
+            eng = ops.Engine(cfg, make_weights(cfg, 0), h, w, B, prec)
+            eng.calibrate(x[:2])
+            monkeypatch.delenv("D2S_GEMM_PP", raising=False); ops.reload_env()
+            big = ops.post_process_depth(eng(x), p).cpu().numpy()
+            monkeypatch.setenv("D2S_GEMM_PP", "0"); ops.reload_env()
+            small = ops.post_process_depth(eng(x), p).cpu().numpy()
+            floor = np.abs(ops.post_process_depth(eng(xn), p).cpu().numpy() - small)
+            d = np.abs(big - small)
+            dev_small, dev_big = np.abs(small[0] - z["f0_post_depth"]), np.abs(big[0] - z["f0_post_depth"])
+            print(f"[vitb {prec}] 256x256 K64 tiles vs small tiles: mean {d.mean():.5f} max {d.max():.4f}; rounding floor (input x (1 + 1e-6 n)): mean {floor.mean():.5f} "
+                  f"max {floor.max():.4f}; vs fp32 reference: small {dev_small.mean():.5f} / {dev_small.max():.4f}, batched {dev_big.mean():.5f} / {dev_big.max():.4f}")
+            assert d.mean() <= 1.25 * floor.mean() and d.max() <= 1.5 * floor.max(), (prec, d.mean(), d.max(), floor.mean(), floor.max())
+            assert dev_big.mean() <= 1.15 * dev_small.mean() + 1e-4, (prec, dev_big.mean(), dev_small.mean())
+            eng.close()
+    finally:
+        monkeypatch.delenv("D2S_GEMM_PP", raising=False); ops.reload_env()

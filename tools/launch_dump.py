@@ -22,6 +22,7 @@ ap.add_argument("--prec", default="bf16")
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--vda", action="store_true")
+ap.add_argument("--mode", default="Full-SBS")
 a = ap.parse_args()
 os.environ["D2S_PROF_DUMP"] = "1"
 cfg = MODELS[a.model]
@@ -31,8 +32,10 @@ if a.vda:
     eng = ops.Engine(cfg, make_vda_weights(cfg, 0), h, w, 1, a.prec, temporal=True)
 else:
     eng = ops.Engine(cfg, make_weights(cfg, 0), h, w, a.batch, a.prec)
-p = PipelineParams(depth_resolution=a.res)
-sp = ops.sbs_params(0.064, 4.0, 0.0, "Full-SBS", False)
+if a.prec.startswith("fp8"):
+    eng.calibrate(ops.preprocess(torch.from_numpy(synth.structured_frame(a.height, a.width, 0)).cuda(), a.res))
+p = PipelineParams(depth_resolution=a.res, display_mode=a.mode)
+sp = ops.sbs_params(0.064, 4.0, 0.0, a.mode, False)
 frames = torch.from_numpy(np.stack([synth.noise_frame(a.height, a.width, i) for i in range(a.batch)])).cuda()
 for _ in range(40 if a.vda else 5):
     eng.pipeline(frames, p, sp)

@@ -40,7 +40,7 @@ for (M, N, K) in [(700, 512, 256), (1000, 768, 768), (3112, 2304, 768), (3112, 7
         if first is None:
             first = got.clone()
             err = (got - want).abs().max().item() / scale
-            ok = err <= 2e-5
+            ok = err <= (2e-5 if a.prec == "bf16" else 5e-5)        # (fp32 accumulation order; e4m3 operands of this spread leave 2-3e-5)
             print(f"M={M:6d} N={N:5d} K={K:5d}  max rel err {err:.2e}  {'ok' if ok else 'WRONG'}", flush=True)
             bad += not ok
         elif not torch.equal(got, first):
