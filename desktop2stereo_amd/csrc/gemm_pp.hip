@@ -981,6 +981,9 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
     //  measured at batch 32: FC2 164 -> 144 us, proj 65 -> 71)
     // Round 4: the K splits of a tail tile share an XCD and are reduced inside the kernel (pp_tail_reduce_inkernel): no second launch,
     // the exchange stays in one L2 -- which makes the split pay for the 12-K-tile proj as well (D2S_PP_INK=0: the two-launch path)
+    // (Round 5, measured and removed: cutting EVERY tile of a launch of less than half a round -- ViT-L at batch 8: 25 x 4 = 100 tiles on
+    //  256 CUs -- into two K ranges reduced in-kernel: e4m3 FC2 51 -> 66 us, config 3 batch 8 1 056 -> 1 005 frames/s; the slab round trip
+    //  costs more than the idle CUs.)
     static EnvInt ink_on{"D2S_PP_INK", 1};
     int ink = 0;
     if (pp_kind_f32(kind) && e.part && split_pct > 0) {
