@@ -45,7 +45,7 @@ template <int PST> __device__ __forceinline__ int c3_chunk_slot(int c) {
 
 // CPP: 16-byte chunks per input pixel (C / 8: 8 | 16);  PST: pixel stride in LDS, in chunks;  BN: output channels per block;
 // WM x WN waves over the 8 x 16 pixel tile (wave_m owns FM = 8 / WM tile rows) and the BN channels;  NS: weight ring stages.
-template <int CPP, int PST, int BN, int WM, int WN, int NS>
+template <int CPP, int PST, int BN, int WM, int WN, int NS, int HG = 3 /* halo chunks a thread keeps in flight per pass of the fill */>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad, GemmEpi e, int xn) {
     KERNARG_WARM(kaw_)                                   // all argument lines in one round trip (common.h)
@@ -94,7 +94,7 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
     {
         const short floor_ = a.relu ? (short)0 : (short)0x8000;      // max as int16: 0 = ReLU, most negative = identity
         typedef short s16x8_ __attribute__((ext_vector_type(8)));
-        conv_halo_fill<bf16_t, 64 * NW, 3>(a, b, ty0, tx0, HWD, HPX, CPP, tid, halo,
+        conv_halo_fill<bf16_t, 64 * NW, HG>(a, b, ty0, tx0, HWD, HPX, CPP, tid, halo,
             [&](int p, int c) { return p * PST + c3_chunk_slot<PST>(c); },
             [&](u32x4 v) {
                 s16x8_ x = __builtin_bit_cast(s16x8_, v);
@@ -122,7 +122,9 @@ conv3_halo2_kernel(GemmA a, const bf16_t* __restrict__ W, int M, int N, int Kpad
         constexpr int kt = decltype(ktc)::value;
         constexpr int tap = kt / KPT, sub = kt % KPT, ky = tap / 3, kx = tap % 3;
         // my W loads of tile kt have landed (and, the first time, my halo stores); then everybody's
-        if constexpr (kt + PD - 1 < NKT) c3_wait_vm<(PD - 1) * BI>(); else c3_wait_vm<0>();
+        // (tiles kt .. min(kt + PD, NKT) - 1 are in flight; vmcnt retires in order: all but tile kt may stay out.  PD >= NKT -- the
+        //  "deep" instantiations of the small maps -- means every weight tile was requested in the prologue)
+        c3_wait_vm<((kt + PD - 1 < NKT) ? PD - 1 : NKT - 1 - kt) * BI>();
         __builtin_amdgcn_s_barrier();
         if constexpr (kt + PD < NKT) C3_ISSUE_W(kt + PD)
         const u32x4* B_l = lds + (kt % NS) * WST;
@@ -1067,6 +1069,25 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
         }
     }
     const long tiles_m = (long)nimg * cdiv(a.Ho, 8) * cdiv(a.Wo, 16);
+    // Mid-size maps (round 5): the fusion stage on the 84 x 148 map of the batch-1 frame (110 tiles x 2 blocks of 64 channels = 220
+    // blocks, every one resident at once) ran as implicit-GEMM tiles + a split-K reduce launch, 19.5 us per convolution of 3.7 GF.  With
+    // one block per CU a block can afford the LDS: ten 8 KB weight stages requested ahead (NS = 10: half of its 18 K tiles in the
+    // prologue) and the halo fill with all of a thread's chunks in flight (HG = 6 instead of 3 per pass: nobody else covers its round
+    // trips here): 19.5 -> 15.5 us, two launches per frame.  The SMALLER maps (11 x 19 ... 42 x 74: 16-120 blocks) were tried the same
+    // way with all 72 KB of a 32-channel block's weights up front (NS = 19, HG = 12): 11.6-12.7 us before, 11.4-14.9 after -- those
+    // launches are not paced by the K loop's round trips (boundary, cold code and the epilogue are what is left); not kept.
+    // D2S_HALO2_DEEP=0: off
+    static EnvInt deep_on{"D2S_HALO2_DEEP", 1};
+    static const int ncu_d = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+    if (deep_on.get() && a.C == 128 && e.map == MAP_ROWS && N % 64 == 0 && (long)gemm_npad(N) * Kpad * 2 < (1L << 31) &&
+        tiles_m * (N / 64) <= ncu_d && tiles_m * (N / 64) * 2 > ncu_d) {
+        if (dry) return true;
+        GemmEpi e1 = e; e1.ksplit = 1;
+        unsigned grid = 0;
+        const int xn = pick_xn((int)tiles_m, N / 64, 64, Kpad, 2, grid);
+        hipLaunchKernelGGL((conv3_halo2_kernel<16, 17, 64, 4, 2, 10, 6>), dim3(grid), dim3(512), 0, st, a, (const bf16_t*)W, M, N, Kpad, e1, xn);
+        return true;
+    }
     const int bn = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
     static EnvInt halo2_min{"D2S_HALO2_MIN", 384};        // (head conv1 at batch 1: 399 tiles, 26.5 -> 21.8 us here; 110-tile maps lose)
     if (tiles_m * cdiv(N, bn) < halo2_min.get()) return false;    // small maps: latency-bound, the small-tile kernels do better
