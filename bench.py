@@ -680,6 +680,33 @@ def rank_body(args, engine_factory=None, device=None):
             pass
 
     default_run = (args.model, args.res, args.precision, args.mode, H, W, B) == ("vitb", 518, "bf16", "Full-SBS", 1080, 1920, 1) and not args.vda
+    if rank == 0 and world == 1 and not fake and default_run and not args.no_profile:
+        # the viewer's DIBR shader with disocclusion in-painting as a HIP kernel (d2s_dibr_warp), the caller's alternative
+        # to make_sbs.  1080p scene with hard depth edges (the in-painting's work), viewer defaults, both eyes, Full-SBS uint8.
+        # Algorithmic bytes: 6.22 MB rgb + 8.29 MB float32 depth in, 12.44 MB out.
+        img_d, dep_d = synth.dibr_scene(H, W, 11, "boxes")
+        fr_d, de_d = torch.from_numpy(img_d).to(dev)[None], torch.from_numpy(dep_d).to(dev)[None]
+        dp_d = ops.dibr_params(display_mode="Full-SBS")
+        rows_d = {}
+        for Bd in (1, 8):
+            f_b, d_b = fr_d.expand(Bd, -1, -1, -1).contiguous(), de_d.expand(Bd, -1, -1).contiguous()
+            for _ in range(3):
+                ops.dibr_warp(f_b, d_b, dp_d)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                ops.dibr_warp(f_b, d_b, dp_d)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 20
+            nbytes = Bd * (H * W * 3 + H * W * 4 + 2 * H * W * 3)
+            rows_d[f"batch{Bd}"] = {"us_per_launch": us, "us_per_frame": us / Bd,
+                                    "roofline": {"bound": "hbm", "achieved": nbytes / us / 1e3, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                 "frac": nbytes / us / 1e3 / PEAK_HBM_GBS}}
+        result["f1_dibr"] = dict(rows_d, workload="d2s_dibr_warp: 1920x1080 uint8 frame + float32 depth (three near boxes: hard edges) -> both eyes, Full-SBS "
+                                                  "3840x1080 uint8, viewer defaults (search radius 12, blending off); parity: tests/golden/dibr.npz (the reference's "
+                                                  "own shader rendered off-screen)")
     if rank == 0 and world == 1 and not fake and default_run and args.resample == "bilinear" and not args.no_profile:
         # the reference's IS_CUDA pre-process branch (one bicubic + antialias resample of the full frame, depth.py:698-699) is
         # what its own GPU path runs; the headline uses the CPU branch (north_star: parity with the reference CPU path)
