@@ -999,6 +999,10 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
             // short K loops (proj: 12 K tiles): a K split costs more in slab traffic than the round it removes (section 3.1f); cut the
             // tail tiles by ROWS instead -- every unit repeats the (short) K loop on a window that starts at its slice and runs 1 / rs of
             // the bandwidth-bound residual epilogue.  No exchange, same MFMA sequence per output: bit-identical.  D2S_PP_RSPLIT=0: off
+            // (Round 5, measured and removed: walking a block's units backwards -- the short row-split unit first, the whole tile second,
+            //  so that the 104 CUs without a tail unit and the 152 with one reach their residual epilogues at different times: proj
+            //  125 -> 131 us, batch 32 3 053 -> 3 038 frames/s on the same box.  The epilogue burst is not shortened by halving the
+            //  CUs in it.)
             static EnvInt rsplit_on{"D2S_PP_RSPLIT", 1};
             if (!ink && nkt < 24 && rsplit_on.get() && rem > 0) {
                 // (measured at batch 32, 38 tail tiles: proj 82.4 us unsplit, 78.4 / 78.1 / 76.6 / 78.8 with 2 / 3 / 4 / 6 slices -- every slice
