@@ -430,6 +430,253 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
 }
 
 // ================================================================================================
+// conv3_c128_ups_kernel (round 5): the head's conv1 (C = 128 -> 64 channels, the fusion stage's x2 align_corners up-sample folded into
+// its loader) at batch.  As a one-shot conv3_halo2 launch (8 x 16-pixel tiles x 64 channels, 12 768 blocks at batch 32) every block
+// streams its 147 KB of weights through LDS for 128 pixels: 2.5 GB of L2 -> LDS traffic per launch, 358 us = 0.26 of the MFMA peak,
+// the largest single convolution of the batched step.  Here, as in conv3_head_kernel: ONE persistent 8-wave block per CU, W in
+// REGISTERS -- wave (mh, nq) owns tile rows 4 mh .. 4 mh + 3 and channels 16 nq .. + 15: 9 taps x 4 K groups x 4 VGPRs = 144 -- so the
+// K loop reads only halo fragments from LDS and has no barrier; an input row's fragment is read once and feeds the (up to three) output
+// rows that tap it (72 fragment reads per 144 MFMAs).  Per accumulator the MFMA order is conv3_halo2's (tap-major, channel groups
+// ascending): bit-identical results (tests/test_gpu_parity.py).
+// The up-sample: the SOURCE window under a tile's halo (<= 7 x 11 pixels for scales <= 0.5) is fetched raw into registers two tiles
+// ahead, parked in LDS one tile ahead, and the 10 x 18 halo is interpolated from there with lerp_chunk's expression -- the function
+// conv_halo_fill applies to its four global taps, on the same four chunks; tap tables per tile instead of linear_tap per chunk.
+// The output tile leaves through LDS as whole 128-byte rows.
+// MEASURED (batch 32, one-shot blocks 334-362 us on the same boxes): 341 us with the source loads one tile ahead, 372 us as it stands
+// (two tiles ahead: 23 spilled registers) -- cut-point builds: K loop + epilogue 176 us, the halo interpolation (all eight waves,
+// lock-step with the K loop) 165 us; before the epilogue went through LDS: 438 us.  Not faster than what it replaces, so it is OFF by default
+// (D2S_HEAD1P_MIN=2048 enables it; the parity test does).  What it needs is conv3_head_ups_kernel's cut: four consumer waves with all
+// of W (144 VGPRs each, 8 rows) and four producer waves interpolating the next halo meanwhile: ~190 us by these numbers.
+// LDS: 2 x 48 960 B of halo (pixel stride 17 chunks, c3_chunk_slot / c3_lane_pixel as in conv3_halo2) + 20 944 B of source window + tap tables.
+// ================================================================================================
+__global__ void __launch_bounds__(512)
+conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEpi e, int ntiles) {
+    KERNARG_WARM(kaw_)
+    KERNARG_WARM_END(kaw_)
+    constexpr int CPP = 16, PST = 17, TH = 8, TW = 16, HWD = TW + 2, HPX = (TH + 2) * HWD, HALO = HPX * PST;
+    constexpr int NCH = HPX * CPP, NLD = (NCH + 511) / 512;       // halo chunks (2 880), chunks per thread (6)
+    constexpr int SRY = 7, SRX = 11, SPX = SRY * SRX, SCH = SPX * CPP, NSL = (SCH + 511) / 512;   // source window, its chunks (1 232), loads per thread (3)
+    constexpr int SPS = CPP + 1;                               // staging stride of a source pixel (odd: neighbouring pixels' taps spread over the banks)
+    static_assert(NLD == 6, "one halo chunk per input-row group of the K loop");
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * HALO + SPX * SPS];
+    // tap tables of the tile whose source window is staged: row taps of its 10 halo rows, column taps of its 18 columns (linear_tap per
+    // CHUNK was a third of the loader's instructions): (i0 - origin) | (i1 - origin) << 8, or -1 outside the image; [0] rows, [1] columns
+    __shared__ int tap_i[2][HWD + TH + 2];
+    __shared__ float tap_w[2][HWD + TH + 2][2];
+    D2S_POISON_LDS(lds, 2 * HALO + SPX * SPS)
+    u32x4* const stg = lds + 2 * HALO;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = wid & 3, mh = wid >> 2;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int px = c3_lane_pixel<PST>(fr);                     // tile column of this lane's pixel
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+
+    // ---- W fragments, once: MFMA row 16 nq + fr, K step (tap, g) -> chunk 4 g + fg of the tap's 128 channels
+    u32x4 wf[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nq * 16 + fr;
+            wf[tap][g] = n < N ? *(const u32x4*)(W + (long)n * Kpad + tap * 128 + (g * 4 + fg) * 8) : (u32x4){0u, 0u, 0u, 0u};
+        }
+    const int n0 = nq * 16 + fg * 4;
+    EpiCols cols;
+    if (n0 < N) epi_cols_load(e, n0, cols);
+
+    typedef short s16x8_ __attribute__((ext_vector_type(8)));
+    const short floor_ = a.relu ? (short)0 : (short)0x8000;
+    auto tile_org = [&](int t, int& b, int& ty0, int& tx0) {
+        b = t / (tiles_y * tiles_x);
+        const int r = t - b * (tiles_y * tiles_x);
+        ty0 = (r / tiles_x) * TH; tx0 = (r % tiles_x) * TW;
+    };
+    auto src_org = [&](int ty0, int tx0, int& rs0, int& cs0) {
+        rs0 = linear_tap(ty0 > 0 ? ty0 - 1 : 0, a.usy, a.Hs, true).i0;
+        cs0 = linear_tap(tx0 > 0 ? tx0 - 1 : 0, a.usx, a.Ws, true).i0;
+    };
+    u32x4 hr[NSL];
+    auto load_src = [&](int t) {                               // raw source window of tile t -> registers
+        int b, ty0, tx0, rs0, cs0;
+        tile_org(t, b, ty0, tx0);
+        src_org(ty0, tx0, rs0, cs0);
+        const bf16_t* img = (const bf16_t*)a.ptr + (long)b * a.Hs * a.Ws * a.C;
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int idx = tid + k * 512;
+            const int p = idx >> 4, c = idx & 15;
+            const int sr = p / SRX, sc = p - sr * SRX;
+            const int row = rs0 + sr < a.Hs ? rs0 + sr : a.Hs - 1, col = cs0 + sc < a.Ws ? cs0 + sc : a.Ws - 1;
+            hr[k] = (u32x4){0u, 0u, 0u, 0u};
+            if (idx < SCH) hr[k] = *(const u32x4*)(img + ((long)row * a.Ws + col) * a.C + c * 8);
+        }
+    };
+    auto stage = [&](int t) {                                  // registers -> staging area + the tile's tap tables (no barrier here)
+        int b, ty0, tx0, rs0, cs0;
+        tile_org(t, b, ty0, tx0);
+        src_org(ty0, tx0, rs0, cs0);
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int idx = tid + k * 512;
+            if (idx < SCH) stg[(idx >> 4) * SPS + (idx & 15)] = hr[k];
+        }
+        if (tid < TH + 2 + HWD) {
+            const bool rowtab = tid < TH + 2;
+            const int j = rowtab ? tid : tid - (TH + 2);
+            const int i = (rowtab ? ty0 : tx0) + j - 1, lim = rowtab ? a.Hi : a.Wi;
+            int v = -1;
+            float w0 = 0.f, w1 = 0.f;
+            if (i >= 0 && i < lim) {
+                const Tap tp = linear_tap(i, rowtab ? a.usy : a.usx, rowtab ? a.Hs : a.Ws, true);
+                v = (tp.i0 - (rowtab ? rs0 : cs0)) | ((tp.i1 - (rowtab ? rs0 : cs0)) << 8);
+                w0 = tp.w0; w1 = tp.w1;
+            }
+            tap_i[rowtab ? 0 : 1][j] = v; tap_w[rowtab ? 0 : 1][j][0] = w0; tap_w[rowtab ? 0 : 1][j][1] = w1;
+        }
+    };
+    // One halo chunk of the staged tile in three steps: lerp_begin (taps + weights into registers), lerp_q (one dword = two channels,
+    // lerp_chunk's own expression), lerp_end (ReLU-on-load, store).  (Spread over the K loop -- chunk ir between the MFMAs of input-row
+    // group ir -- the kernel was SLOWER, 422 us: 32 spilled registers at the 256-register budget and LDS waits in the MFMA stream.)
+    u32x4 l00, l01, l10, l11, lr;
+    float lwx0 = 0.f, lwx1 = 0.f, lwy0 = 0.f, lwy1 = 0.f;
+    int ldst = -1;
+    bool lval = false;
+    auto lerp_begin = [&](int k) {
+        const int idx = tid + k * 512;
+        ldst = -1; lval = false;
+        lr = (u32x4){0u, 0u, 0u, 0u};
+        if (idx < NCH) {
+            const int p = idx >> 4, c = idx & 15;
+            const int hy = p / HWD, hx = p - hy * HWD;
+            const int vy = tap_i[0][hy], vx = tap_i[1][hx];
+            ldst = p * PST + c3_chunk_slot<PST>(c);
+            if ((vy | vx) >= 0) {
+                lval = true;
+                lwy0 = tap_w[0][hy][0]; lwy1 = tap_w[0][hy][1]; lwx0 = tap_w[1][hx][0]; lwx1 = tap_w[1][hx][1];
+                const int r0 = (vy & 255) * SRX, r1 = (vy >> 8) * SRX, c0 = vx & 255, c1 = vx >> 8;
+                l00 = stg[(r0 + c0) * SPS + c]; l01 = stg[(r0 + c1) * SPS + c]; l10 = stg[(r1 + c0) * SPS + c]; l11 = stg[(r1 + c1) * SPS + c];
+            }
+        }
+    };
+    auto lerp_q = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if (lval) lr[q] = lerp_pair_bf16(l00[q], l01[q], l10[q], l11[q], lwx0, lwx1, lwy0, lwy1);
+    };
+    auto lerp_end = [&](int buf) {
+        if (ldst >= 0) {
+            s16x8_ x = __builtin_bit_cast(s16x8_, lr);
+            x = __builtin_elementwise_max(x, (s16x8_){floor_, floor_, floor_, floor_, floor_, floor_, floor_, floor_});
+            lds[buf * HALO + ldst] = __builtin_bit_cast(u32x4, x);
+        }
+    };
+
+    // tile walk: XCD x owns a contiguous run of tiles, its CUs take consecutive tiles of it (conv3_head_kernel)
+    const bool xcd_walk = (gridDim.x & 7) == 0;
+    const int xcd_ = blockIdx.x & 7, slot_ = blockIdx.x >> 3, nslot_ = gridDim.x >> 3, per_ = (ntiles + 7) >> 3;
+    auto tile_at = [&](int k) {
+        if (!xcd_walk) { const int tt = blockIdx.x + k * gridDim.x; return tt < ntiles ? tt : -1; }
+        const int j = slot_ + k * nslot_, tt = xcd_ * per_ + j;
+        return (j < per_ && tt < ntiles) ? tt : -1;
+    };
+    int kk = 0;
+    int t = tile_at(0);
+    if (t < 0) return;
+    // prologue: the first tile's halo in one go, then the second tile's source window staged
+    load_src(t);
+    stage(t);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        lerp_begin(k);
+        static_for<4>([&](auto qc) { lerp_q(qc); });
+        lerp_end(0);
+    }
+    int t1 = tile_at(1);
+    if (t1 >= 0) load_src(t1);
+    __syncthreads();                                           // the first halo is complete; nobody reads the staging area any more
+    if (t1 >= 0) stage(t1);
+    __syncthreads();
+    // A fragment of input row ir (of this wave's six), tap column kx, K group g: pixel (4 mh + ir, px + kx), chunk 4 g + fg = hb + constant
+    const int hb0 = ((mh * 4) * HWD + px) * PST + c3_chunk_slot<PST>(fg);
+    int buf = 0;
+    for (; t >= 0;) {
+        const int t2 = tile_at(kk + 2);
+        ++kk;
+        if (t2 >= 0) load_src(t2);                             // in flight under the K loop
+        const bool build = t1 >= 0;                            // block-uniform
+        const u32x4* hp = lds + buf * HALO + hb0;
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // 72 fragment reads (input row ir, tap column kx, K group g), DEPTH ahead of the MFMAs that use them (left to the compiler every
+        // ds_read_b128 was followed by s_waitcnt lgkmcnt(0))
+        constexpr int DEPTH = 4;
+        u32x4 fq[DEPTH];
+        auto frag = [&](auto ic) {
+            constexpr int idx = decltype(ic)::value, ir = idx / 12, kx = (idx / 4) % 3, g = idx % 4;
+            return hp[(ir * HWD + kx) * PST + g * 4];
+        };
+        static_for<DEPTH>([&](auto ic) { fq[decltype(ic)::value] = frag(ic); });
+#if defined(C128_CUT) && C128_CUT == 2     // (tuning aid, timing only: no MFMA loop)
+        static_for<0>([&](auto ic) {
+#else
+        static_for<72>([&](auto ic) {
+#endif
+            constexpr int idx = decltype(ic)::value, ir = idx / 12, kx = (idx / 4) % 3, g = idx % 4;
+            const u32x4 fa = fq[idx % DEPTH];
+            if constexpr (idx + DEPTH < 72) fq[idx % DEPTH] = frag(std::integral_constant<int, idx + DEPTH < 72 ? idx + DEPTH : 0>{});
+            // output row i = ir - ky: ky ascends with ir for a fixed i, so each accumulator sees (ky, kx, g) in conv3_halo2's order
+            static_for<3>([&](auto kyc) {
+                constexpr int ky = decltype(kyc)::value, i = ir - ky;
+                if constexpr (i >= 0 && i < 4) mma_chunk(acc[i], wf[ky * 3 + kx][g], fa, bf16_t());
+            });
+        });
+        // ---- epilogue through LDS.  A lane holds 4 channels (8 bytes) of a pixel and the four N-quarter waves hold one pixel's 128-byte
+        // row between them: stored straight from the accumulators that is 32-byte pieces from four waves -- cut-point builds put the
+        // MFMA phase + such stores at 263 us of a 438 us launch (the MFMAs are 94).  The tile's bf16 rows are assembled in the halo buffer
+        // the K loop has just finished with (chunk index XOR pixel: conflict-free 8-byte writes and 16-byte reads) and leave as whole
+        // 128-byte lines.  bias add and rounding as epilogue4's: the same bits.
+        int b, ty0, tx0;
+        tile_org(t, b, ty0, tx0);
+        __syncthreads();                                       // every wave is done with halo[buf] and with the staging area
+        {
+            uint2* patch = (uint2*)(lds + buf * HALO);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pp = (mh * 4 + i) * 16 + px;
+                float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+                if (e.bias) { v[0] += cols.bias[0]; v[1] += cols.bias[1]; v[2] += cols.bias[2]; v[3] += cols.bias[3]; }
+                uint2 w2;
+                w2.x = pk_bf16(v[0], v[1]); w2.y = pk_bf16(v[2], v[3]);
+                patch[(pp * 8 + ((nq * 2 + (fg >> 1)) ^ (pp & 7))) * 2 + (fg & 1)] = w2;
+            }
+        }
+        if (build) {                                           // the next tile's halo, from the staged source window (lock-step: see the header)
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                lerp_begin(k);
+                static_for<4>([&](auto qc) { lerp_q(qc); });
+                lerp_end(buf ^ 1);
+            }
+        }
+        __syncthreads();                                       // patch complete, next halo complete, staging area read out
+        if (t2 >= 0) stage(t2);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = tid + k * 512, pp = idx >> 3, c = idx & 7;
+            const int y = ty0 + (pp >> 4), x = tx0 + (pp & 15);
+            if (y < a.Ho && x < a.Wo)
+                *(u32x4*)((bf16_t*)e.out + ((long)(b * a.Ho + y) * a.Wo + x) * e.ldc + c * 8) = lds[buf * HALO + pp * 8 + (c ^ (pp & 7))];
+        }
+        __syncthreads();                                       // the patch is read out: halo[buf] is the next iteration's build target
+        buf ^= 1;
+        t = t1; t1 = t2;
+    }
+}
+
+// ================================================================================================
 // conv3_head_ups_kernel: the head's conv2 with the up-sample in front of it folded in (what conv3_head_kernel<1> does), re-cut into
 // PRODUCER and CONSUMER waves.
 // What conv3_head_kernel<1> spends (profiles/r3_06, batch 32: 349 us, MFMA busy 0.23, 36 % of the LDS cycles in bank conflicts): its
@@ -1050,6 +1297,19 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
         if (a.ups && !ups_v1.get() && ups_fits) hipLaunchKernelGGL(conv3_head_ups_kernel, dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         else if (a.ups) hipLaunchKernelGGL((conv3_head_kernel<1>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
         else hipLaunchKernelGGL((conv3_head_kernel<0>), dim3(std::min(ncu, ntiles)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e, ntiles);
+        return true;
+    }
+    // the head's conv1 at batch: persistent blocks with W in registers and the up-sample in the loader (conv3_c128_ups_kernel)
+    static EnvInt c128_min{"D2S_HEAD1P_MIN", 0};             // fewest tiles of 8 x 16 pixels (2048 = 6 frames of 168 x 296); 0 = off, the default (see the kernel's header)
+    if (a.ups && a.C == 128 && N == 64 && e.map == MAP_ROWS && !a.relu && a.usy <= 0.5f && a.usx <= 0.5f && a.Hs >= 2 && a.Ws >= 2 &&
+        (e.out_type == OUT_T || e.out_type == OUT_BF16) && !e.scale && !e.res1 && !e.res2 && e.act == ACT_NONE && !e.deq && !e.out2 && !(e.ldc & 7) &&
+        c128_min.get() > 0 && (long)nimg * cdiv(a.Ho, 8) * cdiv(a.Wo, 16) >= c128_min.get() &&
+        (long)nimg * cdiv(a.Ho, 8) * cdiv(a.Wo, 16) < (1L << 30) && (long)nimg * a.Hs * a.Ws * a.C * 2 < (1L << 31)) {
+        if (dry) return true;
+        static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+        const int ntl = (int)((long)nimg * cdiv(a.Ho, 8) * cdiv(a.Wo, 16));
+        GemmEpi e1 = e; e1.ksplit = 1;
+        hipLaunchKernelGGL(conv3_c128_ups_kernel, dim3(std::min(ncu & ~7, ntl)), dim3(512), 0, st, a, (const bf16_t*)W, N, Kpad, e1, ntl);
         return true;
     }
     static EnvInt no_wide{"D2S_NO_WIDE", 0};

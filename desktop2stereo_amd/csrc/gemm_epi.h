@@ -101,19 +101,21 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
 }
 // One 16-byte chunk of an align_corners bilinear sample from its four tap chunks: bilerp1 (common.h) on every element, two at a
 // time as v_pk_fma_f32; 8 bf16 (rounded like the stand-alone up-sample kernel's output) or 4 floats.
-__device__ __forceinline__ u32x4 lerp_chunk(const u32x4& v00, const u32x4& v01, const u32x4& v10, const u32x4& v11, const Tap& tx, const Tap& ty, bf16_t) {
+// (one dword = two bf16 channels of the chunk; kernels that spread a chunk's interpolation over their K loop call this directly)
+__device__ __forceinline__ uint32_t lerp_pair_bf16(uint32_t v00, uint32_t v01, uint32_t v10, uint32_t v11, float w0x_, float w1x_, float w0y_, float w1y_) {
     typedef float f2_ __attribute__((ext_vector_type(2)));
-    const f2_ w0x = {tx.w0, tx.w0}, w1x = {tx.w1, tx.w1}, w0y = {ty.w0, ty.w0}, w1y = {ty.w1, ty.w1};
+    const f2_ w0x = {w0x_, w0x_}, w1x = {w1x_, w1x_}, w0y = {w0y_, w0y_}, w1y = {w1y_, w1y_};
+    const f2_ a00 = {__uint_as_float(v00 << 16), __uint_as_float(v00 & 0xffff0000u)}, a01 = {__uint_as_float(v01 << 16), __uint_as_float(v01 & 0xffff0000u)};
+    const f2_ a10 = {__uint_as_float(v10 << 16), __uint_as_float(v10 & 0xffff0000u)}, a11 = {__uint_as_float(v11 << 16), __uint_as_float(v11 & 0xffff0000u)};
+    const f2_ top = __builtin_elementwise_fma(w1x, a01, w0x * a00);
+    const f2_ bot = __builtin_elementwise_fma(w1x, a11, w0x * a10);
+    const f2_ o = __builtin_elementwise_fma(w1y, bot, w0y * top);
+    return pk_bf16(o[0], o[1]);
+}
+__device__ __forceinline__ u32x4 lerp_chunk(const u32x4& v00, const u32x4& v01, const u32x4& v10, const u32x4& v11, const Tap& tx, const Tap& ty, bf16_t) {
     u32x4 r;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f2_ a00 = {__uint_as_float(v00[q] << 16), __uint_as_float(v00[q] & 0xffff0000u)}, a01 = {__uint_as_float(v01[q] << 16), __uint_as_float(v01[q] & 0xffff0000u)};
-        const f2_ a10 = {__uint_as_float(v10[q] << 16), __uint_as_float(v10[q] & 0xffff0000u)}, a11 = {__uint_as_float(v11[q] << 16), __uint_as_float(v11[q] & 0xffff0000u)};
-        const f2_ top = __builtin_elementwise_fma(w1x, a01, w0x * a00);
-        const f2_ bot = __builtin_elementwise_fma(w1x, a11, w0x * a10);
-        const f2_ o = __builtin_elementwise_fma(w1y, bot, w0y * top);
-        r[q] = pk_bf16(o[0], o[1]);
-    }
+    for (int q = 0; q < 4; ++q) r[q] = lerp_pair_bf16(v00[q], v01[q], v10[q], v11[q], tx.w0, tx.w1, ty.w0, ty.w1);
     return r;
 }
 __device__ __forceinline__ u32x4 lerp_chunk(const u32x4& v00, const u32x4& v01, const u32x4& v10, const u32x4& v11, const Tap& tx, const Tap& ty, float) {

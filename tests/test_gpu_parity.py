@@ -669,6 +669,44 @@ def test_head_ups_producer_consumer_kernel_equals_lockstep(dev, monkeypatch, H, 
     assert np.array_equal(outs["default"], outs["standalone"])
 
 
+@pytest.mark.parametrize("H,W,res,B", [(1080, 1920, 518, 7), (720, 1280, 336, 16), (1440, 2560, 518, 6), (1080, 1440, 518, 9)])
+def test_head_conv1_persistent_kernel_equals_one_shot_blocks(dev, monkeypatch, H, W, res, B):
+    """conv3_c128_ups_kernel (round 5: the head's conv1 at batch -- persistent blocks, the 64 x 1152 weights in registers, the fusion
+    stage's x2 up-sample interpolated from a staged source window; off by default: not faster yet, D2S_HEAD1P_MIN=2048 enables it)
+    against the one-shot conv3_halo2 blocks (D2S_HEAD1P_MIN=0) and the
+    stand-alone up-sample (D2S_NO_UPSFOLD=1): lerp_chunk on the same four chunks and conv3_halo2's accumulation order per output, so
+    the depth maps must be bit-identical -- several model-input sizes (ragged edge tiles, other scales), >= 2048 conv1 tiles."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import MODELS, engine_shape
+    from desktop2stereo_amd.weights import make_weights
+    cfg = MODELS["vitb"]
+    wts = make_weights(cfg, 0)
+    h, w, _ = engine_shape(H, W, res)
+    gh, gw = h // 14, w // 14
+    assert B * ((8 * gh + 7) // 8) * ((8 * gw + 15) // 16) >= 2048            # conv1 runs on the (8 gh) x (8 gw) map
+    x = ops.preprocess(torch.stack([_t(synth.structured_frame(H, W, 90 + s), dev) for s in range(B)]), res)
+    keys = ("D2S_HEAD1P_MIN", "D2S_NO_UPSFOLD")
+    outs = {}
+    try:
+        for name, env in (("default", {"D2S_HEAD1P_MIN": "2048"}), ("one_shot", {"D2S_HEAD1P_MIN": "0"}), ("standalone", {"D2S_NO_UPSFOLD": "1"})):
+            for k in keys:
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ops.reload_env()
+            eng = ops.Engine(cfg, wts, h, w, B, "bf16")
+            outs[name] = eng(x).cpu().numpy()
+            assert np.array_equal(outs[name], eng(x).cpu().numpy()), name            # run-to-run identical
+            eng.close()
+    finally:
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        ops.reload_env()
+    assert np.isfinite(outs["default"]).all() and float(np.abs(outs["default"]).max()) > 0
+    assert np.array_equal(outs["default"], outs["one_shot"])
+    assert np.array_equal(outs["default"], outs["standalone"])
+
+
 @pytest.mark.parametrize("B", [32, 13])
 def test_gemm_pp_in_kernel_tail_reduce_equals_two_launches(dev, monkeypatch, B):
     """gemm_pp.hip, D2S_PP_INK: the K-split units of a tail tile exchange their slabs through their XCD's L2 and finish the tile
