@@ -432,59 +432,56 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
 // ================================================================================================
 // conv3_c128_ups_kernel (round 5): the head's conv1 (C = 128 -> 64 channels, the fusion stage's x2 align_corners up-sample folded into
 // its loader) at batch.  As a one-shot conv3_halo2 launch (8 x 16-pixel tiles x 64 channels, 12 768 blocks at batch 32) every block
-// streams its 147 KB of weights through LDS for 128 pixels: 2.5 GB of L2 -> LDS traffic per launch, 358 us = 0.26 of the MFMA peak,
-// the largest single convolution of the batched step.  Here, as in conv3_head_kernel: ONE persistent 8-wave block per CU, W in
-// REGISTERS -- wave (mh, nq) owns tile rows 4 mh .. 4 mh + 3 and channels 16 nq .. + 15: 9 taps x 4 K groups x 4 VGPRs = 144 -- so the
-// K loop reads only halo fragments from LDS and has no barrier; an input row's fragment is read once and feeds the (up to three) output
-// rows that tap it (72 fragment reads per 144 MFMAs).  Per accumulator the MFMA order is conv3_halo2's (tap-major, channel groups
-// ascending): bit-identical results (tests/test_gpu_parity.py).
-// The up-sample: the SOURCE window under a tile's halo (<= 7 x 11 pixels for scales <= 0.5) is fetched raw into registers two tiles
-// ahead, parked in LDS one tile ahead, and the 10 x 18 halo is interpolated from there with lerp_chunk's expression -- the function
-// conv_halo_fill applies to its four global taps, on the same four chunks; tap tables per tile instead of linear_tap per chunk.
-// The output tile leaves through LDS as whole 128-byte rows.
-// MEASURED (batch 32, one-shot blocks 334-362 us on the same boxes): 341 us with the source loads one tile ahead, 372 us as it stands
-// (two tiles ahead: 23 spilled registers) -- cut-point builds: K loop + epilogue 176 us, the halo interpolation (all eight waves,
-// lock-step with the K loop) 165 us; before the epilogue went through LDS: 438 us.  Not faster than what it replaces, so it is OFF by default
-// (D2S_HEAD1P_MIN=2048 enables it; the parity test does).  What it needs is conv3_head_ups_kernel's cut: four consumer waves with all
-// of W (144 VGPRs each, 8 rows) and four producer waves interpolating the next halo meanwhile: ~190 us by these numbers.
-// LDS: 2 x 48 960 B of halo (pixel stride 17 chunks, c3_chunk_slot / c3_lane_pixel as in conv3_halo2) + 20 944 B of source window + tap tables.
+// streams its 147 KB of weights through LDS for 128 pixels: 2.5 GB of L2 -> LDS traffic per launch, 334-378 us = 0.25-0.28 of the MFMA
+// peak, the largest single convolution of the batched step.  Here ONE persistent 8-wave block per CU, cut like conv3_head_ups_kernel:
+//   * waves 0-3, CONSUMERS (one per SIMD): W in REGISTERS -- wave nq owns channels 16 nq .. + 15 of all 8 tile rows: 9 taps x 4 K groups
+//     x 4 VGPRs = 144 -- so the K loop reads only halo fragments from LDS; a halo row's fragment is read once (8 ahead of its MFMAs) and
+//     feeds the up-to-three output rows that tap it (120 reads per 288 MFMAs).  Per accumulator the MFMA order is conv3_halo2's
+//     (tap-major, channel groups ascending), bias add and rounding are epilogue4's: bit-identical results (tests/test_gpu_parity.py).
+//     The finished tile goes to an LDS patch (chunk index XOR pixel) and leaves as whole 128-byte rows during the next tile's first phase
+//     (stored as 32-byte pieces straight from the accumulators of four waves the launch took 438 us).
+//   * waves 4-7, PRODUCERS: the SOURCE window under a tile's halo (<= 7 x 11 pixels for scales <= 0.5) is fetched raw two tiles ahead,
+//     parked in one of two LDS staging buffers with per-tile tap tables (offsets pre-multiplied), and the 10 x 18 halo of the NEXT tile is
+//     interpolated from there into the other halo buffer with lerp_chunk's own expression on the same four chunks while the consumers
+//     compute; a thread's 12 halo chunks are the same in every tile (packed once).
+//   * two block barriers per tile (A: halo / staging / patch complete; B: patch read out, half the next halo in place); the roles run
+//     their own loops (one loop with a role branch kept the 144 weight registers alive through the producers' code: 119 spills).
+// LDS: 2 x 48 960 B halo + 2 x 20 944 B staging + 16 384 B patch + tables = 157 KB.
+// MEASURED (batch 32; one-shot blocks 338-378 us on the same boxes): 330-351 us.  Cut-point builds: consumers alone 185 us, producers
+// alone 218-240 us, together 342: the roles slow each other down instead of overlapping (PMC, gpurun_out/pmc_c128: MFMA busy 0.28, waves
+// waiting 0.45 of their cycles, 4 900 non-MFMA VALU instructions per tile = ~100 per halo chunk as designed, LDS conflicts 3 %).  Earlier
+// cuts of the same idea: all eight waves in lock-step (K loop, then interpolation) 341-372 us; the interpolation spread over the K loop
+// inside each wave 422 us (32 spilled registers).  Not faster than what it replaces, so it is OFF by default (D2S_HEAD1P_MIN=2048
+// enables it; the parity test does).  Open: why the two roles do not overlap -- by instruction count the tile is 2.8 us of issue slots
+// per SIMD (137 us per launch).
 // ================================================================================================
 __global__ void __launch_bounds__(512)
 conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEpi e, int ntiles) {
     KERNARG_WARM(kaw_)
     KERNARG_WARM_END(kaw_)
     constexpr int CPP = 16, PST = 17, TH = 8, TW = 16, HWD = TW + 2, HPX = (TH + 2) * HWD, HALO = HPX * PST;
-    constexpr int NCH = HPX * CPP, NLD = (NCH + 511) / 512;       // halo chunks (2 880), chunks per thread (6)
-    constexpr int SRY = 7, SRX = 11, SPX = SRY * SRX, SCH = SPX * CPP, NSL = (SCH + 511) / 512;   // source window, its chunks (1 232), loads per thread (3)
-    constexpr int SPS = CPP + 1;                               // staging stride of a source pixel (odd: neighbouring pixels' taps spread over the banks)
-    static_assert(NLD == 6, "one halo chunk per input-row group of the K loop");
-    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * HALO + SPX * SPS];
-    // tap tables of the tile whose source window is staged: row taps of its 10 halo rows, column taps of its 18 columns (linear_tap per
-    // CHUNK was a third of the loader's instructions): (i0 - origin) | (i1 - origin) << 8, or -1 outside the image; [0] rows, [1] columns
-    __shared__ int tap_i[2][HWD + TH + 2];
-    __shared__ float tap_w[2][HWD + TH + 2][2];
-    D2S_POISON_LDS(lds, 2 * HALO + SPX * SPS)
-    u32x4* const stg = lds + 2 * HALO;
+    constexpr int NCH = HPX * CPP;                             // halo chunks (2 880)
+    constexpr int SRY = 7, SRX = 11, SPX = SRY * SRX, SCH = SPX * CPP;   // source window (scales <= 0.5), its chunks (1 232)
+    constexpr int SPS = CPP + 1, STG = SPX * SPS;              // staging stride of a source pixel (odd: neighbouring pixels' taps spread over the banks)
+    constexpr int NSLP = (SCH + 255) / 256, NLDP = (NCH + 255) / 256;      // per PRODUCER thread (256 of them): 5 source chunks, 12 halo chunks
+    constexpr int PATCH = TH * TW * 8;                         // output tile as bf16 rows: 128 pixels x 8 chunks
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * HALO + 2 * STG + PATCH];
+    // tap tables of the staged tiles [staging buffer][rows | columns]: the two source offsets of a halo row / column, already in staging
+    // chunks ((i - origin) * SRX * SPS for rows, * SPS for columns), x < 0 outside the image; and the two weights
+    __shared__ int2 tap_i[2][2][HWD + TH + 2];
+    __shared__ float2 tap_w[2][2][HWD + TH + 2];
+    D2S_POISON_LDS(lds, 2 * HALO + 2 * STG + PATCH)
+    u32x4* const stg0 = lds + 2 * HALO;
+    u32x4* const patch = lds + 2 * HALO + 2 * STG;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nq = wid & 3, mh = wid >> 2;
+    const bool consumer = wid < 4;
+    const int nq = wid & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int px = c3_lane_pixel<PST>(fr);                     // tile column of this lane's pixel
     const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
-
-    // ---- W fragments, once: MFMA row 16 nq + fr, K step (tap, g) -> chunk 4 g + fg of the tap's 128 channels
-    u32x4 wf[9][4];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = nq * 16 + fr;
-            wf[tap][g] = n < N ? *(const u32x4*)(W + (long)n * Kpad + tap * 128 + (g * 4 + fg) * 8) : (u32x4){0u, 0u, 0u, 0u};
-        }
-    const int n0 = nq * 16 + fg * 4;
-    EpiCols cols;
-    if (n0 < N) epi_cols_load(e, n0, cols);
+    const int ptid = tid - 256;                                // producer thread number
 
     typedef short s16x8_ __attribute__((ext_vector_type(8)));
     const short floor_ = a.relu ? (short)0 : (short)0x8000;
@@ -497,15 +494,16 @@ conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
         rs0 = linear_tap(ty0 > 0 ? ty0 - 1 : 0, a.usy, a.Hs, true).i0;
         cs0 = linear_tap(tx0 > 0 ? tx0 - 1 : 0, a.usx, a.Ws, true).i0;
     };
-    u32x4 hr[NSL];
+    // ---- the loader (the 256 producer threads)
+    u32x4 hr[NSLP];
     auto load_src = [&](int t) {                               // raw source window of tile t -> registers
         int b, ty0, tx0, rs0, cs0;
         tile_org(t, b, ty0, tx0);
         src_org(ty0, tx0, rs0, cs0);
         const bf16_t* img = (const bf16_t*)a.ptr + (long)b * a.Hs * a.Ws * a.C;
 #pragma unroll
-        for (int k = 0; k < NSL; ++k) {
-            const int idx = tid + k * 512;
+        for (int k = 0; k < NSLP; ++k) {
+            const int idx = ptid + k * 256;
             const int p = idx >> 4, c = idx & 15;
             const int sr = p / SRX, sc = p - sr * SRX;
             const int row = rs0 + sr < a.Hs ? rs0 + sr : a.Hs - 1, col = cs0 + sc < a.Ws ? cs0 + sc : a.Ws - 1;
@@ -513,63 +511,81 @@ conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
             if (idx < SCH) hr[k] = *(const u32x4*)(img + ((long)row * a.Ws + col) * a.C + c * 8);
         }
     };
-    auto stage = [&](int t) {                                  // registers -> staging area + the tile's tap tables (no barrier here)
+    auto stage = [&](int t, int sb) {                          // registers -> staging buffer sb + the tile's tap tables (no barrier here)
         int b, ty0, tx0, rs0, cs0;
         tile_org(t, b, ty0, tx0);
         src_org(ty0, tx0, rs0, cs0);
 #pragma unroll
-        for (int k = 0; k < NSL; ++k) {
-            const int idx = tid + k * 512;
-            if (idx < SCH) stg[(idx >> 4) * SPS + (idx & 15)] = hr[k];
+        for (int k = 0; k < NSLP; ++k) {
+            const int idx = ptid + k * 256;
+            if (idx < SCH) stg0[sb * STG + (idx >> 4) * SPS + (idx & 15)] = hr[k];
         }
-        if (tid < TH + 2 + HWD) {
-            const bool rowtab = tid < TH + 2;
-            const int j = rowtab ? tid : tid - (TH + 2);
+        if (ptid < TH + 2 + HWD) {
+            const bool rowtab = ptid < TH + 2;
+            const int j = rowtab ? ptid : ptid - (TH + 2);
             const int i = (rowtab ? ty0 : tx0) + j - 1, lim = rowtab ? a.Hi : a.Wi;
-            int v = -1;
-            float w0 = 0.f, w1 = 0.f;
+            int2 v = make_int2(-1, -1);
+            float2 w = make_float2(0.f, 0.f);
             if (i >= 0 && i < lim) {
                 const Tap tp = linear_tap(i, rowtab ? a.usy : a.usx, rowtab ? a.Hs : a.Ws, true);
-                v = (tp.i0 - (rowtab ? rs0 : cs0)) | ((tp.i1 - (rowtab ? rs0 : cs0)) << 8);
-                w0 = tp.w0; w1 = tp.w1;
+                const int mul = rowtab ? SRX * SPS : SPS, org = rowtab ? rs0 : cs0;
+                v = make_int2((tp.i0 - org) * mul, (tp.i1 - org) * mul);
+                w = make_float2(tp.w0, tp.w1);
             }
-            tap_i[rowtab ? 0 : 1][j] = v; tap_w[rowtab ? 0 : 1][j][0] = w0; tap_w[rowtab ? 0 : 1][j][1] = w1;
+            tap_i[sb][rowtab ? 0 : 1][j] = v; tap_w[sb][rowtab ? 0 : 1][j] = w;
         }
     };
-    // One halo chunk of the staged tile in three steps: lerp_begin (taps + weights into registers), lerp_q (one dword = two channels,
-    // lerp_chunk's own expression), lerp_end (ReLU-on-load, store).  (Spread over the K loop -- chunk ir between the MFMAs of input-row
-    // group ir -- the kernel was SLOWER, 422 us: 32 spilled registers at the 256-register budget and LDS waits in the MFMA stream.)
-    u32x4 l00, l01, l10, l11, lr;
-    float lwx0 = 0.f, lwx1 = 0.f, lwy0 = 0.f, lwy1 = 0.f;
-    int ldst = -1;
-    bool lval = false;
-    auto lerp_begin = [&](int k) {
-        const int idx = tid + k * 512;
-        ldst = -1; lval = false;
-        lr = (u32x4){0u, 0u, 0u, 0u};
-        if (idx < NCH) {
-            const int p = idx >> 4, c = idx & 15;
-            const int hy = p / HWD, hx = p - hy * HWD;
-            const int vy = tap_i[0][hy], vx = tap_i[1][hx];
-            ldst = p * PST + c3_chunk_slot<PST>(c);
-            if ((vy | vx) >= 0) {
-                lval = true;
-                lwy0 = tap_w[0][hy][0]; lwy1 = tap_w[0][hy][1]; lwx0 = tap_w[1][hx][0]; lwx1 = tap_w[1][hx][1];
-                const int r0 = (vy & 255) * SRX, r1 = (vy >> 8) * SRX, c0 = vx & 255, c1 = vx >> 8;
-                l00 = stg[(r0 + c0) * SPS + c]; l01 = stg[(r0 + c1) * SPS + c]; l10 = stg[(r1 + c0) * SPS + c]; l11 = stg[(r1 + c1) * SPS + c];
+    // this producer thread's halo chunks are the same in every tile: chunk k = ptid + 256 k -> (halo pixel p, channel chunk c); packed
+    // once: LDS destination (12 bits) | halo row (4) | halo column (5) | c (4), or -1 past the halo
+    int pc[NLDP];
+#pragma unroll
+    for (int k = 0; k < NLDP; ++k) {
+        const int idx = ptid + k * 256;
+        const int p = idx >> 4, c = idx & 15, hy = p / HWD, hx = p - hy * HWD;
+        pc[k] = (consumer || idx >= NCH) ? -1 : ((p * PST + c3_chunk_slot<PST>(c)) | (hy << 12) | (hx << 16) | (c << 21));
+    }
+    // halo chunks k0 <= k < k1 of the tile staged in sb -> halo buffer hbuf; two at a time, their eight tap chunks requested before the
+    // first is used.  (Per chunk: two table reads, four adds, four tap reads, lerp_chunk's arithmetic, one store -- with the index
+    // arithmetic and linear_tap per chunk the four producer waves needed 4.3 us per tile against 1.9 us of MFMA work.)
+    auto lerp_chunks = [&](int sb, int hbuf, auto k0c, auto k1c) {
+        const u32x4* stg = stg0 + sb * STG;
+#if defined(C128_CUT) && C128_CUT == 1     // (tuning aid, timing only: no interpolation)
+        if (a.Hs > 0) return;
+#endif
+        static_for<(decltype(k1c)::value - decltype(k0c)::value) / 2>([&](auto jc) {
+            constexpr int k = decltype(k0c)::value + 2 * decltype(jc)::value;
+            bool val[2];
+            u32x4 v[2][4];
+            float2 wx[2], wy[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pk = pc[k + u];
+                val[u] = false;
+                if (pk >= 0) {
+                    const int hy = (pk >> 12) & 15, hx = (pk >> 16) & 31, c = pk >> 21;
+                    const int2 vy = tap_i[sb][0][hy], vx = tap_i[sb][1][hx];
+                    if ((vy.x | vx.x) >= 0) {
+                        val[u] = true;
+                        wy[u] = tap_w[sb][0][hy]; wx[u] = tap_w[sb][1][hx];
+                        v[u][0] = stg[vy.x + vx.x + c]; v[u][1] = stg[vy.x + vx.y + c]; v[u][2] = stg[vy.y + vx.x + c]; v[u][3] = stg[vy.y + vx.y + c];
+                    }
+                }
             }
-        }
-    };
-    auto lerp_q = [&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        if (lval) lr[q] = lerp_pair_bf16(l00[q], l01[q], l10[q], l11[q], lwx0, lwx1, lwy0, lwy1);
-    };
-    auto lerp_end = [&](int buf) {
-        if (ldst >= 0) {
-            s16x8_ x = __builtin_bit_cast(s16x8_, lr);
-            x = __builtin_elementwise_max(x, (s16x8_){floor_, floor_, floor_, floor_, floor_, floor_, floor_, floor_});
-            lds[buf * HALO + ldst] = __builtin_bit_cast(u32x4, x);
-        }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pk = pc[k + u];
+                if (pk >= 0) {
+                    u32x4 r = {0u, 0u, 0u, 0u};
+                    if (val[u]) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) r[q] = lerp_pair_bf16(v[u][0][q], v[u][1][q], v[u][2][q], v[u][3][q], wx[u].x, wx[u].y, wy[u].x, wy[u].y);   // = lerp_chunk
+                    }
+                    s16x8_ x = __builtin_bit_cast(s16x8_, r);
+                    x = __builtin_elementwise_max(x, (s16x8_){floor_, floor_, floor_, floor_, floor_, floor_, floor_, floor_});
+                    lds[hbuf * HALO + (pk & 4095)] = __builtin_bit_cast(u32x4, x);
+                }
+            }
+        });
     };
 
     // tile walk: XCD x owns a contiguous run of tiles, its CUs take consecutive tiles of it (conv3_head_kernel)
@@ -583,97 +599,119 @@ conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
     int kk = 0;
     int t = tile_at(0);
     if (t < 0) return;
-    // prologue: the first tile's halo in one go, then the second tile's source window staged
-    load_src(t);
-    stage(t);
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        lerp_begin(k);
-        static_for<4>([&](auto qc) { lerp_q(qc); });
-        lerp_end(0);
-    }
     int t1 = tile_at(1);
-    if (t1 >= 0) load_src(t1);
-    __syncthreads();                                           // the first halo is complete; nobody reads the staging area any more
-    if (t1 >= 0) stage(t1);
+    constexpr std::integral_constant<int, 0> K0{};
+    constexpr std::integral_constant<int, NLDP / 2> KH{};
+    constexpr std::integral_constant<int, NLDP> KE{};
+    static_assert(NLDP % 4 == 0, "two halves of chunk pairs");
+    // ---- prologue (producers; the consumers load their weights meanwhile): the first tile's halo, the second tile's source window staged in buffer 0
+    if (!consumer) { load_src(t); stage(t, 1); }
     __syncthreads();
-    // A fragment of input row ir (of this wave's six), tap column kx, K group g: pixel (4 mh + ir, px + kx), chunk 4 g + fg = hb + constant
-    const int hb0 = ((mh * 4) * HWD + px) * PST + c3_chunk_slot<PST>(fg);
-    int buf = 0;
+    if (!consumer) {
+        lerp_chunks(1, 0, K0, KE);
+        if (t1 >= 0) { load_src(t1); stage(t1, 0); }
+    }
+
+    // From here on the two roles run their OWN loops (one loop with a role branch keeps the consumers' 144 weight registers alive
+    // through the producers' code: 119 spilled registers); both pass the same two block barriers per tile, A and B:
+    //   A: halo[buf] = tile t, staging sb = the source of tile t1, patch = the rows of the previous tile -- all complete
+    //   B: the patch is read out (consumers), the first half of tile t1's halo is in place (producers)
+    int buf = 0, sb = 0;
+    if (!consumer) {
+        for (; t >= 0;) {
+            const int t2 = tile_at(kk + 2);
+            ++kk;
+            __syncthreads();                                   // A
+            if (t2 >= 0) load_src(t2);                         // the source window of tile t2 is requested,
+            if (t1 >= 0) lerp_chunks(sb, buf ^ 1, K0, KH);     // the first half of tile t1's halo interpolated
+            __syncthreads();                                   // B
+            if (t1 >= 0) lerp_chunks(sb, buf ^ 1, KH, KE);     // the second half;
+            if (t2 >= 0) stage(t2, sb ^ 1);                    // tile t2's source window into the other staging buffer
+            buf ^= 1; sb ^= 1;
+            t = t1; t1 = t2;
+        }
+        __syncthreads();
+        return;
+    }
+    // ---- consumers: W fragments (MFMA row 16 nq + fr; K step (tap, g) -> chunk 4 g + fg of the tap's 128 channels), bias
+    u32x4 wf[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nq * 16 + fr;
+            wf[tap][g] = n < N ? *(const u32x4*)(W + (long)n * Kpad + tap * 128 + (g * 4 + fg) * 8) : (u32x4){0u, 0u, 0u, 0u};
+        }
+    EpiCols cols;
+    const int n0 = nq * 16 + fg * 4;
+    if (n0 < N) epi_cols_load(e, n0, cols);
+    // A fragment of halo row ir, tap column kx, K group g: pixel (ir, px + kx), chunk 4 g + fg = hb + constant
+    const int hb0 = px * PST + c3_chunk_slot<PST>(fg);
+    auto store_rows = [&](int tp) {                            // the patch -> global memory, whole 128-byte lines
+        int b, ty0, tx0;
+        tile_org(tp, b, ty0, tx0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + k * 256, pp = idx >> 3, c = idx & 7;
+            const int y = ty0 + (pp >> 4), x = tx0 + (pp & 15);
+            if (y < a.Ho && x < a.Wo)
+                *(u32x4*)((bf16_t*)e.out + ((long)(b * a.Ho + y) * a.Wo + x) * e.ldc + c * 8) = patch[pp * 8 + (c ^ (pp & 7))];
+        }
+    };
+    int tprev = -1;                                            // the tile whose output rows sit in the patch
+    constexpr int DEPTH = 8, NFR = 10 * 12;                    // fragments in flight (4: the K loop ran at the LDS latency, 3.5 us per tile alone); fragments per tile (halo row, kx, g)
     for (; t >= 0;) {
         const int t2 = tile_at(kk + 2);
         ++kk;
-        if (t2 >= 0) load_src(t2);                             // in flight under the K loop
-        const bool build = t1 >= 0;                            // block-uniform
+        __syncthreads();                                       // A
         const u32x4* hp = lds + buf * HALO + hb0;
-        f32x4 acc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // 72 fragment reads (input row ir, tap column kx, K group g), DEPTH ahead of the MFMAs that use them (left to the compiler every
-        // ds_read_b128 was followed by s_waitcnt lgkmcnt(0))
-        constexpr int DEPTH = 4;
+        f32x4 acc[8];
         u32x4 fq[DEPTH];
         auto frag = [&](auto ic) {
             constexpr int idx = decltype(ic)::value, ir = idx / 12, kx = (idx / 4) % 3, g = idx % 4;
             return hp[(ir * HWD + kx) * PST + g * 4];
         };
-        static_for<DEPTH>([&](auto ic) { fq[decltype(ic)::value] = frag(ic); });
-#if defined(C128_CUT) && C128_CUT == 2     // (tuning aid, timing only: no MFMA loop)
-        static_for<0>([&](auto ic) {
+        auto kloop = [&](auto lo, auto hi) {                   // fragments [lo, hi): each read DEPTH ahead of its MFMAs
+#if defined(C128_CUT) && C128_CUT == 2     // (timing only: no K loop)
+            static_for<0>([&](auto jc) {
 #else
-        static_for<72>([&](auto ic) {
+            static_for<decltype(hi)::value - decltype(lo)::value>([&](auto jc) {
 #endif
-            constexpr int idx = decltype(ic)::value, ir = idx / 12, kx = (idx / 4) % 3, g = idx % 4;
-            const u32x4 fa = fq[idx % DEPTH];
-            if constexpr (idx + DEPTH < 72) fq[idx % DEPTH] = frag(std::integral_constant<int, idx + DEPTH < 72 ? idx + DEPTH : 0>{});
-            // output row i = ir - ky: ky ascends with ir for a fixed i, so each accumulator sees (ky, kx, g) in conv3_halo2's order
-            static_for<3>([&](auto kyc) {
-                constexpr int ky = decltype(kyc)::value, i = ir - ky;
-                if constexpr (i >= 0 && i < 4) mma_chunk(acc[i], wf[ky * 3 + kx][g], fa, bf16_t());
+                constexpr int idx = decltype(lo)::value + decltype(jc)::value, ir = idx / 12, kx = (idx / 4) % 3, g = idx % 4;
+                const u32x4 fa = fq[idx % DEPTH];
+                if constexpr (idx + DEPTH < NFR) fq[idx % DEPTH] = frag(std::integral_constant<int, idx + DEPTH < NFR ? idx + DEPTH : 0>{});
+                // output row i = ir - ky: ky ascends with ir for a fixed i, so each accumulator sees (ky, kx, g) in conv3_halo2's order
+                static_for<3>([&](auto kyc) {
+                    constexpr int ky = decltype(kyc)::value, i = ir - ky;
+                    if constexpr (i >= 0 && i < 8) mma_chunk(acc[i], wf[ky * 3 + kx][g], fa, bf16_t());
+                });
             });
-        });
-        // ---- epilogue through LDS.  A lane holds 4 channels (8 bytes) of a pixel and the four N-quarter waves hold one pixel's 128-byte
-        // row between them: stored straight from the accumulators that is 32-byte pieces from four waves -- cut-point builds put the
-        // MFMA phase + such stores at 263 us of a 438 us launch (the MFMAs are 94).  The tile's bf16 rows are assembled in the halo buffer
-        // the K loop has just finished with (chunk index XOR pixel: conflict-free 8-byte writes and 16-byte reads) and leave as whole
-        // 128-byte lines.  bias add and rounding as epilogue4's: the same bits.
-        int b, ty0, tx0;
-        tile_org(t, b, ty0, tx0);
-        __syncthreads();                                       // every wave is done with halo[buf] and with the staging area
-        {
-            uint2* patch = (uint2*)(lds + buf * HALO);
+        };
+        // phase 1: the previous tile's rows leave the patch; halo rows 0-4
+        static_for<DEPTH>([&](auto ic) { fq[decltype(ic)::value] = frag(ic); });
+        if (tprev >= 0) store_rows(tprev);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int pp = (mh * 4 + i) * 16 + px;
-                float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-                if (e.bias) { v[0] += cols.bias[0]; v[1] += cols.bias[1]; v[2] += cols.bias[2]; v[3] += cols.bias[3]; }
-                uint2 w2;
-                w2.x = pk_bf16(v[0], v[1]); w2.y = pk_bf16(v[2], v[3]);
-                patch[(pp * 8 + ((nq * 2 + (fg >> 1)) ^ (pp & 7))) * 2 + (fg & 1)] = w2;
-            }
-        }
-        if (build) {                                           // the next tile's halo, from the staged source window (lock-step: see the header)
+        for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        kloop(std::integral_constant<int, 0>{}, std::integral_constant<int, NFR / 2>{});
+        __syncthreads();                                       // B
+        // phase 2: halo rows 5-9, then this tile's rows into the patch (bias add and rounding as epilogue4's: the same bits)
+        kloop(std::integral_constant<int, NFR / 2>{}, std::integral_constant<int, NFR>{});
+        uint2* pw = (uint2*)patch;
 #pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                lerp_begin(k);
-                static_for<4>([&](auto qc) { lerp_q(qc); });
-                lerp_end(buf ^ 1);
-            }
+        for (int i = 0; i < 8; ++i) {
+            const int pp = i * 16 + px;
+            float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+            if (e.bias) { v[0] += cols.bias[0]; v[1] += cols.bias[1]; v[2] += cols.bias[2]; v[3] += cols.bias[3]; }
+            uint2 w2;
+            w2.x = pk_bf16(v[0], v[1]); w2.y = pk_bf16(v[2], v[3]);
+            pw[(pp * 8 + ((nq * 2 + (fg >> 1)) ^ (pp & 7))) * 2 + (fg & 1)] = w2;
         }
-        __syncthreads();                                       // patch complete, next halo complete, staging area read out
-        if (t2 >= 0) stage(t2);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int idx = tid + k * 512, pp = idx >> 3, c = idx & 7;
-            const int y = ty0 + (pp >> 4), x = tx0 + (pp & 15);
-            if (y < a.Ho && x < a.Wo)
-                *(u32x4*)((bf16_t*)e.out + ((long)(b * a.Ho + y) * a.Wo + x) * e.ldc + c * 8) = lds[buf * HALO + pp * 8 + (c ^ (pp & 7))];
-        }
-        __syncthreads();                                       // the patch is read out: halo[buf] is the next iteration's build target
+        tprev = t;
         buf ^= 1;
         t = t1; t1 = t2;
     }
+    __syncthreads();                                           // the last tile's rows
+    if (tprev >= 0) store_rows(tprev);
 }
 
 // ================================================================================================
