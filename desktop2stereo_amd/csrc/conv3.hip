@@ -447,13 +447,13 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
 //   * two block barriers per tile (A: halo / staging / patch complete; B: patch read out, half the next halo in place); the roles run
 //     their own loops (one loop with a role branch kept the 144 weight registers alive through the producers' code: 119 spills).
 // LDS: 2 x 48 960 B halo + 2 x 20 944 B staging + 16 384 B patch + tables = 157 KB.
-// MEASURED (batch 32; one-shot blocks 338-378 us on the same boxes): 330-351 us.  Cut-point builds: consumers alone 185 us, producers
-// alone 218-240 us, together 342: the roles slow each other down instead of overlapping (PMC, gpurun_out/pmc_c128: MFMA busy 0.28, waves
-// waiting 0.45 of their cycles, 4 900 non-MFMA VALU instructions per tile = ~100 per halo chunk as designed, LDS conflicts 3 %).  Earlier
-// cuts of the same idea: all eight waves in lock-step (K loop, then interpolation) 341-372 us; the interpolation spread over the K loop
-// inside each wave 422 us (32 spilled registers).  Not faster than what it replaces, so it is OFF by default (D2S_HEAD1P_MIN=2048
-// enables it; the parity test does).  Open: why the two roles do not overlap -- by instruction count the tile is 2.8 us of issue slots
-// per SIMD (137 us per launch).
+// MEASURED (batch 32; one-shot blocks 338-378 us on the same boxes): **296-315 us** (one-shot 345-360 on those boxes).  How it got there --
+// every cut bit-identical: all eight waves in lock-step (K loop, then interpolation) 341-372 us; the interpolation spread over the K loop
+// inside each wave 422 us (32 spilled registers); producer / consumer waves with one chunk pair interpolated at a time 330-351 us
+// (cut-point builds: consumers alone 185 us, producers alone 218-240 us, together 342: ONE wave per SIMD and role has nobody to cover its
+// LDS round trips, and together the round trips get longer; PMC, profiles/r5_08: MFMA busy 0.28, waves waiting 0.45 of their cycles);
+// all table reads and all 24 tap reads of a six-chunk half-tile in flight together: 296-315 us (producers alone 205).  By instruction
+// count a tile is 2.8 us of issue slots per SIMD (137 us per launch): what is left is latency in both roles' single waves.
 // ================================================================================================
 __global__ void __launch_bounds__(512)
 conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEpi e, int ntiles) {
@@ -552,31 +552,32 @@ conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
 #if defined(C128_CUT) && C128_CUT == 1     // (tuning aid, timing only: no interpolation)
         if (a.Hs > 0) return;
 #endif
-        static_for<(decltype(k1c)::value - decltype(k0c)::value) / 2>([&](auto jc) {
-            constexpr int k = decltype(k0c)::value + 2 * decltype(jc)::value;
-            bool val[2];
-            u32x4 v[2][4];
-            float2 wx[2], wy[2];
+        constexpr int k0 = decltype(k0c)::value, NB = 6;       // chunks per batch: all their table reads, then all 24 tap reads, are in flight together
+        static_for<(decltype(k1c)::value - k0) / NB>([&](auto jc) {
+            constexpr int k = k0 + NB * decltype(jc)::value;
+            int2 vy[NB], vx[NB];
+            float2 wx[NB], wy[NB];
+            u32x4 v[NB][4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int pk = pc[k + u];
-                val[u] = false;
-                if (pk >= 0) {
-                    const int hy = (pk >> 12) & 15, hx = (pk >> 16) & 31, c = pk >> 21;
-                    const int2 vy = tap_i[sb][0][hy], vx = tap_i[sb][1][hx];
-                    if ((vy.x | vx.x) >= 0) {
-                        val[u] = true;
-                        wy[u] = tap_w[sb][0][hy]; wx[u] = tap_w[sb][1][hx];
-                        v[u][0] = stg[vy.x + vx.x + c]; v[u][1] = stg[vy.x + vx.y + c]; v[u][2] = stg[vy.y + vx.x + c]; v[u][3] = stg[vy.y + vx.y + c];
-                    }
-                }
+            for (int u = 0; u < NB; ++u) {
+                const int pk = pc[k + u] < 0 ? 0 : pc[k + u];  // (chunk 0's entries for the threads past the halo: loads are unconditional)
+                const int hy = (pk >> 12) & 15, hx = (pk >> 16) & 31;
+                vy[u] = tap_i[sb][0][hy]; vx[u] = tap_i[sb][1][hx];
+                wy[u] = tap_w[sb][0][hy]; wx[u] = tap_w[sb][1][hx];
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NB; ++u) {
+                const int c = (pc[k + u] < 0 ? 0 : pc[k + u]) >> 21;
+                const bool ok = (vy[u].x | vx[u].x) >= 0;
+                const int y0 = ok ? vy[u].x : 0, y1 = ok ? vy[u].y : 0, x0 = ok ? vx[u].x : 0, x1 = ok ? vx[u].y : 0;
+                v[u][0] = stg[y0 + x0 + c]; v[u][1] = stg[y0 + x1 + c]; v[u][2] = stg[y1 + x0 + c]; v[u][3] = stg[y1 + x1 + c];
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
                 const int pk = pc[k + u];
                 if (pk >= 0) {
                     u32x4 r = {0u, 0u, 0u, 0u};
-                    if (val[u]) {
+                    if ((vy[u].x | vx[u].x) >= 0) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) r[q] = lerp_pair_bf16(v[u][0][q], v[u][1][q], v[u][2][q], v[u][3][q], wx[u].x, wx[u].y, wy[u].x, wy[u].y);   // = lerp_chunk
                     }
@@ -603,7 +604,7 @@ conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
     constexpr std::integral_constant<int, 0> K0{};
     constexpr std::integral_constant<int, NLDP / 2> KH{};
     constexpr std::integral_constant<int, NLDP> KE{};
-    static_assert(NLDP % 4 == 0, "two halves of chunk pairs");
+    static_assert(NLDP == 12, "two halves of six chunks");
     // ---- prologue (producers; the consumers load their weights meanwhile): the first tile's halo, the second tile's source window staged in buffer 0
     if (!consumer) { load_src(t); stage(t, 1); }
     __syncthreads();
@@ -634,6 +635,7 @@ conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
         return;
     }
     // ---- consumers: W fragments (MFMA row 16 nq + fr; K step (tap, g) -> chunk 4 g + fg of the tap's 128 channels), bias
+    // (s_setprio 2 for these waves -- the MFMA stream first when both waves of a SIMD can issue: 308 vs 306 us, no effect)
     u32x4 wf[9][4];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -1338,7 +1340,7 @@ bool launch_conv3_halo2(const GemmA& a, const void* W, int M, int N, int K, int 
         return true;
     }
     // the head's conv1 at batch: persistent blocks with W in registers and the up-sample in the loader (conv3_c128_ups_kernel)
-    static EnvInt c128_min{"D2S_HEAD1P_MIN", 0};             // fewest tiles of 8 x 16 pixels (2048 = 6 frames of 168 x 296); 0 = off, the default (see the kernel's header)
+    static EnvInt c128_min{"D2S_HEAD1P_MIN", 2048};          // fewest tiles of 8 x 16 pixels (2048 = 6 frames of 168 x 296); 0 = off
     if (a.ups && a.C == 128 && N == 64 && e.map == MAP_ROWS && !a.relu && a.usy <= 0.5f && a.usx <= 0.5f && a.Hs >= 2 && a.Ws >= 2 &&
         (e.out_type == OUT_T || e.out_type == OUT_BF16) && !e.scale && !e.res1 && !e.res2 && e.act == ACT_NONE && !e.deq && !e.out2 && !(e.ldc & 7) &&
         c128_min.get() > 0 && (long)nimg * cdiv(a.Ho, 8) * cdiv(a.Wo, 16) >= c128_min.get() &&

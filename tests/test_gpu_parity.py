@@ -672,8 +672,8 @@ def test_head_ups_producer_consumer_kernel_equals_lockstep(dev, monkeypatch, H, 
 @pytest.mark.parametrize("H,W,res,B", [(1080, 1920, 518, 7), (720, 1280, 336, 16), (1440, 2560, 518, 6), (1080, 1440, 518, 9)])
 def test_head_conv1_persistent_kernel_equals_one_shot_blocks(dev, monkeypatch, H, W, res, B):
     """conv3_c128_ups_kernel (round 5: the head's conv1 at batch -- persistent blocks, the 64 x 1152 weights in registers, the fusion
-    stage's x2 up-sample interpolated from a staged source window; off by default: not faster yet, D2S_HEAD1P_MIN=2048 enables it)
-    against the one-shot conv3_halo2 blocks (D2S_HEAD1P_MIN=0) and the
+    stage's x2 up-sample interpolated from a staged source window by producer waves while consumer waves run the MFMAs) against the
+    one-shot conv3_halo2 blocks (D2S_HEAD1P_MIN=0) and the
     stand-alone up-sample (D2S_NO_UPSFOLD=1): lerp_chunk on the same four chunks and conv3_halo2's accumulation order per output, so
     the depth maps must be bit-identical -- several model-input sizes (ragged edge tiles, other scales), >= 2048 conv1 tiles."""
     from desktop2stereo_amd import ops, synth
@@ -688,7 +688,7 @@ def test_head_conv1_persistent_kernel_equals_one_shot_blocks(dev, monkeypatch, H
     keys = ("D2S_HEAD1P_MIN", "D2S_NO_UPSFOLD")
     outs = {}
     try:
-        for name, env in (("default", {"D2S_HEAD1P_MIN": "2048"}), ("one_shot", {"D2S_HEAD1P_MIN": "0"}), ("standalone", {"D2S_NO_UPSFOLD": "1"})):
+        for name, env in (("default", {}), ("one_shot", {"D2S_HEAD1P_MIN": "0"}), ("standalone", {"D2S_NO_UPSFOLD": "1"})):
             for k in keys:
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
