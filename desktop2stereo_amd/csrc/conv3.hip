@@ -453,7 +453,8 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
 // (cut-point builds: consumers alone 185 us, producers alone 218-240 us, together 342: ONE wave per SIMD and role has nobody to cover its
 // LDS round trips, and together the round trips get longer; PMC, profiles/r5_08: MFMA busy 0.28, waves waiting 0.45 of their cycles);
 // all table reads and all 24 tap reads of a six-chunk half-tile in flight together: 296-315 us (producers alone 205).  By instruction
-// count a tile is 2.8 us of issue slots per SIMD (137 us per launch): what is left is latency in both roles' single waves.
+// count a tile is 2.8 us of issue slots per SIMD (137 us per launch): what is left is latency in both roles' single waves -- the K loop
+// alone (cut 3: no interpolation, no output path) is 196-207 us = 31 cycles per v_mfma_f32_16x16x32_bf16 against ~17 back to back.
 // ================================================================================================
 __global__ void __launch_bounds__(512)
 conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEpi e, int ntiles) {
@@ -549,7 +550,7 @@ conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
     // arithmetic and linear_tap per chunk the four producer waves needed 4.3 us per tile against 1.9 us of MFMA work.)
     auto lerp_chunks = [&](int sb, int hbuf, auto k0c, auto k1c) {
         const u32x4* stg = stg0 + sb * STG;
-#if defined(C128_CUT) && C128_CUT == 1     // (tuning aid, timing only: no interpolation)
+#if defined(C128_CUT) && (C128_CUT == 1 || C128_CUT == 3)     // (tuning aid, timing only: no interpolation)
         if (a.Hs > 0) return;
 #endif
         constexpr int k0 = decltype(k0c)::value, NB = 6;       // chunks per batch: all their table reads, then all 24 tap reads, are in flight together
@@ -691,7 +692,9 @@ conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
         };
         // phase 1: the previous tile's rows leave the patch; halo rows 0-4
         static_for<DEPTH>([&](auto ic) { fq[decltype(ic)::value] = frag(ic); });
+#if !(defined(C128_CUT) && C128_CUT == 3)    // (CUT 3, timing only: no interpolation, no output path -- the K loop and the barriers)
         if (tprev >= 0) store_rows(tprev);
+#endif
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         kloop(std::integral_constant<int, 0>{}, std::integral_constant<int, NFR / 2>{});
