@@ -454,8 +454,16 @@ conv3_head_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEp
 // LDS round trips, and together the round trips get longer; PMC, profiles/r5_08: MFMA busy 0.28, waves waiting 0.45 of their cycles);
 // all table reads and all 24 tap reads of a six-chunk half-tile in flight together: 296-315 us (producers alone 205).  By instruction
 // count a tile is 2.8 us of issue slots per SIMD (137 us per launch): what is left is latency in both roles' single waves -- the K loop
-// alone (cut 3: no interpolation, no output path) is 196-207 us = 31 cycles per v_mfma_f32_16x16x32_bf16 against ~17 back to back.
+// alone (cut 3: no interpolation, no output path) was 196-207 us = 31 cycles per v_mfma_f32_16x16x32_bf16 against ~17 back to back: the
+// compiler had sunk the "8 ahead" fragment reads to just behind the previous use of their registers (s_waitcnt lgkmcnt(1) before every
+// MFMA group); as inline asm with hand-counted lgkmcnt (6 in flight) the K loop alone takes 170 us; the launch 296-307 (producers: 205 alone).
 // ================================================================================================
+template <int OFF> __device__ __forceinline__ void c3_lds_read_b128(u32x4& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N_> __device__ __forceinline__ void c3_lgkm_wait(u32x4& frag) {     // the fragment rides along: its consumers cannot move above the wait
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N_));
+}
 __global__ void __launch_bounds__(512)
 conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, GemmEpi e, int ntiles) {
     KERNARG_WARM(kaw_)
@@ -662,7 +670,7 @@ conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
         }
     };
     int tprev = -1;                                            // the tile whose output rows sit in the patch
-    constexpr int DEPTH = 8, NFR = 10 * 12;                    // fragments in flight (4: the K loop ran at the LDS latency, 3.5 us per tile alone); fragments per tile (halo row, kx, g)
+    constexpr int DEPTH = 6, NFR = 10 * 12;                    // fragments in flight; fragments per tile (halo row, kx, g)
     for (; t >= 0;) {
         const int t2 = tile_at(kk + 2);
         ++kk;
@@ -670,28 +678,34 @@ conv3_c128_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
         const u32x4* hp = lds + buf * HALO + hb0;
         f32x4 acc[8];
         u32x4 fq[DEPTH];
-        auto frag = [&](auto ic) {
+        // Fragment reads as inline asm with hand-counted lgkmcnt: written as plain loads "DEPTH ahead", the compiler sank every ds_read_b128
+        // to just behind the previous use of its registers and waited lgkmcnt(1) before each group of MFMAs -- the K loop ran at the LDS
+        // round trip, 31 cycles per MFMA.  LDS returns in order: before fragment idx is used, at most DEPTH - 1 younger reads may be out
+        // (fewer at the end of the tile).  The wait carries the fragment as an operand so that its MFMAs cannot move above it.
+        const unsigned hpa = (unsigned)(unsigned long)((__attribute__((address_space(3))) const char*)hp);
+        auto frag_issue = [&](auto ic) {
             constexpr int idx = decltype(ic)::value, ir = idx / 12, kx = (idx / 4) % 3, g = idx % 4;
-            return hp[(ir * HWD + kx) * PST + g * 4];
+            c3_lds_read_b128<((ir * HWD + kx) * PST + g * 4) * 16>(fq[idx % DEPTH], hpa);
         };
-        auto kloop = [&](auto lo, auto hi) {                   // fragments [lo, hi): each read DEPTH ahead of its MFMAs
-#if defined(C128_CUT) && C128_CUT == 2     // (timing only: no K loop)
-            static_for<0>([&](auto jc) {
-#else
+        auto kloop = [&](auto lo, auto hi) {                   // fragments [lo, hi)
             static_for<decltype(hi)::value - decltype(lo)::value>([&](auto jc) {
-#endif
                 constexpr int idx = decltype(lo)::value + decltype(jc)::value, ir = idx / 12, kx = (idx / 4) % 3, g = idx % 4;
+                constexpr int out = NFR - 1 - idx < DEPTH - 1 ? NFR - 1 - idx : DEPTH - 1;     // younger reads in flight
+                c3_lgkm_wait<out>(fq[idx % DEPTH]);
                 const u32x4 fa = fq[idx % DEPTH];
-                if constexpr (idx + DEPTH < NFR) fq[idx % DEPTH] = frag(std::integral_constant<int, idx + DEPTH < NFR ? idx + DEPTH : 0>{});
                 // output row i = ir - ky: ky ascends with ir for a fixed i, so each accumulator sees (ky, kx, g) in conv3_halo2's order
                 static_for<3>([&](auto kyc) {
                     constexpr int ky = decltype(kyc)::value, i = ir - ky;
                     if constexpr (i >= 0 && i < 8) mma_chunk(acc[i], wf[ky * 3 + kx][g], fa, bf16_t());
                 });
+                if constexpr (idx + DEPTH < NFR) {
+                    asm volatile("" : "+v"(acc[ir < 8 ? ir : 7]));                              // (the refill stays BEHIND this fragment's MFMAs)
+                    frag_issue(std::integral_constant<int, idx + DEPTH < NFR ? idx + DEPTH : 0>{});
+                }
             });
         };
         // phase 1: the previous tile's rows leave the patch; halo rows 0-4
-        static_for<DEPTH>([&](auto ic) { fq[decltype(ic)::value] = frag(ic); });
+        static_for<DEPTH>([&](auto ic) { frag_issue(ic); });
 #if !(defined(C128_CUT) && C128_CUT == 3)    // (CUT 3, timing only: no interpolation, no output path -- the K loop and the barriers)
         if (tprev >= 0) store_rows(tprev);
 #endif
