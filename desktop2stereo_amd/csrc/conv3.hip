@@ -972,6 +972,8 @@ conv3_head_ups_kernel(GemmA a, const bf16_t* __restrict__ W, int N, int Kpad, Ge
             f32x4 acc[4][2];
             const u32x4* hp = lds + buf * HALO + hb0;
             // input rows R0 .. R0 + 2 of the wave's six: fragment (r, kx, ks) feeds output rows i = r - ky, ky = 0 .. 2
+            // (round 5: these reads pinned four ahead of their MFMAs as in conv3_c128_ups_kernel -- 282 vs 283 us: here the producers
+            //  set the pace; not kept)
             auto mma_rows = [&](auto r0c) {
                 constexpr int R0 = decltype(r0c)::value;
                 static_for<3>([&](auto rc) {
