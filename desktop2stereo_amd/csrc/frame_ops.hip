@@ -612,6 +612,33 @@ __device__ __forceinline__ void wl_sync() { asm volatile("s_waitcnt lgkmcnt(0)" 
 __device__ __forceinline__ void wl_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
 
+// Round 5 (session 3): the kernel is bound by VALU issue (a wave64 VALU instruction occupies its SIMD for 4 cycles: 289 per wave-row of
+// 256 pixels x 2 eyes = 122 us of the 187 at batch 32), so the per-pixel stream is written for instruction count:
+//   * the six taps of a pixel leave as ds_read_b32 with IMMEDIATE plane offsets off one address register (ds_read2_b32's 8-bit offsets
+//     cannot reach the next plane: the compiler spent two v_add per pixel on plane bases), waited for with hand-counted lgkmcnt;
+//   * the sum of a tap pair's two products is one v_add_f32 issued from (non-volatile) inline asm: left to itself the SLP vectoriser
+//     pairs the sums of different pixels into v_pk_add_f32 and pays three v_mov per pair to line the operands up;
+//   * RGBX -> 12 bytes is three v_perm_b32; the row part of an output address is wave-uniform (SALU) and the lane part a constant.
+// WL_PLAIN_C (tools/build_variant.sh) restores the compiler-scheduled form: same bits (tools/warp_bench.py --digest).
+__device__ __forceinline__ float wl_add(float a, float b) {
+#ifdef WL_PLAIN_C
+    return a + b;
+#else
+    float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#endif
+}
+struct WlTaps { float r0, r1, g0, g1, b0, b1; };
+// the six taps (x, x + 1) x (R, G, B) of the pixel whose R tap 0 sits at LDS byte address a
+__device__ __forceinline__ void wl_taps_issue(WlTaps& t, uint32_t a) {
+    constexpr int P = WL_PLANE * 4;
+    asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %6 offset:4\n\tds_read_b32 %2, %6 offset:%7\n\tds_read_b32 %3, %6 offset:%8\n\t"
+                 "ds_read_b32 %4, %6 offset:%9\n\tds_read_b32 %5, %6 offset:%10"
+                 : "=&v"(t.r0), "=&v"(t.r1), "=&v"(t.g0), "=&v"(t.g1), "=&v"(t.b0), "=&v"(t.b1)
+                 : "v"(a), "n"(P), "n"(P + 4), "n"(2 * P), "n"(2 * P + 4) : "memory");
+}
+// the taps of t have landed when at most N younger LDS instructions of this wave are outstanding (LDS returns in order)
+#define WL_TAPS_WAIT(T, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(T.r0), "+v"(T.r1), "+v"(T.g0), "+v"(T.g1), "+v"(T.b0), "+v"(T.b1) :: "memory")
+
 template <int MODE>
 __global__ void __launch_bounds__(256, 4)
 stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
@@ -713,6 +740,7 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
     const bool interior = wave_x0 >= FP_MARGIN + 2 && wave_x0 + 255 <= g.W - 1 - (FP_MARGIN + 2);
     const int xs = wave_x0 + 4 * lane;                    // first of the 4 consecutive pixels this lane stores
     uint32_t* const tp = tpose[wid];
+    const uint32_t xs3 = (uint32_t)xs * 3u;              // this lane's byte column inside an output row (one eye)
     int n1_b = cur_b, n1_y = cur_y; advance(n1_b, n1_y);
     int n2_b = n1_b, n2_y = n1_y; advance(n2_b, n2_y);
     int step = 0;
@@ -756,14 +784,47 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
 #pragma unroll
             for (int k = 0; k < FP_PX; ++k) {
                 const wl_f2 dd = (wl_f2){dr[li0[k]], dr[li1[k]]} * (wl_f2){lw0[k], lw1[k]};
-                const float d = (dd[0] + dd[1]) - g.conv;
+                const float d = wl_add(dd[0], dd[1]) - g.conv;
                 shift[k] = ((-d * g.ratio) * g.max_px) * 0.05f;
+#ifdef WL_PLAIN_C
                 small = small && fabsf(shift[k]) < (float)(FP_MARGIN - 1);
+#endif
             }
+#ifndef WL_PLAIN_C
+            static_assert(FP_PX == 4, "the shift bound below is written for four pixels per lane");
+            small = fmaxf(fmaxf(fabsf(shift[0]), fabsf(shift[1])), fmaxf(fabsf(shift[2]), fabsf(shift[3]))) < (float)(FP_MARGIN - 1);
+#endif
             const bool easy = interior && __all(small);
 #pragma unroll
             for (int eye = 0; eye < 2; ++eye) {
                 float px[FP_PX][3];
+#if !defined(WL_PLAIN_C) && !defined(WL_CUT_TAPS)
+                if (easy) {
+                    const uint32_t sbase = (uint32_t)(size_t)sp;               // LDS byte address of plane R at frame x = 0 (wave-uniform)
+                    WlTaps tp_[FP_PX];
+                    wl_f2 ww[FP_PX];
+                    auto issue = [&](int k) {
+                        const float sx = eye ? xf[k] - shift[k] : xf[k] + shift[k];
+                        const float fl = floorf(sx);
+                        const float w1 = sx - fl, w0 = 1.0f - w1;
+                        ww[k] = (wl_f2){w0, w1};
+                        wl_taps_issue(tp_[k], sbase + ((uint32_t)(int)fl << 2));
+                    };
+                    auto blend = [&](int k) {
+                        const wl_f2 vr = (wl_f2){tp_[k].r0, tp_[k].r1} * ww[k], vg = (wl_f2){tp_[k].g0, tp_[k].g1} * ww[k],
+                                    vb = (wl_f2){tp_[k].b0, tp_[k].b1} * ww[k];
+                        px[k][0] = wl_add(vr[0], vr[1]); px[k][1] = wl_add(vg[0], vg[1]); px[k][2] = wl_add(vb[0], vb[1]);
+                    };
+                    // at most 12 reads in flight (lgkmcnt counts to 15); a pixel is blended while the next but one is requested
+                    issue(0); issue(1);
+                    WL_TAPS_WAIT(tp_[0], 6); blend(0);
+                    issue(2);
+                    WL_TAPS_WAIT(tp_[1], 6); blend(1);
+                    issue(3);
+                    WL_TAPS_WAIT(tp_[2], 6); blend(2);
+                    WL_TAPS_WAIT(tp_[3], 0); blend(3);
+                } else
+#endif
                 if (easy) {
 #pragma unroll
                     for (int k = 0; k < FP_PX; ++k) {
@@ -803,7 +864,7 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
                             const wl_f2 ww = {w0, w1};
                             const wl_f2 vr = (wl_f2){p0[0], p1[0]} * ww, vg = (wl_f2){p0[WL_PLANE], p1[WL_PLANE]} * ww,
                                         vb = (wl_f2){p0[2 * WL_PLANE], p1[2 * WL_PLANE]} * ww;
-                            px[k][0] = vr[0] + vr[1]; px[k][1] = vg[0] + vg[1]; px[k][2] = vb[0] + vb[1];
+                            px[k][0] = wl_add(vr[0], vr[1]); px[k][1] = wl_add(vg[0], vg[1]); px[k][2] = wl_add(vb[0], vb[1]);
                         }
                     } else {
                         const uint8_t* src_row = rgb + ((long)b * g.H + y) * (long)g.W * 3;
@@ -842,15 +903,28 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
                 const uint4 v = *(const uint4*)&tp[4 * lane];
                 if (xs < g.W) {
                     const long row = MODE == D2S_MODE_FULL_SBS ? y : (MODE == D2S_MODE_FULL_TAB ? (long)eye * g.H + y : (long)eye * (g.H / 2) + (y >> 1));
-                    const long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + xs : xs;
                     uint3 w3;
+#ifdef WL_PLAIN_C
+                    const long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + xs : xs;
                     w3.x = (v.x & 0x00ffffffu) | (v.y << 24);
                     w3.y = ((v.y >> 8) & 0x0000ffffu) | (v.z << 16);
                     w3.z = ((v.z >> 16) & 0x000000ffu) | (v.w << 8);
+                    uint8_t* dst = out + (b * per + row * g.out_w + col) * 3;
+#else
+                    // v_perm_b32(hi, lo, sel): byte i of the result = byte sel[i] of the eight bytes lo (0-3) | hi (4-7)
+                    w3.x = __builtin_amdgcn_perm(v.y, v.x, 0x04020100u);       // R0 G0 B0 R1
+                    w3.y = __builtin_amdgcn_perm(v.z, v.y, 0x05040201u);       // G1 B1 R2 G2
+                    w3.z = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);       // B2 R3 G3 B3
+                    // wave-uniform row base (b, y, eye: scalar registers) + this lane's constant byte column
+                    // (readfirstlane: a 64-bit product added to a lane value is otherwise selected as v_mad_u64_u32 chains, six VALU per store)
+                    const long uo = ((long)b * per + row * g.out_w + (MODE == D2S_MODE_FULL_SBS ? (long)eye * g.W : 0L)) * 3;
+                    const uint32_t uo_lo = __builtin_amdgcn_readfirstlane((uint32_t)uo), uo_hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long)uo >> 32));
+                    uint8_t* dst = out + (long)(((unsigned long)uo_hi << 32) | uo_lo) + xs3;
+#endif
 #ifdef WL_CUT_STORE         // (timing only: no global stores; one conditional store keeps the values alive)
                     if (w3.x == 0x12345678u && w3.y == 0x9abcdef0u)
 #endif
-                    *(uint3*)(out + (b * per + row * g.out_w + col) * 3) = w3;
+                    *(uint3*)dst = w3;
                 }
             }
         }
