@@ -37,6 +37,10 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# Kernel arguments in device memory (the HIP runtime reads this when it is loaded, i.e. before `import torch`).  It is the default of the
+# ROCm 7.2 image; pinned here because the batch-1 frame is a chain of ~85 dependent launches and the other setting costs 7 % of it
+# (same-box A/B, tools/ab_env.sh: 817-821 against 878-882 frames/s).
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 # dense MFMA peaks, MI355X_MICROARCH.md.  "fp8": from round 5 the batched e4m3 linears (gemm_pp) run the scaled K=64 instruction
 # v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales), which issues at twice the bf16 rate -> priced against the 5 PF dense fp8 peak.
