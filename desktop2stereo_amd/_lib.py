@@ -48,7 +48,7 @@ class DibrParams(C.Structure):
                 ("search_radius", C.c_float), ("depth_tolerance", C.c_float), ("blur_radius", C.c_float),
                 ("res_w", C.c_float), ("res_h", C.c_float), ("display_mode", C.c_int32),
                 ("feather_enabled", C.c_int32), ("feather_width", C.c_float), ("corner_radius", C.c_float),
-                ("viewport", C.c_float * 4), ("alpha_mode", C.c_int32)]
+                ("viewport", C.c_float * 4), ("alpha_mode", C.c_int32), ("struct_size", C.c_uint32)]
 
 
 DIBR_ALPHA = {"window": 0, "premultiplied": 1, "rgba": 2}      # D2S_DIBR_ALPHA_*
@@ -61,6 +61,7 @@ SYMBOLS = {
     "d2s_version": (C.c_int, []),
     "d2s_debug_reload_env": (C.c_int, []),
     "d2s_debug_lds_poison": (C.c_int, []),
+    "d2s_debug_pp_tail_timeouts": (C.c_int, [C.c_int, C.POINTER(C.c_uint)]),
     "d2s_engine_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_P)]),
     "d2s_engine_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),
     "d2s_engine_finalize": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/d2s.h"
@@ -59,7 +60,8 @@ struct KernargWarm { int d0, d1, d2, d3, d4, d5; };
 // d2s_debug_reload_env() so that one process can run both sides.  Usage:  static EnvInt f{"D2S_NO_X", 0};  if (f.get()) ...
 int env_generation();
 struct EnvInt {
-    const char* name; int dflt; int gen = 0; int val = 0;
+    const char* name; int dflt;
+    std::atomic<uint64_t> cached{0};          // (generation << 32) | value: one relaxed load on the launch path, no lock
     int get();
 };
 

@@ -3,7 +3,6 @@
 
 #include <atomic>
 #include <cstdlib>
-#include <mutex>
 
 namespace d2s {
 
@@ -20,12 +19,15 @@ int hip_fail(hipError_t err, const char* what, const char* file, int line) {
 static std::atomic<int> g_env_gen{1};
 int env_generation() { return g_env_gen.load(std::memory_order_relaxed); }
 // Two host threads may enter a launcher at once (two engines, or the depth and the warp thread of the reference's main loop): the
-// cached (generation, value) pair is read and refreshed under one lock -- a few nanoseconds per launch decision.
-static std::mutex g_env_mu;
+// cached (generation, value) pair is ONE 64-bit atomic -- the hot read is a relaxed load and a compare; only the first read after
+// d2s_debug_reload_env() calls getenv (two racing refreshers store the same pair).
 int EnvInt::get() {
-    const int g = env_generation();
-    std::lock_guard<std::mutex> lk(g_env_mu);
-    if (gen != g) { const char* v = getenv(name); val = v ? atoi(v) : dflt; gen = g; }
+    const uint32_t g = (uint32_t)env_generation();
+    const uint64_t c = cached.load(std::memory_order_relaxed);
+    if ((uint32_t)(c >> 32) == g) return (int)(uint32_t)c;
+    const char* v = getenv(name);
+    const int val = v ? atoi(v) : dflt;
+    cached.store(((uint64_t)g << 32) | (uint32_t)val, std::memory_order_relaxed);
     return val;
 }
 
@@ -40,4 +42,6 @@ extern "C" int d2s_debug_lds_poison(void) {
 }
 extern "C" int d2s_debug_reload_env(void) { return d2s::g_env_gen.fetch_add(1) + 1; }
 extern "C" const char* d2s_last_error(void) { return d2s::g_err.c_str(); }
-extern "C" int d2s_version(void) { return 100; }
+// 110 (round 6): d2s_dibr_params carries struct_size (its last 4 bytes; sizeof unchanged = 80) and d2s_dibr_warp rejects a struct
+// that does not say 80 -- a caller built against the 72-byte header of version 100 is refused instead of being read past its end.
+extern "C" int d2s_version(void) { return 110; }

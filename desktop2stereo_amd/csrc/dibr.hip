@@ -473,6 +473,9 @@ extern "C" int d2s_dibr_shape(int H, int W, int display_mode, int* out_h, int* o
 extern "C" int d2s_dibr_warp(const uint8_t* rgb, const float* depth, int batch, int H, int W, const d2s_dibr_params* p,
                              void* out, int out_fmt, void* stream) {
     D2S_REQUIRE(rgb && depth && p && out, "null pointer");
+    D2S_REQUIRE(p->struct_size == sizeof(d2s_dibr_params),
+                "d2s_dibr_params.struct_size must be sizeof(d2s_dibr_params) = 80 (header of d2s_version() >= 110; the 72-byte struct of "
+                "version 100 has no alpha_mode)");
     D2S_REQUIRE(batch > 0 && H > 1 && W > 1, "bad shape");
     D2S_REQUIRE((long)H * W * 3 + 8 < (1L << 31), "frame too large (32-bit texel indices)");
     D2S_REQUIRE(out_fmt == D2S_FMT_U8_HWC || out_fmt == D2S_FMT_F32_HWC, "bad out_fmt (U8_HWC or F32_HWC)");

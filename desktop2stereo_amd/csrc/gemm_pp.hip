@@ -502,6 +502,10 @@ __device__ __forceinline__ f32x4 pp_load4_sc1(const float* p) {
 // rows it finishes every share nobody has claimed (atomic claim mask: each share is summed exactly once, in the same slab order
 // whoever sums it -- the result does not depend on who did).  So two launches that hold part of the chip each (two engines on two
 // streams) cannot dead-lock on each other's unscheduled blocks; they only lose the parallel reduce.
+// Units that gave up waiting for their partners (then the last arrival sums their shares: the result is the same bits, only the
+// parallel reduce is lost).  Counted so that it cannot happen silently: d2s_debug_pp_tail_timeouts() reads / clears it, the soak tests
+// require 0 on a chip the launch has to itself.
+__device__ unsigned pp_tail_timeouts;
 template <typename T>
 __device__ __forceinline__ void pp_tail_reduce_inkernel(const GemmEpi& e, float* part, size_t part_elems, int M, int N, int tm, int tn, int slab, int ks, int tid,
                                                         volatile unsigned* sh /* 4 words of LDS, free at this point */, bool no_wait /* test aid */) {
@@ -520,6 +524,7 @@ __device__ __forceinline__ void pp_tail_reduce_inkernel(const GemmEpi& e, float*
                 if (wall_clock64() - t0 > 5000L) break;              // 50 us at 100 MHz
             }
         }
+        if (!all) __hip_atomic_fetch_add(&pp_tail_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sh[0] = all ? 1u : 0u; sh[1] = last ? 1u : 0u;
     }
     __syncthreads();
@@ -1052,6 +1057,15 @@ int launch_gemm_pp(int precision, const GemmA& a, const void* W, int M, int N, i
 }
 
 }  // namespace d2s
+
+// Units of the in-kernel K-split tail reduce that timed out waiting for their partners since the last clear, on the CURRENT device
+// (synchronous: call it after the stream has been synchronised).  0 is the healthy value on a chip the launch has to itself.
+extern "C" int d2s_debug_pp_tail_timeouts(int clear, unsigned* count) {
+    unsigned v = 0;
+    if (count) { D2S_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(d2s::pp_tail_timeouts), sizeof(v))); *count = v; }
+    if (clear) { v = 0; D2S_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d2s::pp_tail_timeouts), &v, sizeof(v))); }
+    return D2S_OK;
+}
 
 #ifdef D2S_PP_TIMING
 extern "C" int d2s_pp_timing(int kind, unsigned long long* out) {      // kind >= 0: select + clear; out != null: read 264 x 64 stamps

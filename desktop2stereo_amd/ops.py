@@ -280,7 +280,8 @@ def dibr_params(ipd_uv=0.064, depth_ratio=1.0, convergence=0.0, display_mode="Fu
     return _lib.DibrParams(float(ipd_uv), float(viewer_depth_strength * depth_ratio), float(convergence), float(roll),
                            float(search_radius), float(depth_tolerance), float(blur_radius), float(resolution[0]),
                            float(resolution[1]), MODE[display_mode], int(bool(feather)), float(feather_width),
-                           float(corner_radius), (C.c_float * 4)(*[float(v) for v in viewport]), _lib.DIBR_ALPHA[alpha])
+                           float(corner_radius), (C.c_float * 4)(*[float(v) for v in viewport]), _lib.DIBR_ALPHA[alpha],
+                           C.sizeof(_lib.DibrParams))
 
 
 def dibr_warp(frames: torch.Tensor, depth: torch.Tensor, dp: "_lib.DibrParams", out_u8: bool = True) -> torch.Tensor:

@@ -148,6 +148,10 @@ typedef struct d2s_dibr_params {
                                   PREMULTIPLIED (1) = rgb * a, what an alpha-compositing consumer (the OpenXR layer) shows over
                                   black; RGBA (2) = frag_color itself, FOUR channels per pixel (rgb 0..255, a 0..255 / 0..1 for
                                   the u8 / f32 output formats) */
+    uint32_t struct_size;      /* MUST be sizeof(d2s_dibr_params) = 80 (d2s_version() >= 110).  The struct grew from 72 to 80 bytes when
+                                  alpha_mode was added; this field occupies what was tail padding, so the size is unchanged, and
+                                  d2s_dibr_warp refuses anything else -- a caller built against the 72-byte header is rejected
+                                  instead of having alpha_mode read from beyond its struct */
 } d2s_dibr_params;
 enum { D2S_DIBR_ALPHA_WINDOW = 0, D2S_DIBR_ALPHA_PREMULTIPLIED = 1, D2S_DIBR_ALPHA_RGBA = 2 };
 
@@ -156,6 +160,10 @@ int d2s_version(void);
 /* Kernel-selection switches (D2S_NO_HALO2, D2S_NO_WIDE, ... -- tuning aids) are read from the environment once and
  * cached; this makes the library read them again (tests run both sides of a switch in one process).  Returns the new generation. */
 int d2s_debug_reload_env(void);
+/* gemm_pp's in-kernel K-split tail reduce never dead-locks: a unit that has waited 50 us for its partners leaves, and the last arrival
+ * sums its share (same bits).  That degradation is COUNTED, not silent: *count = units that timed out on the current device since the
+ * last clear (synchronise the stream first); tests/test_gpu_soak.py requires 0.   */
+int d2s_debug_pp_tail_timeouts(int clear, unsigned* count);
 /* 1 if the library was built with -DD2S_LDS_POISON (LDS rings pre-filled with NaN patterns: a debug build for the parity suite). */
 int d2s_debug_lds_poison(void);
 

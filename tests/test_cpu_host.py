@@ -29,7 +29,7 @@ def test_header_symbols_exported(lib):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.d2s_version() >= 100
+    assert lib.d2s_version() >= 110          # 110: d2s_dibr_params.struct_size
 
 
 def test_struct_layout_matches_header():
@@ -37,7 +37,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_lib.PostParams) == 28 and _lib.PostParams.metric.offset == 24
     assert C.sizeof(_lib.SbsParams) == 24 and _lib.SbsParams.ipd_uv.offset == 0 and _lib.SbsParams.depth_ratio.offset == 8
     assert (C.sizeof(_lib.DibrParams) == 80 and _lib.DibrParams.corner_radius.offset == 52 and _lib.DibrParams.viewport.offset == 56
-            and _lib.DibrParams.alpha_mode.offset == 72)          # (76 bytes of fields, padded to the double's alignment)
+            and _lib.DibrParams.alpha_mode.offset == 72 and _lib.DibrParams.struct_size.offset == 76)   # struct_size sits in what was tail padding
     assert C.sizeof(_lib.PreParams) == 32 and _lib.PreParams.std.offset == 12 and _lib.PreParams.resample.offset == 24 and _lib.PreParams.square.offset == 28
 
 

@@ -12,14 +12,30 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, env_extra=None, timeout=900):
+def _run(args, env_extra=None, timeout=900, tmp=None):
+    """-> the full report (written to a file by bench.py), after checking the stdout contract: the LAST stdout line is ONE compact JSON
+    object of < 6 000 bytes (the driver parses that line and keeps an ~8 KB tail; a 21 KB line left BENCH_r05.parsed = null)."""
+    import tempfile
     env = dict(os.environ, **(env_extra or {}))
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=REPO)
+    full = os.path.join(tmp or tempfile.mkdtemp(), "bench_full.json")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--full-out", full] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    out_lines = r.stdout.strip().splitlines()
+    lines = [l for l in out_lines if l.startswith("{")]
+    assert len(lines) == 1 and out_lines[-1] == lines[0], r.stdout[-2000:]
+    assert len(lines[0].encode()) < 6000, len(lines[0])
+    compact = json.loads(lines[0])
+    with open(full) as f:
+        res = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "rccl_ranks"):
+        assert k in compact, k
+        if k != "config":
+            assert compact[k] == res[k] or abs(compact[k] - res[k]) <= 1e-4 * abs(res[k]), k      # (floats are cut to 5 significant digits)
+    assert set(compact["config"]) >= {"workload", "frames_per_step_per_gpu", "timed_region"}
+    res["_compact"] = compact
+    return res
 
 
 def test_bench_contract_n1():
@@ -28,6 +44,12 @@ def test_bench_contract_n1():
               "data", "config", "roofline", "roofline_warp", "parity_class", "batched", "ingest_rank0", "rccl_ranks"):
         assert k in res, k
     assert res["n_gpus"] == 1 and res["steps"] == 6 and res["dtype"] == "bf16" and res["vs_baseline"] is None
+    c = res["_compact"]                            # what the driver parses: headline + roofline + parity + one number per sub-run
+    for k in ("roofline", "roofline_warp", "parity_class", "batched", "depth_l1_vs_ref", "depth_max_vs_ref", "warp_max_lsb", "kernels", "full_report"):
+        assert k in c, k
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in c["roofline"], k
+    assert abs(c["roofline"]["frac"] - res["roofline"]["frac"]) < 1e-4 and c["batched"]["roofline"]["frac"] > 0
     assert abs(res["value"] - 1e3 / res["ms_per_step"]) < 1e-6 * res["value"]
     rf = res["roofline"]
     assert rf["bound"] in ("mfma", "hbm") and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9

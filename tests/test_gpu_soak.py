@@ -18,6 +18,16 @@ def dev():
     return torch.device("cuda", 0)
 
 
+def _tail_timeouts(clear=True) -> int:
+    """units of gemm_pp's in-kernel tail reduce that gave up waiting for their partners (include/d2s.h): must stay 0"""
+    import ctypes
+    from desktop2stereo_amd import _lib
+    torch.cuda.synchronize()
+    n = ctypes.c_uint(0)
+    assert _lib.load().d2s_debug_pp_tail_timeouts(1 if clear else 0, ctypes.byref(n)) == 0
+    return n.value
+
+
 class _Perturb:
     """Concurrent traffic on a side stream: 256 MiB device-to-device copies back to back (L2 / MALL / HBM contention)."""
 
@@ -36,6 +46,7 @@ def test_soak_gemm_pp_bit_identical_under_load(dev):
     from desktop2stereo_amd import ops
     torch.manual_seed(3)
     pert = _Perturb(dev)
+    _tail_timeouts()
     # ViT-B encoder linears at batch 32 (24896 rows: two rounds, K-split tail on FC2) and 27 (21006 rows: one round), ragged M
     shapes = [(24896, 768, 3072), (24896, 3072, 768), (24896, 2304, 768), (21006, 768, 768), (21006, 3072, 768), (6225, 768, 768), (513, 1024, 512)]
     for prec in ("bf16", "fp8"):
@@ -49,6 +60,13 @@ def test_soak_gemm_pp_bit_identical_under_load(dev):
                 if r % 8 == 0:
                     pert.kick()
                 assert torch.equal(ops.gemm_probe(A, W, b, prec, 256256), first), (prec, M, N, K, r)
+            if M > 20000:                    # the chip to itself (no copy kernels competing for CUs): no unit may time out
+                under_load = _tail_timeouts()
+                for r in range(5):
+                    assert torch.equal(ops.gemm_probe(A, W, b, prec, 256256), first)
+                assert _tail_timeouts() == 0, ("a K-split tail unit timed out waiting for its partners on an idle chip", prec, M, N, K)
+                if under_load:
+                    print(f"[soak] {prec} {M}x{N}x{K}: {under_load} tail unit(s) timed out under copy load (same bits, reduce done by the last arrival)")
             del A, W, first
     torch.cuda.synchronize()
 
@@ -89,6 +107,7 @@ def test_soak_batched_engine_bit_identical_under_load(dev):
     sp = ops.sbs_params(p.ipd, p.depth_strength, p.convergence, "Full-SBS", p.fill_16_9)
     pert = _Perturb(dev)
     wts = make_weights(cfg, 0)
+    _tail_timeouts()
     for B in (32, 27):
         eng = ops.Engine(cfg, wts, h, w, B, "bf16")
         frames = torch.from_numpy(np.stack([synth.structured_frame(H, W_, i) for i in range(B)])).to(dev)
@@ -97,6 +116,12 @@ def test_soak_batched_engine_bit_identical_under_load(dev):
             if r % 2 == 0:
                 pert.kick(8)
             assert torch.equal(eng.pipeline(frames, p, sp), first), (B, r)
+        under_load = _tail_timeouts()
+        for r in range(3):
+            assert torch.equal(eng.pipeline(frames, p, sp), first), (B, "idle", r)
+        assert _tail_timeouts() == 0, B
+        if under_load:
+            print(f"[soak] batch {B}: {under_load} tail unit(s) timed out under copy load")
         eng.close()
         del frames, first
     torch.cuda.synchronize()
