@@ -4,6 +4,7 @@
 //   stereo_warp     A14    (reference depth.py:2122-2184), with A13 fused when depth comes at model res
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace d2s {
 
@@ -940,6 +941,380 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
 #undef WL_UB
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gather path (round 6; Full-SBS / Full-TAB / Half-SBS / Half-TAB, u8 HWC in and out, W % 4 == 0, 3 dw < W).
+// stereo_warp_lanes above ends at 0.41 of the HBM rate: ~230 VALU instructions per wave-row (fp32 planes in LDS: unpack once, six
+// ds_read_b32 and six float operations per pixel and eye, a transpose through LDS for the stores) behind one block barrier per row,
+// 16 waves per CU.  This kernel has no barrier, no float blend and no shared state between waves (8 waves per SIMD cover each
+// other's round trips, nothing runs in lock step):
+//   * a lane owns FOUR CONSECUTIVE pixels of a row and both eyes: its results are 12 contiguous bytes per eye (one 12-byte store,
+//     768 contiguous bytes per wave), no transpose;
+//   * a wave stages ITS OWN window of the source row (256 + 2 x 64 pixels) in 2 KiB of LDS as one RGBX dword per pixel -- aligned
+//     12-byte global loads, three instructions to unpack four pixels -- one row ahead through registers; a wave's LDS operations
+//     execute in order, so the window of row r + 1 overwrites row r's behind its reads without any barrier or second buffer;
+//   * the two taps of a pixel and eye are ONE ds_read2_b32 (x0, x0 + 1).  Measured (tools/ubench/lds_tap_patterns.hip): with lanes
+//     4 pixels apart that read runs into 4-way bank conflicts (16.5 cycles per wave instruction); one pad dword per 16 pixels (slot
+//     16 of a chunk = a copy of the next chunk's first pixel, so x0 + 1 stays adjacent) makes it conflict-free (7 cycles).  An
+//     8-byte LDS read at a 4-byte-aligned address (ds_read_b64) takes 65 cycles and an unaligned 8-byte GLOBAL load per tap 29
+//     cycles of the CU's texture path (tools/ubench/unaligned_taps.hip: the first form of this kernel, 323 us at batch 32);
+//   * coordinates are 16.16 fixed point (the reference's own float32 sum x + shift has 2^-13 .. 2^-14 px of resolution at x ~ 1000):
+//     x0 = s >> 16, w1 = s & 0xffff, w0 = 65535 - w1, and a channel is v_dot2_u32_u16([p0, p1], [w0, w1]) + 32768 -> byte 2 of the
+//     result is the rounded value: one v_perm_b32 (bytes -> u16 pair) and one dot per channel instead of two conversions, two
+//     products and a sum.  Weight error <= 2^-16: the blend is within 0.008 of a level of the exact bilinear value, inside the
+//     1-LSB gate like the float kernels' 0.004 (from their float32 coordinate);
+//   * the depth sample (A13 fused) comes from three depth columns per lane (4 pixels span < 1 column step when 3 dw < W) with
+//     per-lane constant weights that already carry -ratio * max_px * 0.05 * 65536: three FMAs give a pixel's fixed-point shift;
+//   * Half modes chain the second blend of a pair into the first through the dot's accumulator (one shift at the end).
+// A wave-row whose |shift| reaches the staged halo takes its taps from global memory (8-byte loads, reflection in fixed point, one per
+// side); beyond |shift| >= W - 1, and for the last wave of the buffer's last row (whose 8-byte loads could read 2 bytes past the
+// allocation), the per-pixel float arithmetic of the generic kernel.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned short wg_u16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint32_t wg_lds_u32;
+__device__ __forceinline__ uint2 wg_load8(const uint8_t* p) { uint2 d; __builtin_memcpy(&d, p, 8); return d; }     // global_load_dwordx2, any alignment
+__device__ __forceinline__ uint32_t wg_dot(uint32_t a, uint32_t w, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(wg_u16x2, a), __builtin_bit_cast(wg_u16x2, w), c, false);
+}
+// explicit global-address-space types: pointers that went through scalar arithmetic keep global_load / global_store (not flat_*)
+typedef __attribute__((address_space(1))) const uint8_t wg_gc8;
+typedef __attribute__((address_space(1))) uint8_t wg_g8;
+typedef uint32_t wg_u3 __attribute__((ext_vector_type(3)));         // (a plain vector type: HIP's uint3 is a class on the host pass)
+typedef __attribute__((address_space(1), aligned(4))) wg_u3 wg_g_u3w;
+// an opaque copy of a per-lane 32-bit offset, made INSIDE the loop: the zero-extension then stays in the loop's block, where instruction
+// selection can fold "uniform 64-bit base + zext(lane offset)" into the scalar-base addressing mode (hoisted out of the loop as a
+// 64-bit register pair it costs a v_lshl_add_u64 per access)
+__device__ __forceinline__ uint32_t wg_v(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+// 12 bytes at scalar base + lane offset, issued from inline asm (the compiler neither waits for it nor copies its result: WG_WAIT)
+__device__ __forceinline__ void wg_gload3(wl_u3& d, uint32_t off, wg_gc8* base) {
+    asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(d) : "v"(off), "s"(base) : "memory");
+}
+// a wave-uniform value pinned to a scalar register
+__device__ __forceinline__ int wg_s(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float wg_sf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+constexpr int WG_MG = 64;                                  // staged halo each side (pixels)
+constexpr int WG_WIN_BYTES = 2048;                         // per wave: (256 + 2 * 64) pixels * 34 / 32 dwords = 1 632 bytes, rounded up
+
+// the float path for one lane's 4 pixels of one output row (Half-TAB: of the row pair y, y + 1), both eyes: the generic kernel's
+// arithmetic (eye_sample), inlined -- a call in the row loop would make the register allocator keep the loop's values in scratch
+__device__ __forceinline__ void wg_eye_sample(const uint8_t* __restrict__ rgb, long fo, const float* __restrict__ dep, const WarpGeom& g,
+                                              int y, int x, float sign, float& r, float& gg, float& b) {
+    const float d = depth_at(dep, g, y, x) - g.conv;
+    const float shift = ((-d * g.ratio) * g.max_px) * 0.05f;
+    const float span = (float)(g.W - 1);
+    float sx = fabsf((float)x + sign * shift);
+    if (sx > span) {                                           // ATen reflect_coordinates + clip
+        const float extra = fmodf(sx, span);
+        const int flips = (int)floorf(sx / span);
+        sx = (flips & 1) ? span - extra : extra;
+        sx = fminf(fmaxf(sx, 0.f), span);
+    }
+    const int x0 = (int)sx;
+    const float w1 = sx - (float)x0, w0 = 1.0f - w1;
+    const int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
+    const uint8_t* p0 = rgb + (fo + (long)y * g.W + x0) * 3;
+    const uint8_t* p1 = rgb + (fo + (long)y * g.W + x1) * 3;
+    r = w0 * (float)p0[0] + w1 * (float)p1[0]; gg = w0 * (float)p0[1] + w1 * (float)p1[1]; b = w0 * (float)p0[2] + w1 * (float)p1[2];
+}
+template <int MODE>
+__device__ __forceinline__ void wg_slow_row(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
+                                            const WarpGeom& g, int b, int y, int x) {
+    constexpr bool HSBS = MODE == D2S_MODE_HALF_SBS, HTAB = MODE == D2S_MODE_HALF_TAB;
+    const long fo = (long)b * g.H * g.W, per = (long)g.out_h * g.out_w;
+    const float* dep = depth + (long)b * g.dh * g.dw;
+    for (int eye = 0; eye < 2; ++eye) {
+        const float sg = eye ? -1.f : 1.f;
+        const long orow = MODE == D2S_MODE_FULL_TAB ? (long)eye * g.H + y : (HTAB ? (long)eye * (g.H / 2) + (y >> 1) : y);
+        uint8_t* o = out + (b * per + orow * g.out_w) * 3;
+        for (int k = 0; k < 4; k += (HSBS ? 2 : 1)) {
+            float r, gg, bl;
+            wg_eye_sample(rgb, fo, dep, g, y, x + k, sg, r, gg, bl);
+            if (HTAB || HSBS) {
+                float r2, g2, b2;
+                wg_eye_sample(rgb, fo, dep, g, HTAB ? y + 1 : y, HSBS ? x + k + 1 : x + k, sg, r2, g2, b2);
+                r = (r + r2) * 0.5f; gg = (gg + g2) * 0.5f; bl = (bl + b2) * 0.5f;
+            }
+            const long col = HSBS ? (((long)eye * g.W + x + k) >> 1) : (MODE == D2S_MODE_FULL_SBS ? (long)eye * g.W + x + k : x + k);
+            o[col * 3] = to_u8(r); o[col * 3 + 1] = to_u8(gg); o[col * 3 + 2] = to_u8(bl);
+        }
+    }
+}
+
+template <int MODE, int WPS /* resident waves per SIMD the register budget is cut for */>
+__global__ void __launch_bounds__(256, WPS)
+stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
+                   int B, WarpGeom g, int rpw /* source rows per wave (even for Half-TAB) */, int ntx /* 256-pixel column tiles */) {
+    constexpr bool HSBS = MODE == D2S_MODE_HALF_SBS, HTAB = MODE == D2S_MODE_HALF_TAB, HALF = HSBS || HTAB;
+    constexpr int NR = HTAB ? 2 : 1;                          // source rows per output row
+    __shared__ __attribute__((aligned(WG_WIN_BYTES))) uint32_t win[4][WG_WIN_BYTES / 4];
+    const int lane = threadIdx.x & 63, wid = wg_s((int)(threadIdx.x >> 6));
+    const int gw = wg_s((int)(blockIdx.x * 4)) + wid;
+    // (integer division runs on the vector unit: its results are read back into scalar registers, or everything derived from them --
+    //  row, frame, every row pointer -- would be computed per lane)
+    const int band = wg_s(gw / ntx), tx = gw - band * ntx;
+    const int rows = B * g.H;
+    const int R0 = band * rpw;
+    if (R0 >= rows) return;
+    const int nrow = rows - R0 < rpw ? rows - R0 : rpw;
+    int b = wg_s(R0 / g.H), y = R0 - b * g.H;               // (one division per wave)
+    const int wx0 = tx * 256;
+    const int x = wx0 + 4 * lane;
+    const bool act = x < g.W;
+    const int xc = act ? x : g.W - 4;                       // idle lanes (last tile) repeat the last group, stores masked
+    const int span_fx = (g.W - 1) << 16;
+    const long W3 = (long)g.W * 3;
+    // this wave's window of a source row: pixels [ws, we), 4-pixel groups
+    const int ws = wx0 - WG_MG < 0 ? 0 : wx0 - WG_MG;
+    const int we = wx0 + 256 + WG_MG > g.W ? g.W : wx0 + 256 + WG_MG;
+    const int ngroups = (we - ws) >> 2;
+    const int g0 = lane < ngroups ? lane : ngroups - 1, g1 = lane + 64 < ngroups ? lane + 64 : ngroups - 1;   // (clamped: duplicates write the same dwords)
+    const uint32_t gofs0 = (uint32_t)(ws + 4 * g0) * 3u, gofs1 = (uint32_t)(ws + 4 * g1) * 3u;
+    const uint32_t wbase = (uint32_t)(size_t)&win[wid][0];  // LDS byte address of this wave's window: a multiple of WG_WIN_BYTES
+    wg_lds_u32* const wl0 = (wg_lds_u32*)(wbase + 4u * (uint32_t)(4 * g0 + 2 * (g0 >> 3)));     // where this lane's groups go (two pad dwords per 32 pixels)
+    wg_lds_u32* const wl1 = (wg_lds_u32*)(wbase + 4u * (uint32_t)(4 * g1 + 2 * (g1 >> 3)));
+    const bool dup0 = (g0 & 7) == 0 && g0 > 0, dup1 = (g1 & 7) == 0;       // first pixel of a 32-pixel chunk: also the first pad slot of the chunk before
+
+    // per-lane column constants: three depth columns c0 .. c0 + 2; pixel k lerps columns (jk, jk + 1), jk = 0 | 1, by w1[k].  The shift
+    // is linear in depth, so the three COLUMNS are turned into fixed-point shifts first (shift_fx = depth * K + ck, K = -ratio * max_px *
+    // 0.05 * 65536, ck = -conv * K) and a pixel costs two selects, a difference and one FMA; the selects' lane masks live in SGPRs.
+    const float K = ((-g.ratio * g.max_px) * 0.05f) * 65536.f;
+    const float ck = -g.conv * K;
+    uint32_t c0b;                                           // byte offset of column c0 inside a depth row
+    float w1k[4];
+    bool jk[4];
+    {
+        const Tap t0 = linear_tap(xc, g.dsx, g.dw, false);
+        const int c0 = t0.i0 < g.dw - 3 ? t0.i0 : g.dw - 3;
+        c0b = 4u * (uint32_t)c0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const Tap t = linear_tap(xc + k, g.dsx, g.dw, false);
+            const int j0 = t.i0 - c0;                       // 0, 1, or 2 = the clamped last column (i1 == i0): columns (1, 2) with weight 1
+            jk[k] = j0 >= 1;
+            w1k[k] = j0 >= 2 ? 1.0f : t.w1;
+        }
+    }
+    // a wave whose pixels stay more than MG + 2 away from both frame edges never reflects while |shift| < MG - 1
+    const bool interior = wx0 >= WG_MG + 2 && wx0 + 255 <= g.W - 1 - (WG_MG + 2);
+    const uint32_t lane_col = (uint32_t)xc * 3u;           // byte column of this lane's group inside one eye's output row
+    const int xfx_rel = (xc - ws) << 16, ws_fx = ws << 16;  // fixed-point x of this lane's first pixel relative to the window (the fraction is the same)
+    const float small_lim = (float)((WG_MG - 1) << 16);
+
+    // Everything about a ROW is wave-uniform and kept in scalar registers: the source row pointer advances by W * 3 (frames are contiguous:
+    // the global row index runs through them), the vertical depth tap is computed on the vector unit once and read back with
+    // v_readfirstlane (its row offsets then cost scalar multiplies, not v_mul_lo_u32), lanes add constant 32-bit offsets.
+    wg_gc8* srow = (wg_gc8*)rgb + (long)R0 * W3;
+    const uint32_t drow_b = (uint32_t)g.dw * 4u, dplane = (uint32_t)g.dh * drow_b;      // bytes of a depth row / map (the launcher keeps B * dplane < 2^32)
+    // Two rows of window loads in flight (register sets A / B; the row loop is unrolled by two so that a set is a fixed group of registers):
+    // the set staged at the end of row r was requested at the end of row r - 2.  All loads of the row loop are issued from inline asm and
+    // waited for with hand-counted vmcnt, as in stereo_warp_lanes: left to the compiler, a load whose result crosses the loop's back edge or
+    // a branch gets a register copy -- and an s_waitcnt vmcnt(0) -- right behind its issue (the first builds of this kernel ran 165 us at
+    // every prefetch depth and occupancy for that reason).  Every load is unconditional (clamped to the wave's last row): the counts below
+    // are the same on every path.
+    wl_u3 pwA0, pwA1, pwB0, pwB1;
+    wl_u3 dA0, dA1, dB0, dB1;                               // depth columns (rows i0 / i1 of the depth grid) of the current / next row, as bits
+    float dwA0, dwA1, dwB0, dwB1;                           // their vertical weights (scalar registers)
+#ifdef WG_CUT_LOAD           // (tuning aid, tools/build_variant.sh: timing only -- no window loads from global memory)
+#define WG_WIN_LOAD(P0, P1, ROW_) { P0 = (wl_u3){(uint32_t)(size_t)(ROW_), 0x01020304u, 0x05060708u}; P1 = P0; }
+#else
+#define WG_WIN_LOAD(P0, P1, ROW_) { wg_gload3(P0, gofs0, (ROW_)); wg_gload3(P1, gofs1, (ROW_)); }
+#endif
+#define WG_DEPTH_LOAD(BB, YY, T_, B_, W0_, W1_)                                                    \
+    {                                                                                             \
+        const Tap ty_ = linear_tap((YY), g.dsy, g.dh, false);                                     \
+        const int i0_ = wg_s(ty_.i0), i1_ = wg_s(ty_.i1);                                         \
+        wg_gc8* dp_ = (wg_gc8*)depth + (unsigned long)((uint32_t)(BB) * dplane);                   \
+        wg_gload3(T_, c0b, dp_ + (uint32_t)i0_ * drow_b); wg_gload3(B_, c0b, dp_ + (uint32_t)i1_ * drow_b); \
+        W0_ = wg_sf(ty_.w0); W1_ = wg_sf(ty_.w1);                                                 \
+    }
+    // at most N vector-memory operations younger than the awaited loads may stay in flight (vmcnt retires in order)
+    // ONE asm statement per wait (two statements merged by a branch made the compiler copy the in-flight registers ahead of the wait):
+    // vmcnt(N) always; when FIRST (wave-uniform: the band's first step, with fewer operations behind it) the stricter vmcnt(N0) first
+#ifdef WG_STRICT             // (debugging aid: every wait drains the queue)
+#define WG_WAIT(N, N0, FIRST, R0_, R1_) asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0_), "+v"(R1_) : "n"(N), "n"(N0), "s"(wg_s((int)(FIRST))) : "memory")
+#else
+#define WG_WAIT(N, N0, FIRST, R0_, R1_)                                                            \
+    asm volatile("s_cmp_eq_u32 %4, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(%3)\n1:\n\ts_waitcnt vmcnt(%2)"   \
+                 : "+v"(R0_), "+v"(R1_) : "n"(N), "n"((N0) < (N) ? (N0) : (N)), "s"(wg_s((int)(FIRST))) : "memory", "scc")
+#endif
+    // 12 bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 -> four RGBX dwords; the first pixel of a 16-pixel chunk is also written into the
+    // pad slot of the chunk before it
+#define WG_STAGE(PW, WL_, DUP_)                                                                    \
+    {                                                                                             \
+        WL_[0] = PW[0]; WL_[1] = __builtin_amdgcn_alignbyte(PW[1], PW[0], 3);                     \
+        WL_[2] = __builtin_amdgcn_alignbyte(PW[2], PW[1], 2); WL_[3] = PW[2] >> 8;                \
+        if (DUP_) WL_[-2] = PW[0];                                                                \
+    }
+    WG_WIN_LOAD(pwA0, pwA1, srow)
+    WG_DEPTH_LOAD(b, y, dA0, dA1, dwA0, dwA1)
+    WG_WAIT(2, 2, 0, pwA0, pwA1);
+    WG_STAGE(pwA0, wl0, dup0) WG_STAGE(pwA1, wl1, dup1)                       // row 0 is staged; rows 1 and 2 are requested
+    WG_WIN_LOAD(pwA0, pwA1, srow + (1 < nrow ? 1 : 0) * W3)
+    WG_WIN_LOAD(pwB0, pwB1, srow + (2 < nrow ? 2 : nrow - 1) * W3)
+    uint32_t hold[2][HTAB ? 12 : 1];                        // Half-TAB: the even row's 16.16 sums, chained into the odd row's dots
+    bool pair_slow = false;
+    // Vector-memory operations a step issues on the LDS path: 2 depth loads (top), ST stores, 2 window loads (end).  The other paths issue
+    // at least as many (taps from global memory: 8 more loads; the float path: byte stores), so the constant wait counts below -- exact on
+    // the LDS path -- are never larger than the number of younger operations, which is all a vmcnt wait needs to be safe.  (One count per
+    // wait, no run-time choice: two asm statements merged by a branch made the compiler copy the in-flight registers ahead of the wait.)
+    constexpr int ST_FULL = HSBS ? 4 : 2;
+    // (the first step has fewer operations behind it: WG_WAIT's FIRST_ count, applied when r == 0 inside the same asm statement)
+    // Every register set is named by an empty asm statement at the end of every step: a set whose load will never be consumed (the
+    // clamped loads of a band's last rows) would otherwise be dead to the compiler, which would hand its registers to other values --
+    // and the load lands in them later.
+#define WG_KEEP_ALL() asm volatile("" : "+v"(pwA0), "+v"(pwA1), "+v"(pwB0), "+v"(pwB1), "+v"(dA0), "+v"(dA1), "+v"(dB0), "+v"(dB1))
+    // one source row; set_c: which register set holds the NEXT row's window and THIS row's depth columns (A on even steps, B on odd ones).
+    // Half-TAB: a wave's band starts on an even row (rpw and H are even), so the step's parity is the row's place in its pair
+    auto row_step = [&](auto set_c, const int r) {
+        constexpr int set = decltype(set_c)::value;
+        constexpr int h = HTAB ? set : 0;
+        constexpr int ST_CUR = HTAB ? (h ? 2 : 0) : ST_FULL, ST_PREV = HTAB ? (h ? 0 : 2) : ST_FULL;
+        {
+            int nb = b, ny = y + 1;
+            if (ny >= g.H) { ny = 0; ++nb; }
+            const bool has_next = r + 1 < nrow;
+            nb = wg_s(has_next ? nb : b); ny = wg_s(has_next ? ny : y);      // (readfirstlane: the row state stays in scalar registers; the last row repeats itself)
+            // the next row's depth columns into the other set; then this row's have landed: younger than them are the previous step's
+            // stores (ST_PREV) and window loads (2) and the two loads just issued
+            if (set == 0) WG_DEPTH_LOAD(nb, ny, dB0, dB1, dwB0, dwB1) else WG_DEPTH_LOAD(nb, ny, dA0, dA1, dwA0, dwA1)
+            // (first step: the prologue's four window loads and the two loads just issued)
+            if (set == 0) WG_WAIT(4 + ST_PREV, 6, r == 0, dA0, dA1); else WG_WAIT(4 + ST_PREV, 4 + ST_PREV, 0, dB0, dB1);
+            const wl_u3 dt = set == 0 ? dA0 : dB0, db = set == 0 ? dA1 : dB1;
+            const float dw0 = set == 0 ? dwA0 : dwB0, dw1 = set == 0 ? dwA1 : dwB1;
+            if (HTAB && h == 0) pair_slow = false;
+            // ---- fixed-point shifts: the three columns first, then this lane's 4 pixels
+            float scol[3];
+            scol[0] = fmaf(fmaf(dw1, __uint_as_float(db[0]), dw0 * __uint_as_float(dt[0])), K, ck);
+            scol[1] = fmaf(fmaf(dw1, __uint_as_float(db[1]), dw0 * __uint_as_float(dt[1])), K, ck);
+            scol[2] = fmaf(fmaf(dw1, __uint_as_float(db[2]), dw0 * __uint_as_float(dt[2])), K, ck);
+            // (a pixel's shift is a convex combination of two columns: bounds on the columns bound it)
+            const float amax = fmaxf(fmaxf(fabsf(scol[0]), fabsf(scol[1])), fabsf(scol[2]));
+            const bool all_small = __all(amax < small_lim);
+            int shq[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = jk[k] ? scol[1] : scol[0], bq = jk[k] ? scol[2] : scol[1];
+                shq[k] = (int)fmaf(w1k[k], bq - a, a);
+            }
+            bool slow = false;
+            if (!all_small) slow = ((R0 + r == rows - 1) && tx == ntx - 1) || !__all(amax < (float)span_fx);
+            if (HTAB) { pair_slow = pair_slow || slow; slow = pair_slow; }
+            if (slow) {
+                if (act && h == NR - 1) wg_slow_row<MODE>(rgb, depth, out, g, b, HTAB ? y - 1 : y, x);
+            } else
+#ifdef WG_CUT_BLEND          // (timing only: load + stage, no taps / blends / stores)
+            if (win[wid][lane] == 0x12345678u && shq[0] == 0x7654321) out[lane] = 1; else if (false)
+#endif
+            {
+                // output row(s) of this source row: wave-uniform pointers
+                const long orow = MODE == D2S_MODE_FULL_TAB ? (long)b * 2 * g.H + y : (HTAB ? (long)b * g.H + (y >> 1) : (long)b * g.H + y);
+                wg_g8* const o0 = (wg_g8*)out + orow * g.out_w * 3;
+                const long eye_ofs = MODE == D2S_MODE_FULL_SBS ? W3 : (HSBS ? W3 / 2 : (MODE == D2S_MODE_FULL_TAB ? (long)g.H * W3 : (long)(g.H / 2) * W3));
+                auto blend_row = [&](auto lds_c, auto easy_c) {
+                    constexpr bool lds = decltype(lds_c)::value, easy = decltype(easy_c)::value;
+#pragma unroll
+                    for (int eye = 0; eye < 2; ++eye) {
+                        uint2 tp[4];
+                        uint32_t wp[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            int s = xfx_rel + (k << 16) + (eye ? -shq[k] : shq[k]);      // window-relative
+                            if (!easy) {                      // absolute: one reflection per side, then x0 <= W - 2
+                                s += ws_fx;
+                                s = s < 0 ? -s : s;
+                                const int s2 = 2 * span_fx - s;
+                                s = s < s2 ? s : s2;
+                                s = s < span_fx - 1 ? s : span_fx - 1;
+                                if (lds) s -= ws_fx;
+                            }
+                            wp[k] = __builtin_amdgcn_perm((uint32_t)s, ~(uint32_t)s, 0x05040100u);      // [65535 - w1 | w1]
+                            if (lds) {                        // window pixel xr at dword xr + 2 (xr >> 5)
+                                const uint32_t sa = wbase + (((uint32_t)s >> 21) << 3);
+                                wg_lds_u32* q = (wg_lds_u32*)(sa + (((uint32_t)s >> 16) << 2));
+                                tp[k].x = q[0]; tp[k].y = q[1];
+                            } else {
+                                wg_gc8* q = srow + (uint32_t)((s >> 16) * 3);
+                                __builtin_memcpy(&tp[k], (const uint8_t*)q, 8);
+                            }
+                        }
+                        uint32_t v[12];                       // R0 G0 B0 R1 ... B3 (Half-SBS: two pixels): value in byte 2
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t dx = tp[k].x, dy = tp[k].y, w = wp[k];
+                            // [p0, p1] as a u16 pair per channel, from RGBX dwords (LDS) or from the packed bytes R0 G0 B0 R1 | G1 B1 . .
+                            const uint32_t aR = __builtin_amdgcn_perm(dy, dx, lds ? 0x0c040c00u : 0x0c030c00u),
+                                           aG = __builtin_amdgcn_perm(dy, dx, lds ? 0x0c050c01u : 0x0c040c01u),
+                                           aB = __builtin_amdgcn_perm(dy, dx, lds ? 0x0c060c02u : 0x0c050c02u);
+                            if (HTAB) {
+                                const uint32_t cR = h ? hold[eye][3 * k] : 65536u, cG = h ? hold[eye][3 * k + 1] : 65536u, cB = h ? hold[eye][3 * k + 2] : 65536u;
+                                v[3 * k] = wg_dot(aR, w, cR); v[3 * k + 1] = wg_dot(aG, w, cG); v[3 * k + 2] = wg_dot(aB, w, cB);
+                            } else if (HSBS) {                // pixels 2 q, 2 q + 1 chain into one sum
+                                const int q = k >> 1;
+                                const uint32_t cR = (k & 1) ? v[3 * q] : 65536u, cG = (k & 1) ? v[3 * q + 1] : 65536u, cB = (k & 1) ? v[3 * q + 2] : 65536u;
+                                v[3 * q] = wg_dot(aR, w, cR); v[3 * q + 1] = wg_dot(aG, w, cG); v[3 * q + 2] = wg_dot(aB, w, cB);
+                            } else { v[3 * k] = wg_dot(aR, w, 32768u); v[3 * k + 1] = wg_dot(aG, w, 32768u); v[3 * k + 2] = wg_dot(aB, w, 32768u); }
+                        }
+                        if (HTAB && h == 0) {
+#pragma unroll
+                            for (int i = 0; i < 12; ++i) hold[eye][i] = v[i];
+                            continue;
+                        }
+                        if (HALF) {
+#pragma unroll
+                            for (int i = 0; i < (HSBS ? 6 : 12); ++i) v[i] >>= 1;      // two blends + 65536 -> mean in byte 2
+                        }
+                        // byte 2 of four sums -> one dword: [a b . .] | [. . c d]
+#define WG_PACK(A_, B_, C_, D_) (__builtin_amdgcn_perm(v[B_], v[A_], 0x0c0c0602u) | __builtin_amdgcn_perm(v[D_], v[C_], 0x06020c0cu))
+                        if (act) {
+                            wg_g8* const oe = eye ? o0 + eye_ofs : o0;
+                            if (HSBS) {
+                                const uint32_t q0 = WG_PACK(0, 1, 2, 3);
+                                const uint16_t q1 = (uint16_t)__builtin_amdgcn_perm(v[5], v[4], 0x0c0c0602u);
+                                wg_g8* dst = oe + wg_v(lane_col >> 1);             // 6 bytes at a 2-byte aligned address
+                                typedef __attribute__((aligned(2))) uint32_t u32_a2;
+                                *(__attribute__((address_space(1))) u32_a2*)dst = q0;
+                                *(__attribute__((address_space(1))) uint16_t*)(dst + 4) = q1;
+                            } else {
+                                wg_u3 w3;
+                                w3[0] = WG_PACK(0, 1, 2, 3); w3[1] = WG_PACK(4, 5, 6, 7); w3[2] = WG_PACK(8, 9, 10, 11);
+#ifdef WG_CUT_STORE          // (timing only: no global stores; one impossible store keeps the values alive)
+                                if (w3[0] == 0x12345678u && w3[1] == 0x9abcdef0u && w3[2] == 0x0fedcba9u)
+#endif
+                                *(wg_g_u3w*)(oe + wg_v(lane_col)) = w3;
+                            }
+                        }
+#undef WG_PACK
+                    }
+                };
+                // (wave-uniform choices: the reflecting form costs 5 more instructions per pixel and eye; taps beyond the halo come from global memory)
+                if (all_small) { if (interior) blend_row(std::true_type(), std::true_type()); else blend_row(std::true_type(), std::false_type()); }
+                else blend_row(std::false_type(), std::false_type());
+            }
+            // the next row's window goes into LDS behind this row's tap reads (one wave's LDS operations execute in order).  Its loads were
+            // issued at the end of step r - 2; younger: step r - 1's depth loads (2), stores and window loads (2), this step's depth loads (2)
+            // and stores.  Then the set takes the row after the other set's.
+            // (first step: the prologue's second window pair, this step's depth loads and stores)
+            if (set == 0) WG_WAIT(6 + ST_PREV + ST_CUR, 4 + ST_CUR, r == 0, pwA0, pwA1); else WG_WAIT(6 + ST_PREV + ST_CUR, 6 + ST_PREV + ST_CUR, 0, pwB0, pwB1);
+            if (has_next) { if (set == 0) { WG_STAGE(pwA0, wl0, dup0) WG_STAGE(pwA1, wl1, dup1) } else { WG_STAGE(pwB0, wl0, dup0) WG_STAGE(pwB1, wl1, dup1) } }
+            {
+                wg_gc8* nrow_p = srow + (long)(r + 3 < nrow ? 3 : nrow - 1 - r) * W3;
+                if (set == 0) WG_WIN_LOAD(pwA0, pwA1, nrow_p) else WG_WIN_LOAD(pwB0, pwB1, nrow_p)
+            }
+            b = nb; y = ny; srow += W3;
+            WG_KEEP_ALL();
+        }
+    };
+    for (int r = 0; r < nrow; r += 2) {
+        row_step(std::integral_constant<int, 0>(), r);
+        if (r + 1 < nrow) row_step(std::integral_constant<int, 1>(), r + 1);
+    }
+    WG_KEEP_ALL();
+#undef WG_KEEP_ALL
+#undef WG_DEPTH_LOAD
+#undef WG_WAIT
+#undef WG_WIN_LOAD
+#undef WG_STAGE
+}
+
 // Half-TAB fast path: thread = 4 source pixels x 2 rows (y, y+1 with even y); H even.
 __global__ void __launch_bounds__(256)
 stereo_warp_fast_halftab(const uint8_t* __restrict__ rgb, const float* __restrict__ depth,
@@ -1150,6 +1525,35 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
                    (W % 4 == 0) && dw <= W && dh <= H && ((uintptr_t)rgb % 4 == 0) && ((uintptr_t)out % 4 == 0) &&
                    ((long)H * W * 3 % 4 == 0);
     if (fast_ok && g.mode == D2S_MODE_HALF_TAB && (H % 2 != 0)) fast_ok = false;
+    // round 6: the gather kernel (no LDS, fixed-point blend) serves every display mode when 4 pixels span less than one depth column
+    // step (3 dw < W: 1080p and up at Depth Resolution 518; 720p frames stay on the kernels below).  D2S_WARP_GATHER=0: off (A/B, tests)
+    static EnvInt gather_env{"D2S_WARP_GATHER", 1};
+    if (fast_ok && gather_env.get() && 3L * dw < W && dw >= 3 && W >= 8 && W < 16384 && (long)batch * dh * dw * 4 < (1L << 32)) {
+        const int ntx = cdiv(W, 256);
+        const long rows = (long)H * batch;
+        static EnvInt wpc_env{"D2S_WARP_WPC", 16};                 // resident waves per CU the grid is cut for
+        long rpw = cdiv(rows * ntx, 256L * wpc_env.get());
+        if (g.mode == D2S_MODE_HALF_TAB) rpw += rpw & 1;           // whole row pairs (H is even)
+        const long waves = cdiv(rows, rpw) * ntx;
+        const dim3 grid((unsigned)cdiv(waves, 4L)), block(256);
+        // register budget: 96 VGPRs (5 waves per SIMD) holds the row loop without spills; at 80 (6 waves) four loop constants are reloaded from
+        // scratch per row, and a scratch reload queues behind the window prefetch in the same in-order vmcnt (D2S_WARP_WPS: A/B)
+        static EnvInt wps_env{"D2S_WARP_WPS", 4};
+        const int wps = wps_env.get();
+#define WG_LAUNCH_W(MODE_, WPS_) hipLaunchKernelGGL((stereo_warp_gather<MODE_, WPS_>), grid, block, 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rpw, ntx)
+#define WG_LAUNCH(MODE_) { if (wps == 5) WG_LAUNCH_W(MODE_, 5); else WG_LAUNCH_W(MODE_, 4); }
+        if (g.mode == D2S_MODE_FULL_SBS && wps == 6) WG_LAUNCH_W(D2S_MODE_FULL_SBS, 6);            // (tuning aid: Full-SBS only)
+        else if (g.mode == D2S_MODE_FULL_SBS && wps == 8) WG_LAUNCH_W(D2S_MODE_FULL_SBS, 8);
+        else
+        if (g.mode == D2S_MODE_FULL_SBS) WG_LAUNCH(D2S_MODE_FULL_SBS)
+        else if (g.mode == D2S_MODE_FULL_TAB) WG_LAUNCH(D2S_MODE_FULL_TAB)
+        else if (g.mode == D2S_MODE_HALF_SBS) WG_LAUNCH(D2S_MODE_HALF_SBS)
+        else WG_LAUNCH(D2S_MODE_HALF_TAB)
+#undef WG_LAUNCH
+#undef WG_LAUNCH_W
+        D2S_CHECK_LAUNCH();
+        return D2S_OK;
+    }
     if (fast_ok) {
         int tiles_x = cdiv(W, FP_TW);
         static const bool no_lanes = getenv("D2S_WARP_LANES") && atoi(getenv("D2S_WARP_LANES")) == 0;     // (A/B switch for tests)

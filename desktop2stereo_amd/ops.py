@@ -237,8 +237,9 @@ def upsample_depth(depth: torch.Tensor, H: int, W: int) -> torch.Tensor:
     return out
 
 
-def make_sbs(frames: torch.Tensor, depth: torch.Tensor, sp: SbsParams, out_fmt: int = FMT_U8_HWC) -> torch.Tensor:
-    """A14 (+A13 fused when depth is at model resolution) (reference depth.py:2122-2184)."""
+def make_sbs(frames: torch.Tensor, depth: torch.Tensor, sp: SbsParams, out_fmt: int = FMT_U8_HWC, out: torch.Tensor = None) -> torch.Tensor:
+    """A14 (+A13 fused when depth is at model resolution) (reference depth.py:2122-2184).  `out`: a caller-allocated result (the
+    C-ABI's own convention), shape [B, oh, ow, 3] / [B, 3, oh, ow] of the format's dtype."""
     _need_cuda(frames, "frames")
     _need_cuda(depth, "depth")
     _same_device(frames, depth, "make_sbs")
@@ -251,7 +252,11 @@ def make_sbs(frames: torch.Tensor, depth: torch.Tensor, sp: SbsParams, out_fmt: 
     dh, dw = d.shape[-2:]
     oh, ow = sbs_shape(H, W, sp)
     batched = frames.dim() == 4
-    if out_fmt == FMT_U8_HWC:
+    if out is not None:
+        want = ((B, 3, oh, ow) if out_fmt == FMT_F32_CHW else (B, oh, ow, 3), torch.uint8 if out_fmt == FMT_U8_HWC else torch.float32)
+        if tuple(out.shape) != want[0] or out.dtype != want[1] or not out.is_contiguous() or out.device != frames.device:
+            raise ValueError(f"make_sbs: out must be a contiguous {want[1]} tensor of shape {want[0]} on {frames.device}")
+    elif out_fmt == FMT_U8_HWC:
         out = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=frames.device)
     elif out_fmt == FMT_F32_HWC:
         out = torch.empty((B, oh, ow, 3), dtype=torch.float32, device=frames.device)
