@@ -945,29 +945,31 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
 // Gather path (round 6; Full-SBS / Full-TAB / Half-SBS / Half-TAB, u8 HWC in and out, W % 4 == 0, 3 dw < W).
 // stereo_warp_lanes above ends at 0.41 of the HBM rate: ~230 VALU instructions per wave-row (fp32 planes in LDS: unpack once, six
 // ds_read_b32 and six float operations per pixel and eye, a transpose through LDS for the stores) behind one block barrier per row,
-// 16 waves per CU.  This kernel has no barrier, no float blend and no shared state between waves (8 waves per SIMD cover each
-// other's round trips, nothing runs in lock step):
+// 16 waves per CU.  This kernel has no barrier, no float blend and no shared state between waves (nothing runs in lock step):
 //   * a lane owns FOUR CONSECUTIVE pixels of a row and both eyes: its results are 12 contiguous bytes per eye (one 12-byte store,
 //     768 contiguous bytes per wave), no transpose;
 //   * a wave stages ITS OWN window of the source row (256 + 2 x 64 pixels) in 2 KiB of LDS as one RGBX dword per pixel -- aligned
-//     12-byte global loads, three instructions to unpack four pixels -- one row ahead through registers; a wave's LDS operations
-//     execute in order, so the window of row r + 1 overwrites row r's behind its reads without any barrier or second buffer;
+//     12-byte global loads, three instructions to unpack four pixels -- TWO rows ahead through two register sets; a wave's LDS
+//     operations execute in order, so the window of row r + 1 overwrites row r's behind its reads without a barrier or a second buffer;
 //   * the two taps of a pixel and eye are ONE ds_read2_b32 (x0, x0 + 1).  Measured (tools/ubench/lds_tap_patterns.hip): with lanes
-//     4 pixels apart that read runs into 4-way bank conflicts (16.5 cycles per wave instruction); one pad dword per 16 pixels (slot
-//     16 of a chunk = a copy of the next chunk's first pixel, so x0 + 1 stays adjacent) makes it conflict-free (7 cycles).  An
+//     4 pixels apart that read runs into 4-way bank conflicts (16.5 cycles per wave instruction); two pad dwords per 32 pixels (the
+//     first = a copy of the next chunk's first pixel, so x0 + 1 stays adjacent) bring it to 7.2 against 6.8 for consecutive lanes.  An
 //     8-byte LDS read at a 4-byte-aligned address (ds_read_b64) takes 65 cycles and an unaligned 8-byte GLOBAL load per tap 29
 //     cycles of the CU's texture path (tools/ubench/unaligned_taps.hip: the first form of this kernel, 323 us at batch 32);
 //   * coordinates are 16.16 fixed point (the reference's own float32 sum x + shift has 2^-13 .. 2^-14 px of resolution at x ~ 1000):
 //     x0 = s >> 16, w1 = s & 0xffff, w0 = 65535 - w1, and a channel is v_dot2_u32_u16([p0, p1], [w0, w1]) + 32768 -> byte 2 of the
 //     result is the rounded value: one v_perm_b32 (bytes -> u16 pair) and one dot per channel instead of two conversions, two
 //     products and a sum.  Weight error <= 2^-16: the blend is within 0.008 of a level of the exact bilinear value, inside the
-//     1-LSB gate like the float kernels' 0.004 (from their float32 coordinate);
-//   * the depth sample (A13 fused) comes from three depth columns per lane (4 pixels span < 1 column step when 3 dw < W) with
-//     per-lane constant weights that already carry -ratio * max_px * 0.05 * 65536: three FMAs give a pixel's fixed-point shift;
-//   * Half modes chain the second blend of a pair into the first through the dot's accumulator (one shift at the end).
+//     1-LSB gate like the float kernels' 0.004 (from their float32 coordinate); 0.2-0.4 % of the bytes differ from theirs, by 1;
+//   * the depth sample (A13 fused) comes from three depth columns per lane (4 pixels span < 1 column step when 3 dw < W), turned into
+//     fixed-point column shifts first; the row's vertical tap is computed by one lane per row and read back with v_readlane;
+//   * Half modes chain the second blend of a pair into the first through the dot's accumulator (one shift at the end);
+//   * everything about a row is wave-uniform and lives in scalar registers (row pointers, depth row offsets, output row pointers).
 // A wave-row whose |shift| reaches the staged halo takes its taps from global memory (8-byte loads, reflection in fixed point, one per
 // side); beyond |shift| >= W - 1, and for the last wave of the buffer's last row (whose 8-byte loads could read 2 bytes past the
 // allocation), the per-pixel float arithmetic of the generic kernel.
+// Batch 32, 1080p Full-SBS: 205 -> 153 us (0.50 of 8 TB/s), 4K 56 -> 33 us (0.56); Half-SBS 213 -> 137, Half-TAB 195 -> 132
+// (profiles/r6_01_warp_gather.md: cut-point builds, counters, what the remaining time is).
 // ------------------------------------------------------------------------------------------------
 typedef unsigned short wg_u16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) uint32_t wg_lds_u32;
@@ -1075,12 +1077,11 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
 
     // per-lane column constants: three depth columns c0 .. c0 + 2; pixel k lerps columns (jk, jk + 1), jk = 0 | 1, by w1[k].  The shift
     // is linear in depth, so the three COLUMNS are turned into fixed-point shifts first (shift_fx = depth * K + ck, K = -ratio * max_px *
-    // 0.05 * 65536, ck = -conv * K) and a pixel costs two selects, a difference and one FMA; the selects' lane masks live in SGPRs.
+    // 0.05 * 65536, ck = -conv * K) and a pixel costs two FMAs on the column differences (weights uk, vk: (w1, 0) or (1, w1)).
     const float K = ((-g.ratio * g.max_px) * 0.05f) * 65536.f;
     const float ck = -g.conv * K;
     uint32_t c0b;                                           // byte offset of column c0 inside a depth row
-    float w1k[4];
-    bool jk[4];
+    float uk[4], vk[4];                                     // shift(k) = scol0 + uk (scol1 - scol0) + vk (scol2 - scol1)
     {
         const Tap t0 = linear_tap(xc, g.dsx, g.dw, false);
         const int c0 = t0.i0 < g.dw - 3 ? t0.i0 : g.dw - 3;
@@ -1089,8 +1090,8 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
         for (int k = 0; k < 4; ++k) {
             const Tap t = linear_tap(xc + k, g.dsx, g.dw, false);
             const int j0 = t.i0 - c0;                       // 0, 1, or 2 = the clamped last column (i1 == i0): columns (1, 2) with weight 1
-            jk[k] = j0 >= 1;
-            w1k[k] = j0 >= 2 ? 1.0f : t.w1;
+            uk[k] = j0 >= 1 ? 1.0f : t.w1;
+            vk[k] = j0 >= 2 ? 1.0f : (j0 == 1 ? t.w1 : 0.f);
         }
     }
     // a wave whose pixels stay more than MG + 2 away from both frame edges never reflects while |shift| < MG - 1
@@ -1111,22 +1112,35 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     // every prefetch depth and occupancy for that reason).  Every load is unconditional (clamped to the wave's last row): the counts below
     // are the same on every path.
     wl_u3 pwA0, pwA1, pwB0, pwB1;
-    wl_u3 dA0, dA1, dB0, dB1;                               // depth columns (rows i0 / i1 of the depth grid) of the current / next row, as bits
-    float dwA0, dwA1, dwB0, dwB1;                           // their vertical weights (scalar registers)
+    wl_u3 dA0, dA1;                                         // depth columns (rows i0 / i1 of the depth grid) of the next row to be computed, as bits:
+    float dwA0, dwA1;                                       // ONE set -- a step turns them into three column shifts, then requests the next row's
+                                                            // (+ their vertical weights, scalar registers)
 #ifdef WG_CUT_LOAD           // (tuning aid, tools/build_variant.sh: timing only -- no window loads from global memory)
 #define WG_WIN_LOAD(P0, P1, ROW_) { P0 = (wl_u3){(uint32_t)(size_t)(ROW_), 0x01020304u, 0x05060708u}; P1 = P0; }
 #else
 #define WG_WIN_LOAD(P0, P1, ROW_) { wg_gload3(P0, gofs0, (ROW_)); wg_gload3(P1, gofs1, (ROW_)); }
 #endif
-#define WG_DEPTH_LOAD(BB, YY, T_, B_, W0_, W1_)                                                    \
+    // The vertical depth tap of a row (ATen's source index: a dozen float operations) is computed once per row by ONE lane: lane l holds
+    // the tap of the band's row 64 q + l (byte offsets of its two depth rows inside the buffer, both weights), refilled every 64 rows; a
+    // row reads its lane's four values back with v_readlane (index in a scalar register).
+    uint32_t tap_o0 = 0, tap_o1 = 0;
+    float tap_w0 = 0.f, tap_w1 = 0.f;
+    auto tap_fill = [&](int fb, int fy) {                   // (fb, fy): frame / row of the band's row 64 q
+        int yl = fy + lane, bl = fb;
+        if (yl >= g.H) { yl -= g.H; ++bl; }                 // (a band is shorter than a frame)
+        if (bl >= B) { bl = B - 1; yl = g.H - 1; }
+        const Tap t = linear_tap(yl, g.dsy, g.dh, false);
+        tap_o0 = (uint32_t)bl * dplane + (uint32_t)t.i0 * drow_b; tap_o1 = (uint32_t)bl * dplane + (uint32_t)t.i1 * drow_b;
+        tap_w0 = t.w0; tap_w1 = t.w1;
+    };
+#define WG_DEPTH_LOAD(RR, T_, B_, W0_, W1_)                                                        \
     {                                                                                             \
-        const Tap ty_ = linear_tap((YY), g.dsy, g.dh, false);                                     \
-        const int i0_ = wg_s(ty_.i0), i1_ = wg_s(ty_.i1);                                         \
-        wg_gc8* dp_ = (wg_gc8*)depth + (unsigned long)((uint32_t)(BB) * dplane);                   \
-        wg_gload3(T_, c0b, dp_ + (uint32_t)i0_ * drow_b); wg_gload3(B_, c0b, dp_ + (uint32_t)i1_ * drow_b); \
-        W0_ = wg_sf(ty_.w0); W1_ = wg_sf(ty_.w1);                                                 \
+        const int l_ = (RR) & 63;                                                                 \
+        const uint32_t o0_ = __builtin_amdgcn_readlane(tap_o0, l_), o1_ = __builtin_amdgcn_readlane(tap_o1, l_);      \
+        wg_gload3(T_, c0b, (wg_gc8*)depth + (unsigned long)o0_); wg_gload3(B_, c0b, (wg_gc8*)depth + (unsigned long)o1_); \
+        W0_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tap_w0), l_));              \
+        W1_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tap_w1), l_));              \
     }
-    // at most N vector-memory operations younger than the awaited loads may stay in flight (vmcnt retires in order)
     // ONE asm statement per wait (two statements merged by a branch made the compiler copy the in-flight registers ahead of the wait):
     // vmcnt(N) always; when FIRST (wave-uniform: the band's first step, with fewer operations behind it) the stricter vmcnt(N0) first
 #ifdef WG_STRICT             // (debugging aid: every wait drains the queue)
@@ -1145,7 +1159,8 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
         if (DUP_) WL_[-2] = PW[0];                                                                \
     }
     WG_WIN_LOAD(pwA0, pwA1, srow)
-    WG_DEPTH_LOAD(b, y, dA0, dA1, dwA0, dwA1)
+    tap_fill(b, y);
+    WG_DEPTH_LOAD(0, dA0, dA1, dwA0, dwA1)
     WG_WAIT(2, 2, 0, pwA0, pwA1);
     WG_STAGE(pwA0, wl0, dup0) WG_STAGE(pwA1, wl1, dup1)                       // row 0 is staged; rows 1 and 2 are requested
     WG_WIN_LOAD(pwA0, pwA1, srow + (1 < nrow ? 1 : 0) * W3)
@@ -1161,7 +1176,7 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     // Every register set is named by an empty asm statement at the end of every step: a set whose load will never be consumed (the
     // clamped loads of a band's last rows) would otherwise be dead to the compiler, which would hand its registers to other values --
     // and the load lands in them later.
-#define WG_KEEP_ALL() asm volatile("" : "+v"(pwA0), "+v"(pwA1), "+v"(pwB0), "+v"(pwB1), "+v"(dA0), "+v"(dA1), "+v"(dB0), "+v"(dB1))
+#define WG_KEEP_ALL() asm volatile("" : "+v"(pwA0), "+v"(pwA1), "+v"(pwB0), "+v"(pwB1), "+v"(dA0), "+v"(dA1))
     // one source row; set_c: which register set holds the NEXT row's window and THIS row's depth columns (A on even steps, B on odd ones).
     // Half-TAB: a wave's band starts on an even row (rpw and H are even), so the step's parity is the row's place in its pair
     auto row_step = [&](auto set_c, const int r) {
@@ -1173,28 +1188,30 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
             if (ny >= g.H) { ny = 0; ++nb; }
             const bool has_next = r + 1 < nrow;
             nb = wg_s(has_next ? nb : b); ny = wg_s(has_next ? ny : y);      // (readfirstlane: the row state stays in scalar registers; the last row repeats itself)
-            // the next row's depth columns into the other set; then this row's have landed: younger than them are the previous step's
-            // stores (ST_PREV) and window loads (2) and the two loads just issued
-            if (set == 0) WG_DEPTH_LOAD(nb, ny, dB0, dB1, dwB0, dwB1) else WG_DEPTH_LOAD(nb, ny, dA0, dA1, dwA0, dwA1)
-            // (first step: the prologue's four window loads and the two loads just issued)
-            if (set == 0) WG_WAIT(4 + ST_PREV, 6, r == 0, dA0, dA1); else WG_WAIT(4 + ST_PREV, 4 + ST_PREV, 0, dB0, dB1);
-            const wl_u3 dt = set == 0 ? dA0 : dB0, db = set == 0 ? dA1 : dB1;
-            const float dw0 = set == 0 ? dwA0 : dwB0, dw1 = set == 0 ? dwA1 : dwB1;
+            // this row's depth columns (requested by the previous step behind its own use of the registers) have landed: younger than them
+            // are the previous step's stores (ST_PREV) and window loads (2); first step: the prologue's four window loads
+            WG_WAIT(2 + ST_PREV, 4, set == 0 && r == 0, dA0, dA1);
+            const wl_u3 dt = dA0, db = dA1;
+            const float dw0 = dwA0, dw1 = dwA1;
             if (HTAB && h == 0) pair_slow = false;
             // ---- fixed-point shifts: the three columns first, then this lane's 4 pixels
             float scol[3];
             scol[0] = fmaf(fmaf(dw1, __uint_as_float(db[0]), dw0 * __uint_as_float(dt[0])), K, ck);
             scol[1] = fmaf(fmaf(dw1, __uint_as_float(db[1]), dw0 * __uint_as_float(dt[1])), K, ck);
             scol[2] = fmaf(fmaf(dw1, __uint_as_float(db[2]), dw0 * __uint_as_float(dt[2])), K, ck);
+            asm volatile("" : "+v"(scol[0]), "+v"(scol[1]), "+v"(scol[2]), "+v"(dA0), "+v"(dA1));      // (the columns are formed before the registers are reloaded)
+            {
+                const int rn = has_next ? r + 1 : r;
+                if ((rn & 63) == 0 && has_next) tap_fill(nb, ny);   // (wave-uniform, every 64 rows)
+                WG_DEPTH_LOAD(rn, dA0, dA1, dwA0, dwA1)
+            }
             // (a pixel's shift is a convex combination of two columns: bounds on the columns bound it)
             const float amax = fmaxf(fmaxf(fabsf(scol[0]), fabsf(scol[1])), fabsf(scol[2]));
             const bool all_small = __all(amax < small_lim);
             int shq[4];
+            const float d01 = scol[1] - scol[0], d12 = scol[2] - scol[1];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float a = jk[k] ? scol[1] : scol[0], bq = jk[k] ? scol[2] : scol[1];
-                shq[k] = (int)fmaf(w1k[k], bq - a, a);
-            }
+            for (int k = 0; k < 4; ++k) shq[k] = (int)fmaf(vk[k], d12, fmaf(uk[k], d01, scol[0]));
             bool slow = false;
             if (!all_small) slow = ((R0 + r == rows - 1) && tx == ntx - 1) || !__all(amax < (float)span_fx);
             if (HTAB) { pair_slow = pair_slow || slow; slow = pair_slow; }
@@ -1531,26 +1548,20 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
     if (fast_ok && gather_env.get() && 3L * dw < W && dw >= 3 && W >= 8 && W < 16384 && (long)batch * dh * dw * 4 < (1L << 32)) {
         const int ntx = cdiv(W, 256);
         const long rows = (long)H * batch;
-        static EnvInt wpc_env{"D2S_WARP_WPC", 16};                 // resident waves per CU the grid is cut for
+        static EnvInt wpc_env{"D2S_WARP_WPC", 32};                 // resident waves per CU the grid is cut for
         long rpw = cdiv(rows * ntx, 256L * wpc_env.get());
         if (g.mode == D2S_MODE_HALF_TAB) rpw += rpw & 1;           // whole row pairs (H is even)
         const long waves = cdiv(rows, rpw) * ntx;
         const dim3 grid((unsigned)cdiv(waves, 4L)), block(256);
-        // register budget: 96 VGPRs (5 waves per SIMD) holds the row loop without spills; at 80 (6 waves) four loop constants are reloaded from
-        // scratch per row, and a scratch reload queues behind the window prefetch in the same in-order vmcnt (D2S_WARP_WPS: A/B)
-        static EnvInt wps_env{"D2S_WARP_WPS", 4};
-        const int wps = wps_env.get();
-#define WG_LAUNCH_W(MODE_, WPS_) hipLaunchKernelGGL((stereo_warp_gather<MODE_, WPS_>), grid, block, 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rpw, ntx)
-#define WG_LAUNCH(MODE_) { if (wps == 5) WG_LAUNCH_W(MODE_, 5); else WG_LAUNCH_W(MODE_, 4); }
-        if (g.mode == D2S_MODE_FULL_SBS && wps == 6) WG_LAUNCH_W(D2S_MODE_FULL_SBS, 6);            // (tuning aid: Full-SBS only)
-        else if (g.mode == D2S_MODE_FULL_SBS && wps == 8) WG_LAUNCH_W(D2S_MODE_FULL_SBS, 8);
-        else
+        // register budget: 128 VGPRs (4 waves per SIMD): two window sets in flight + the row loop without a spill.  At 96 (5 waves) the Full-TAB /
+        // Half modes reload loop constants from scratch every row -- a scratch reload queues behind the window prefetch in the same in-order
+        // vmcnt -- and Full-SBS gains nothing (155-159 us against 153-158; profiles/r6_01_warp_gather.md)
+#define WG_LAUNCH(MODE_) hipLaunchKernelGGL((stereo_warp_gather<MODE_, 4>), grid, block, 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rpw, ntx);
         if (g.mode == D2S_MODE_FULL_SBS) WG_LAUNCH(D2S_MODE_FULL_SBS)
         else if (g.mode == D2S_MODE_FULL_TAB) WG_LAUNCH(D2S_MODE_FULL_TAB)
         else if (g.mode == D2S_MODE_HALF_SBS) WG_LAUNCH(D2S_MODE_HALF_SBS)
         else WG_LAUNCH(D2S_MODE_HALF_TAB)
 #undef WG_LAUNCH
-#undef WG_LAUNCH_W
         D2S_CHECK_LAUNCH();
         return D2S_OK;
     }
