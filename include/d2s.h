@@ -131,8 +131,11 @@ typedef struct d2s_dibr_params {
     float   search_radius;     /* u_search_radius = 12 */
     float   depth_tolerance;   /* u_depth_tolerance = 0.012 */
     float   blur_radius;       /* u_blur_radius = 2.5 */
-    float   res_w, res_h;      /* u_resolution; the reference never assigns it (pixel_size = 1/0, viewer.py:413):
-                                  0 -> the source frame size, i.e. pixel_size = one texel */
+    float   res_w, res_h;      /* u_resolution; the reference never assigns it (pixel_size = 1/0 = +inf, viewer.py:395, 413): every
+                                  tap at uv +- k * pixel_size then has a non-finite coordinate, which OpenGL leaves undefined
+                                  (tests/golden/dibr.npz `as_shipped_*`: what SwiftShader renders for that state -- 6-17 % of the
+                                  pixels more than one level from the intended image; recorded, not a target).
+                                  0 here -> the source frame size, i.e. pixel_size = one texel: the shader's evident intent */
     int32_t display_mode;      /* D2S_MODE_*: how the two eye viewports are packed */
     int32_t feather_enabled;   /* u_feather_enabled */
     float   feather_width;     /* u_feather_width = 0.02 (viewer.py:1343) */

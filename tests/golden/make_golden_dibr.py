@@ -8,7 +8,8 @@ Each case renders both eyes exactly as the viewer does (viewer.py:2686-2720: one
 u_depth_strength = viewer.depth_strength (0.1) * depth_ratio, the full-screen TRIANGLE_STRIP quad, blending off) into an RGBA32F
 target and stores frag_color un-multiplied: rgb * 255 * 256 as uint16 fixed point, alpha * 65535 as uint16 (every `row_stride`-th
 row).  Inputs are regenerated from seeds (desktop2stereo_amd.synth + the `scene` recipe below); nothing of the shader text is kept.
-The one uniform the reference never assigns, u_resolution (pixel_size = 1 / 0, viewer.py:413), is set to the source size.
+The one uniform the reference never assigns, u_resolution (pixel_size = 1 / 0, viewer.py:413), is set to the source size -- except in the
+two `as_shipped_*` cases, which leave it at (0, 0) and record what the rasteriser makes of the non-finite tap coordinates.
 """
 from __future__ import annotations
 
@@ -40,6 +41,15 @@ CASES = [
     ("small_smooth", 72, 128, 8, "smooth", 1, None, dict(ipd_uv=0.064, depth_ratio=1.0, convergence=0.0)),
     ("hd_boxes", 1080, 1920, 9, "boxes", 45, None, dict(ipd_uv=0.064, depth_ratio=4.0, convergence=0.0)),
     ("hd_half_tab", 1080, 1920, 10, "boxes", 45, (1920, 540), dict(ipd_uv=0.064, depth_ratio=2.0, convergence=0.2)),
+    # round 6: a Half-mode viewport with roll, and BASELINE configs[2]'s frame size
+    ("small_half_roll", 90, 160, 11, "boxes", 1, (80, 90), dict(ipd_uv=0.064, depth_ratio=4.0, convergence=0.05, roll=-0.15)),
+    ("uhd_boxes", 2160, 3840, 12, "boxes", 120, None, dict(ipd_uv=0.064, depth_ratio=4.0, convergence=0.0)),
+    # The reference AS SHIPPED: u_resolution is declared (viewer.py:395) and never assigned, so pixel_size = 1.0 / vec2(0) (viewer.py:413)
+    # = +inf and every tap at uv +- k * pixel_size has a non-finite coordinate, whose sampling OpenGL leaves undefined.  These two cases
+    # record what THIS rasteriser (SwiftShader) returns for that uniform state; they do not pin the kernel (d2s_dibr_params.res_w = 0
+    # means "the source size": the shader's evident intent, include/d2s.h) -- tests print the distance, they do not gate on it.
+    ("as_shipped_boxes", 90, 160, 3, "boxes", 1, None, dict(ipd_uv=0.064, depth_ratio=4.0, convergence=0.0, as_shipped=True)),
+    ("as_shipped_smooth", 72, 128, 8, "smooth", 1, None, dict(ipd_uv=0.064, depth_ratio=1.0, convergence=0.0, as_shipped=True)),
 ]
 
 
@@ -59,7 +69,7 @@ def main():
         tc, td = gl.texture(img, 0), gl.texture(dep, 1)
         ow, oh = vp or (w, h)
         for eye, sign in (("left", -1.0), ("right", 1.0)):
-            uni = dict(tex_color=0, tex_depth=1, u_resolution=(float(w), float(h)), u_eye_offset=float(sign * u["ipd_uv"] / 2.0),
+            uni = dict(tex_color=0, tex_depth=1, u_resolution=(0.0, 0.0) if u.get("as_shipped") else (float(w), float(h)), u_eye_offset=float(sign * u["ipd_uv"] / 2.0),
                        u_depth_strength=float(0.1 * u["depth_ratio"]), u_convergence=float(u["convergence"]), u_roll=float(u.get("roll", 0.0)),
                        u_feather_enabled=int(bool(u.get("feather", False))), u_feather_width=float(u.get("feather_width", 0.02)),
                        u_viewport=(0.0, 0.0, float(ow), float(oh)), **{k: float(v) for k, v in defaults.items()})

@@ -144,7 +144,9 @@ def test_dibr_matches_reference_shader_renders(dev, golden_dir):
             d = np.abs(g[..., :3] - rgb)
             da = np.abs(g[..., 3] - a)
             print(f"[dibr vs the reference shader's render, {c['name']} {eye}] rgb max {d.max():.3f} mean {d.mean():.4f} "
-                  f"{(d > 1).mean():.2e} of values > 1 level | alpha max diff {da.max():.1e} (min alpha {a.min():.3f})")
+                  f"{(d > 1).mean():.2e} of values > 1 level ({int((d > 1).sum())} of {d.size}) | alpha max diff {da.max():.1e} (min alpha {a.min():.3f})")
+            if c.get("as_shipped"):          # u_resolution left at (0, 0) as the reference ships it: undefined sampling, recorded not gated
+                continue
             assert da.max() <= 1e-3, (c["name"], eye, float(da.max()))
             if c["w"] <= 320:
                 assert d.max() <= 1.0, (c["name"], eye, float(d.max()))

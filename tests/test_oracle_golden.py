@@ -263,7 +263,7 @@ def test_dibr_oracle_matches_reference_shader_renders(golden_dir):
     tests/golden/dibr.npz, produced by compiling the shader text as OpenGL ES 3.0 and running it off-screen on SwiftShader in the
     build container (tests/golden/gl_harness.py, make_golden_dibr.py).  frag_color.rgb and frag_color.a separately, both eyes:
     hard depth edges, convergence, roll, feathering + rounded corners, a Half-SBS viewport, a smooth scene (small cases, every
-    pixel), 1080p Full and Half-TAB viewports (every 45th row).  Tolerance: GL_LINEAR filters RGB8 with 8-bit sub-texel weights
+    pixel), a Half-SBS viewport with roll, 1080p Full and Half-TAB viewports (every 45th row), a 3840x2160 frame (every 120th row).  Tolerance: GL_LINEAR filters RGB8 with 8-bit sub-texel weights
     (<= 255/512 of a level per lerp axis) where the restatement filters in float32 -> <= 1 level on the small cases (measured max
     0.48); at 1920 columns the shader's hard thresholds flip isolated pixels on a 1-ulp coordinate difference -> >= 99.9 % within
     1 level (measured 3e-4..6e-4 beyond), mean <= 0.06; alpha within 1e-3 everywhere (measured 1e-4; min alpha 0.69 at the 1080p
@@ -284,6 +284,13 @@ def test_dibr_oracle_matches_reference_shader_renders(golden_dir):
             rgb = z[f"{c['name']}_{eye}_rgb"].astype(np.float32) / 256.0
             a = z[f"{c['name']}_{eye}_a"].astype(np.float32) / 65535.0
             d = np.abs(o[..., :3] - rgb)
+            if c.get("as_shipped"):
+                # the reference's as-shipped uniform state (u_resolution never assigned: pixel_size = 1 / 0, taps at non-finite
+                # coordinates, undefined in GL): what SwiftShader rendered is RECORDED, the restatement (pixel_size = one texel, the
+                # shader's intent and d2s_dibr_params.res_w = 0) is not held to it -- the distance is printed
+                print(f"[dibr restatement vs the as-shipped render (u_resolution = 0), {c['name']} {eye}] rgb max {d.max():.1f} mean {d.mean():.3f}, "
+                      f"{(d.max(-1) > 1).mean():.3f} of the pixels beyond 1 level")
+                continue
             assert np.abs(o[..., 3] - a).max() <= 1e-3, (c["name"], eye)
             saw_alpha |= bool(a.min() < 0.9)
             if c["w"] <= 320:
