@@ -199,7 +199,7 @@ temporal_attn_ring_kernel(const T* __restrict__ cur, T* __restrict__ ring, const
         const int j = kg * TA_KPG + t, jj = min(j, Tw - 1);
         int slot = head + jj; if (slot >= slots) slot -= slots;    // (head < slots, jj < 32 <= slots + 1: one conditional subtract, no modulo)
         if (slot >= slots) slot -= slots;
-        krow[t] = jj < Tw - 1 ? ring + (slot * slot_stride + base_s) : cur_row + c;
+        krow[t] = (act && jj < Tw - 1) ? ring + (slot * slot_stride + base_s) : cur_row + c;   // (padding / dead lanes never touch the ring: see the store below)
         jpos[t] = jj;
     }
     RawSeg<T, CH> rk[TA_KPG], rv[TA_KPG];
@@ -253,8 +253,10 @@ temporal_attn_ring_kernel(const T* __restrict__ cur, T* __restrict__ ring, const
         for (int i = 0; i < CH; ++i) out[(long)s * C + c + i] = tcvt<T>(acc[i]);
     }
     // round 5: the frame's k' | v' rows join the window HERE (cache_store_kernel's launch is gone for every frame but the first).  The
-    // oldest slot's segment [c, c + CH) of site s is READ by the key group that owns window position 0 -- kg 0 -- and by nobody else, so kg
-    // 0's lane overwrites it once its own two loads of it are behind it: program order within one thread is all the ordering needed.
+    // oldest slot's segment [c, c + CH) of site s is READ by the key group that owns window position 0 -- kg 0's ACTIVE lane -- and by nobody
+    // else (the padding lanes of a head, li * CH >= head_dim, and the lanes of dead units read the current frame's row instead of the ring:
+    // their q is 0 and they store nothing, but they used to load this segment too -- an unordered read beside the store), so
+    // that lane overwrites it once its own two loads of it are behind it: program order within one thread is all the ordering needed.
     if (act && kg == 0 && store_slot >= 0) {
         T* dst = ring + ((long)store_slot * slot_stride + base_s);
 #pragma unroll

@@ -965,6 +965,38 @@ def test_pipeline_end_to_end(dev):
     eng.close()
 
 
+def test_post_process_one_launch_equals_separate_kernels(dev, monkeypatch):
+    """post_fused_kernel (D2S_POST_ONE=1: bounds + shape + both blur passes in one launch, d2s_post_process_to with <= 2
+    frames) against the separate kernels (D2S_POST_ONE=0) and against the in-place entry point: bit-identical, for the default
+    parameters, a non-default blur radius (the generic tap-count instantiation), a saturated map (ties at both extremes: the
+    value-linear select's edge bins) and a constant map."""
+    from desktop2stereo_amd import ops, synth
+    from desktop2stereo_amd.config import PipelineParams
+    import dataclasses
+    rng = np.random.default_rng(11)
+    maps = {"smooth": np.stack([synth.smooth_depth(294, 518, 3), synth.smooth_depth(294, 518, 4)]),
+            "noise": rng.uniform(0.0, 20.0, (2, 294, 518)).astype(np.float32),
+            "saturated": np.clip(rng.normal(0.5, 1.0, (2, 294, 518)), 0.0, 1.0).astype(np.float32),
+            "constant": np.full((1, 196, 336), 0.25, np.float32),
+            "odd": rng.uniform(0.0, 1.0, (1, 101, 203)).astype(np.float32)}
+    try:
+        for pname, p in (("default", PipelineParams()), ("aa2", dataclasses.replace(PipelineParams(), aa_strength=2.0)),
+                         ("no_fg", dataclasses.replace(PipelineParams(), foreground_scale=0.0))):
+            for mname, m in maps.items():
+                d = _t(m, dev)
+                outs = {}
+                for one in ("1", "0"):
+                    monkeypatch.setenv("D2S_POST_ONE", one)
+                    ops.reload_env()
+                    outs[one] = ops.post_process_depth_to(d, p).cpu().numpy()
+                inplace = ops.post_process_depth(d, p).cpu().numpy()
+                assert np.array_equal(outs["1"], outs["0"]), (pname, mname, float(np.abs(outs["1"] - outs["0"]).max()))
+                assert np.array_equal(outs["1"], inplace), (pname, mname, "in place")
+    finally:
+        monkeypatch.delenv("D2S_POST_ONE", raising=False)
+        ops.reload_env()
+
+
 def test_pipeline_fused_launches_equal_separate(dev, monkeypatch):
     """d2s_pipeline folds launches where an equivalent one-launch form exists: pre-process + patchify (D2S_NO_PREPATCH=1 separates
     them), normalise / gamma + both blur passes at batch 1-2 (D2S_POST_FUSE_MAXB=0).  Same arithmetic, same order: bit-identical
