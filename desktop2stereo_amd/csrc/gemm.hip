@@ -662,6 +662,8 @@ static void launch_glds(const GemmA& a, const void* W, int M, int N, int K, int 
         ks = nkt / sk_div; if (ks > 16) ks = 16;
         while (ks > 1 && (size_t)ks * M * N > e.part_elems) --ks;
     }
+    static EnvInt sk_force{"D2S_SPLITK_FORCE", 0};          // measurement aid (tools/splitk_probe.py): this many K ranges whatever the grid
+    if (sk_force.get() > 1 && STG != 2 && e.part && !e.stats_out && nkt >= sk_force.get() && (size_t)sk_force.get() * M * N <= e.part_elems) ks = sk_force.get();
     if (ks > 1) {
         GemmEpi e2 = e; e2.ksplit = ks;
         hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, CPR, STG>), dim3(grid, ks), dim3(64 * WM * WN), 0, st, (const T*)W, a.ptr, a.lda, M, N, K, Kpad, xn, a, e2);
@@ -952,10 +954,17 @@ extern "C" int d2s_gemm_probe(const float* A, const float* Wt, const float* bias
     a.ptr = dA; a.mode = A_PLAIN; a.lda = Kp;
     GemmEpi e = {};
     e.out = Cout; e.out_type = OUT_F32; e.ldc = N; e.bias = bias;
+    void* dP = nullptr;
+    static EnvInt sk_force{"D2S_SPLITK_FORCE", 0};          // measurement aid: give the launch a split-K workspace
+    if (sk_force.get() > 1) {
+        const size_t pe = (size_t)sk_force.get() * M * N;
+        D2S_HIP(hipMalloc(&dP, pe * sizeof(float) + GEMM_PART_CTR_WORDS * 4));
+        e.part = (float*)dP; e.part_elems = pe;
+    }
     int rc = D2S_OK;
     for (int i = 0; i < iters && rc == D2S_OK; ++i) rc = launch_gemm(precision, tile, a, dW, M, N, Kp, Kp, e, st);
     hipError_t err = hipStreamSynchronize(st);
-    (void)hipFree(dA); (void)hipFree(dW);
+    (void)hipFree(dA); (void)hipFree(dW); if (dP) (void)hipFree(dP);
     if (rc != D2S_OK) return rc;
     D2S_HIP(err);
     return D2S_OK;
