@@ -990,6 +990,14 @@ __device__ __forceinline__ uint32_t wg_v(uint32_t v) { asm volatile("" : "+v"(v)
 __device__ __forceinline__ void wg_gload3(wl_u3& d, uint32_t off, wg_gc8* base) {
     asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(d) : "v"(off), "s"(base) : "memory");
 }
+typedef uint32_t wg_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wg_gload(wl_u3& d, uint32_t off, wg_gc8* base) { wg_gload3(d, off, base); }
+__device__ __forceinline__ void wg_gload(wg_u4& d, uint32_t off, wg_gc8* base) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(off), "s"(base) : "memory");
+}
+template <int N> struct wg_vec;
+template <> struct wg_vec<3> { typedef wl_u3 type; };
+template <> struct wg_vec<4> { typedef wg_u4 type; };
 // a wave-uniform value pinned to a scalar register
 __device__ __forceinline__ int wg_s(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float wg_sf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -1041,12 +1049,16 @@ __device__ __forceinline__ void wg_slow_row(const uint8_t* __restrict__ rgb, con
     }
 }
 
-template <int MODE, int WPS /* resident waves per SIMD the register budget is cut for */>
-__global__ void __launch_bounds__(256, WPS)
+// NC: depth columns a lane's 4 pixels can touch -- 3 when 3 dw < W (model-resolution depth under a 1080p+ frame), 4 when 3 dw < 2 W
+// (720p frames) and for DIRECT; DIRECT: the depth map has the frame's size (the drop-in make_sbs(rgb, depth[H, W]) surface: A13 already
+// applied by predict_depth) -- pixel k reads column k of ONE depth row, no interpolation in either direction.
+template <int MODE, int NC, bool DIRECT>
+__global__ void __launch_bounds__(256, 4)
 stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
                    int B, WarpGeom g, int rpw /* source rows per wave (even for Half-TAB) */, int ntx /* 256-pixel column tiles */) {
     constexpr bool HSBS = MODE == D2S_MODE_HALF_SBS, HTAB = MODE == D2S_MODE_HALF_TAB, HALF = HSBS || HTAB;
     constexpr int NR = HTAB ? 2 : 1;                          // source rows per output row
+    constexpr int DL = DIRECT ? 1 : 2;                        // depth loads per step
     __shared__ __attribute__((aligned(WG_WIN_BYTES))) uint32_t win[4][WG_WIN_BYTES / 4];
     const int lane = threadIdx.x & 63, wid = wg_s((int)(threadIdx.x >> 6));
     const int gw = wg_s((int)(blockIdx.x * 4)) + wid;
@@ -1075,23 +1087,23 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     wg_lds_u32* const wl1 = (wg_lds_u32*)(wbase + 4u * (uint32_t)(4 * g1 + 2 * (g1 >> 3)));
     const bool dup0 = (g0 & 7) == 0 && g0 > 0, dup1 = (g1 & 7) == 0;       // first pixel of a 32-pixel chunk: also the first pad slot of the chunk before
 
-    // per-lane column constants: three depth columns c0 .. c0 + 2; pixel k lerps columns (jk, jk + 1), jk = 0 | 1, by w1[k].  The shift
-    // is linear in depth, so the three COLUMNS are turned into fixed-point shifts first (shift_fx = depth * K + ck, K = -ratio * max_px *
-    // 0.05 * 65536, ck = -conv * K) and a pixel costs two FMAs on the column differences (weights uk, vk: (w1, 0) or (1, w1)).
+    // per-lane column constants: NC depth columns c0 .. c0 + NC - 1; pixel k lerps a pair of them by w1[k].  The shift
+    // is linear in depth, so the COLUMNS are turned into fixed-point shifts first (shift_fx = depth * K + ck, K = -ratio * max_px *
+    // 0.05 * 65536, ck = -conv * K) and a pixel costs NC - 1 FMAs on the column differences (weights 1 below its pair, w1 on it, 0 above).
     const float K = ((-g.ratio * g.max_px) * 0.05f) * 65536.f;
     const float ck = -g.conv * K;
     uint32_t c0b;                                           // byte offset of column c0 inside a depth row
-    float uk[4], vk[4];                                     // shift(k) = scol0 + uk (scol1 - scol0) + vk (scol2 - scol1)
+    float wkj[4][NC - 1];                                   // shift(k) = scol[0] + sum_j wkj[k][j] (scol[j + 1] - scol[j])
     {
         const Tap t0 = linear_tap(xc, g.dsx, g.dw, false);
-        const int c0 = t0.i0 < g.dw - 3 ? t0.i0 : g.dw - 3;
+        const int c0 = t0.i0 < g.dw - NC ? t0.i0 : g.dw - NC;
         c0b = 4u * (uint32_t)c0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const Tap t = linear_tap(xc + k, g.dsx, g.dw, false);
-            const int j0 = t.i0 - c0;                       // 0, 1, or 2 = the clamped last column (i1 == i0): columns (1, 2) with weight 1
-            uk[k] = j0 >= 1 ? 1.0f : t.w1;
-            vk[k] = j0 >= 2 ? 1.0f : (j0 == 1 ? t.w1 : 0.f);
+            const int j0 = t.i0 - c0;                       // first column of the pixel's pair (the clamped last column has no second one)
+#pragma unroll
+            for (int j = 0; j < NC - 1; ++j) wkj[k][j] = j < j0 ? 1.0f : (j == j0 ? t.w1 : 0.f);
         }
     }
     // a wave whose pixels stay more than MG + 2 away from both frame edges never reflects while |shift| < MG - 1
@@ -1112,7 +1124,7 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     // every prefetch depth and occupancy for that reason).  Every load is unconditional (clamped to the wave's last row): the counts below
     // are the same on every path.
     wl_u3 pwA0, pwA1, pwB0, pwB1;
-    wl_u3 dA0, dA1;                                         // depth columns (rows i0 / i1 of the depth grid) of the next row to be computed, as bits:
+    typename wg_vec<NC>::type dA0, dA1;                     // depth columns (rows i0 / i1 of the depth grid) of the next row to be computed, as bits:
     float dwA0, dwA1;                                       // ONE set -- a step turns them into three column shifts, then requests the next row's
                                                             // (+ their vertical weights, scalar registers)
 #ifdef WG_CUT_LOAD           // (tuning aid, tools/build_variant.sh: timing only -- no window loads from global memory)
@@ -1137,7 +1149,8 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     {                                                                                             \
         const int l_ = (RR) & 63;                                                                 \
         const uint32_t o0_ = __builtin_amdgcn_readlane(tap_o0, l_), o1_ = __builtin_amdgcn_readlane(tap_o1, l_);      \
-        wg_gload3(T_, c0b, (wg_gc8*)depth + (unsigned long)o0_); wg_gload3(B_, c0b, (wg_gc8*)depth + (unsigned long)o1_); \
+        wg_gload(T_, c0b, (wg_gc8*)depth + (unsigned long)o0_);                                   \
+        if (!DIRECT) wg_gload(B_, c0b, (wg_gc8*)depth + (unsigned long)o1_);                      \
         W0_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tap_w0), l_));              \
         W1_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tap_w1), l_));              \
     }
@@ -1145,7 +1158,11 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     // vmcnt(N) always; when FIRST (wave-uniform: the band's first step, with fewer operations behind it) the stricter vmcnt(N0) first
 #ifdef WG_STRICT             // (debugging aid: every wait drains the queue)
 #define WG_WAIT(N, N0, FIRST, R0_, R1_) asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0_), "+v"(R1_) : "n"(N), "n"(N0), "s"(wg_s((int)(FIRST))) : "memory")
+#define WG_WAIT1(N, N0, FIRST, R0_) asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0_) : "n"(N), "n"(N0), "s"(wg_s((int)(FIRST))) : "memory")
 #else
+#define WG_WAIT1(N, N0, FIRST, R0_)                                                                \
+    asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(%2)\n1:\n\ts_waitcnt vmcnt(%1)"   \
+                 : "+v"(R0_) : "n"(N), "n"((N0) < (N) ? (N0) : (N)), "s"(wg_s((int)(FIRST))) : "memory", "scc")
 #define WG_WAIT(N, N0, FIRST, R0_, R1_)                                                            \
     asm volatile("s_cmp_eq_u32 %4, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(%3)\n1:\n\ts_waitcnt vmcnt(%2)"   \
                  : "+v"(R0_), "+v"(R1_) : "n"(N), "n"((N0) < (N) ? (N0) : (N)), "s"(wg_s((int)(FIRST))) : "memory", "scc")
@@ -1161,7 +1178,7 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     WG_WIN_LOAD(pwA0, pwA1, srow)
     tap_fill(b, y);
     WG_DEPTH_LOAD(0, dA0, dA1, dwA0, dwA1)
-    WG_WAIT(2, 2, 0, pwA0, pwA1);
+    WG_WAIT(DL, DL, 0, pwA0, pwA1);
     WG_STAGE(pwA0, wl0, dup0) WG_STAGE(pwA1, wl1, dup1)                       // row 0 is staged; rows 1 and 2 are requested
     WG_WIN_LOAD(pwA0, pwA1, srow + (1 < nrow ? 1 : 0) * W3)
     WG_WIN_LOAD(pwB0, pwB1, srow + (2 < nrow ? 2 : nrow - 1) * W3)
@@ -1176,7 +1193,7 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     // Every register set is named by an empty asm statement at the end of every step: a set whose load will never be consumed (the
     // clamped loads of a band's last rows) would otherwise be dead to the compiler, which would hand its registers to other values --
     // and the load lands in them later.
-#define WG_KEEP_ALL() asm volatile("" : "+v"(pwA0), "+v"(pwA1), "+v"(pwB0), "+v"(pwB1), "+v"(dA0), "+v"(dA1))
+#define WG_KEEP_ALL() { asm volatile("" : "+v"(pwA0), "+v"(pwA1), "+v"(pwB0), "+v"(pwB1), "+v"(dA0)); if (!DIRECT) asm volatile("" : "+v"(dA1)); }
     // one source row; set_c: which register set holds the NEXT row's window and THIS row's depth columns (A on even steps, B on odd ones).
     // Half-TAB: a wave's band starts on an even row (rpw and H are even), so the step's parity is the row's place in its pair
     auto row_step = [&](auto set_c, const int r) {
@@ -1190,28 +1207,39 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
             nb = wg_s(has_next ? nb : b); ny = wg_s(has_next ? ny : y);      // (readfirstlane: the row state stays in scalar registers; the last row repeats itself)
             // this row's depth columns (requested by the previous step behind its own use of the registers) have landed: younger than them
             // are the previous step's stores (ST_PREV) and window loads (2); first step: the prologue's four window loads
-            WG_WAIT(2 + ST_PREV, 4, set == 0 && r == 0, dA0, dA1);
-            const wl_u3 dt = dA0, db = dA1;
-            const float dw0 = dwA0, dw1 = dwA1;
+            // (DIRECT has one depth register set: it must not be named twice in one asm statement -- two tied operands on one variable
+            //  make the compiler copy the in-flight registers in front of the wait)
+            if (DIRECT) WG_WAIT1(2 + ST_PREV, 4, set == 0 && r == 0, dA0); else WG_WAIT(2 + ST_PREV, 4, set == 0 && r == 0, dA0, dA1);
             if (HTAB && h == 0) pair_slow = false;
-            // ---- fixed-point shifts: the three columns first, then this lane's 4 pixels
-            float scol[3];
-            scol[0] = fmaf(fmaf(dw1, __uint_as_float(db[0]), dw0 * __uint_as_float(dt[0])), K, ck);
-            scol[1] = fmaf(fmaf(dw1, __uint_as_float(db[1]), dw0 * __uint_as_float(dt[1])), K, ck);
-            scol[2] = fmaf(fmaf(dw1, __uint_as_float(db[2]), dw0 * __uint_as_float(dt[2])), K, ck);
-            asm volatile("" : "+v"(scol[0]), "+v"(scol[1]), "+v"(scol[2]), "+v"(dA0), "+v"(dA1));      // (the columns are formed before the registers are reloaded)
+            // ---- fixed-point shifts: the columns first, then this lane's 4 pixels
+            float scol[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+                scol[j] = DIRECT ? fmaf(__uint_as_float(dA0[j]), K, ck) : fmaf(fmaf(dwA1, __uint_as_float(dA1[j]), dwA0 * __uint_as_float(dA0[j])), K, ck);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) asm volatile("" : "+v"(scol[j]));       // (the columns are formed before the registers are reloaded)
+            WG_KEEP_ALL()
             {
                 const int rn = has_next ? r + 1 : r;
                 if ((rn & 63) == 0 && has_next) tap_fill(nb, ny);   // (wave-uniform, every 64 rows)
                 WG_DEPTH_LOAD(rn, dA0, dA1, dwA0, dwA1)
             }
             // (a pixel's shift is a convex combination of two columns: bounds on the columns bound it)
-            const float amax = fmaxf(fmaxf(fabsf(scol[0]), fabsf(scol[1])), fabsf(scol[2]));
+            float amax = fabsf(scol[0]);
+#pragma unroll
+            for (int j = 1; j < NC; ++j) amax = fmaxf(amax, fabsf(scol[j]));
             const bool all_small = __all(amax < small_lim);
             int shq[4];
-            const float d01 = scol[1] - scol[0], d12 = scol[2] - scol[1];
+            float dj[NC - 1];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) shq[k] = (int)fmaf(vk[k], d12, fmaf(uk[k], d01, scol[0]));
+            for (int j = 0; j < NC - 1; ++j) dj[j] = scol[j + 1] - scol[j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float sh = scol[0];
+#pragma unroll
+                for (int j = 0; j < NC - 1; ++j) sh = fmaf(wkj[k][j], dj[j], sh);
+                shq[k] = (int)sh;
+            }
             bool slow = false;
             if (!all_small) slow = ((R0 + r == rows - 1) && tx == ntx - 1) || !__all(amax < (float)span_fx);
             if (HTAB) { pair_slow = pair_slow || slow; slow = pair_slow; }
@@ -1308,9 +1336,9 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
             }
             // the next row's window goes into LDS behind this row's tap reads (one wave's LDS operations execute in order).  Its loads were
             // issued at the end of step r - 2; younger: step r - 1's depth loads (2), stores and window loads (2), this step's depth loads (2)
-            // and stores.  Then the set takes the row after the other set's.
+            // and stores (DL = depth loads per step: 1 when the depth map has the frame's size).  Then the set takes the row after the other set's.
             // (first step: the prologue's second window pair, this step's depth loads and stores)
-            if (set == 0) WG_WAIT(6 + ST_PREV + ST_CUR, 4 + ST_CUR, r == 0, pwA0, pwA1); else WG_WAIT(6 + ST_PREV + ST_CUR, 6 + ST_PREV + ST_CUR, 0, pwB0, pwB1);
+            if (set == 0) WG_WAIT(2 + 2 * DL + ST_PREV + ST_CUR, 2 + DL + ST_CUR, r == 0, pwA0, pwA1); else WG_WAIT(2 + 2 * DL + ST_PREV + ST_CUR, 2 + 2 * DL + ST_PREV + ST_CUR, 0, pwB0, pwB1);
             if (has_next) { if (set == 0) { WG_STAGE(pwA0, wl0, dup0) WG_STAGE(pwA1, wl1, dup1) } else { WG_STAGE(pwB0, wl0, dup0) WG_STAGE(pwB1, wl1, dup1) } }
             {
                 wg_gc8* nrow_p = srow + (long)(r + 3 < nrow ? 3 : nrow - 1 - r) * W3;
@@ -1328,6 +1356,7 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
 #undef WG_KEEP_ALL
 #undef WG_DEPTH_LOAD
 #undef WG_WAIT
+#undef WG_WAIT1
 #undef WG_WIN_LOAD
 #undef WG_STAGE
 }
@@ -1542,10 +1571,13 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
                    (W % 4 == 0) && dw <= W && dh <= H && ((uintptr_t)rgb % 4 == 0) && ((uintptr_t)out % 4 == 0) &&
                    ((long)H * W * 3 % 4 == 0);
     if (fast_ok && g.mode == D2S_MODE_HALF_TAB && (H % 2 != 0)) fast_ok = false;
-    // round 6: the gather kernel (no LDS, fixed-point blend) serves every display mode when 4 pixels span less than one depth column
-    // step (3 dw < W: 1080p and up at Depth Resolution 518; 720p frames stay on the kernels below).  D2S_WARP_GATHER=0: off (A/B, tests)
+    // round 6: the gather kernel (wave-private LDS window, fixed-point blend) serves every display mode when a lane's 4 pixels touch at most
+    // 3 (3 dw < W: model-resolution depth under 1080p and larger frames) or 4 (3 dw < 2 W: 720p) depth columns, and when the depth map
+    // has the frame's size (the drop-in make_sbs(rgb, depth[H, W]) surface).  D2S_WARP_GATHER=0: the round-5 kernels (A/B, tests)
     static EnvInt gather_env{"D2S_WARP_GATHER", 1};
-    if (fast_ok && gather_env.get() && 3L * dw < W && dw >= 3 && W >= 8 && W < 16384 && (long)batch * dh * dw * 4 < (1L << 32)) {
+    const bool direct = dw == W && dh == H;
+    const int nc = direct ? 4 : (3L * dw < W ? 3 : (3L * dw < 2L * W ? 4 : 0));
+    if (fast_ok && gather_env.get() && nc && dw >= nc && W >= 8 && W < 16384 && (long)batch * dh * dw * 4 < (1L << 32)) {
         const int ntx = cdiv(W, 256);
         const long rows = (long)H * batch;
         static EnvInt wpc_env{"D2S_WARP_WPC", 32};                 // resident waves per CU the grid is cut for
@@ -1556,12 +1588,14 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
         // register budget: 128 VGPRs (4 waves per SIMD): two window sets in flight + the row loop without a spill.  At 96 (5 waves) the Full-TAB /
         // Half modes reload loop constants from scratch every row -- a scratch reload queues behind the window prefetch in the same in-order
         // vmcnt -- and Full-SBS gains nothing (155-159 us against 153-158; profiles/r6_01_warp_gather.md)
-#define WG_LAUNCH(MODE_) hipLaunchKernelGGL((stereo_warp_gather<MODE_, 4>), grid, block, 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rpw, ntx);
+#define WG_LAUNCH_N(MODE_, NC_, DIR_) hipLaunchKernelGGL((stereo_warp_gather<MODE_, NC_, DIR_>), grid, block, 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rpw, ntx)
+#define WG_LAUNCH(MODE_) { if (direct) WG_LAUNCH_N(MODE_, 4, true); else if (nc == 3) WG_LAUNCH_N(MODE_, 3, false); else WG_LAUNCH_N(MODE_, 4, false); }
         if (g.mode == D2S_MODE_FULL_SBS) WG_LAUNCH(D2S_MODE_FULL_SBS)
         else if (g.mode == D2S_MODE_FULL_TAB) WG_LAUNCH(D2S_MODE_FULL_TAB)
         else if (g.mode == D2S_MODE_HALF_SBS) WG_LAUNCH(D2S_MODE_HALF_SBS)
         else WG_LAUNCH(D2S_MODE_HALF_TAB)
 #undef WG_LAUNCH
+#undef WG_LAUNCH_N
         D2S_CHECK_LAUNCH();
         return D2S_OK;
     }

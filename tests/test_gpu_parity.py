@@ -333,7 +333,8 @@ def test_warp_gather_kernel_against_staged_and_generic(dev, monkeypatch):
     (D2S_WARP_GATHER=0) and the generic per-pixel kernel, in every display mode: <= 1 LSB, and at most 1 % of the bytes differ at all
     (the fixed-point blend is within 0.008 of a level of the exact value; the float kernels within 0.004).  Shapes: 1080p batches whose
     rows do not divide into the waves' bands, a width that is not a multiple of 256 (idle lanes in the last tile) or of 64, odd height,
-    4K, a 720p frame (3 dw >= W: stays on the staged kernels), shifts beyond the staged halo (taps from global memory, reflections)
+    4K, a 720p frame (four depth columns per lane), depth maps of the frame's size (direct columns), a frame too small for either
+    (stays on the staged kernels), shifts beyond the staged halo (taps from global memory, reflections)
     and beyond the frame (the float path)."""
     from desktop2stereo_amd import ops, synth, _lib
     lib = _lib.load()
@@ -354,7 +355,11 @@ def test_warp_gather_kernel_against_staged_and_generic(dev, monkeypatch):
         (1, 1080, 1920, (294, 518), 0.5, 40.0, 0.5, None),      # |shift| beyond the frame width: the float path
         (2, 1081, 1924, (294, 518), 0.064, 4.0, 0.0, None),     # odd height (Half-TAB falls back), W % 64 != 0
         (1, 2160, 3840, (294, 518), 0.064, 4.0, 0.1, None),
-        (2, 720, 1280, (294, 518), 0.064, 4.0, 0.0, None),      # 3 dw >= W: not eligible, both runs take the staged kernels
+        (2, 720, 1280, (294, 518), 0.064, 4.0, 0.0, None),      # 3 dw >= W: four depth columns per lane
+        (2, 1080, 1920, (1080, 1920), 0.064, 4.0, 0.05, None),  # depth at frame size (the drop-in make_sbs(rgb, depth[H, W]) surface): direct columns
+        (1, 720, 1280, (720, 1280), 0.064, 40.0, 0.0, 2),       # the same with shifts beyond the halo
+        (3, 90, 160, (90, 160), 0.064, 2.0, 0.0, None),         # a small frame with full-size depth
+        (2, 360, 640, (294, 518), 0.064, 4.0, 0.0, None),       # 3 dw >= 2 W: not eligible, both runs take the staged kernels
         (5, 64, 1600, (32, 400), 0.064, 4.0, 0.0, 64),          # short frames: several frames per band
     ]
     for (B, H, W, (dh, dw), ipd, ratio, conv, wpc) in cases:

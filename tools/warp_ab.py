@@ -9,6 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batches", type=int, nargs="+", default=[1, 32]); ap.add_argument("--hw", type=int, nargs=2, default=[1080, 1920])
 ap.add_argument("--modes", nargs="+", default=["Full-SBS", "Half-SBS", "Full-TAB", "Half-TAB"]); ap.add_argument("--ratio", type=float, default=4.0)
 ap.add_argument("--kind", default="noise"); ap.add_argument("--n", type=int, default=100)
+ap.add_argument("--full-depth", action="store_true", help="depth map of the frame's size (the drop-in make_sbs surface) instead of 294 x 518")
 a = ap.parse_args()
 dev = torch.device("cuda"); H, W = a.hw
 lib = _lib.load()
@@ -17,7 +18,7 @@ def setenv(k, v):
 for B in a.batches:
     gen = synth.noise_frame if a.kind == "noise" else synth.structured_frame
     img = torch.from_numpy(np.stack([gen(H, W, i) for i in range(B)])).to(dev)
-    dep = torch.from_numpy(np.stack([synth.smooth_depth(294, 518, i) for i in range(B)])).to(dev)
+    dep = torch.from_numpy(np.stack([synth.smooth_depth(*((H, W) if a.full_depth else (294, 518)), i) for i in range(B)])).to(dev)
     for mode in a.modes:
         sp = ops.sbs_params(0.064, a.ratio, 0.0, mode, True)
         oh, ow = ops.sbs_shape(H, W, sp)
@@ -34,6 +35,6 @@ for B in a.batches:
             times[gather] = e0.elapsed_time(e1) / a.n * 1e3
             outs[gather] = out.cpu().numpy().astype(np.int16)
         d = np.abs(outs[1] - outs[0])
-        byts = B * (H * W * 3 + 294 * 518 * 4 + oh * ow * 3)
+        byts = B * (H * W * 3 + dep.shape[-2] * dep.shape[-1] * 4 + oh * ow * 3)
         print(f"{mode:9s} B={B:2d} {W}x{H}: staged {times[0]:7.1f} us ({byts/times[0]/1e6:5.2f} TB/s)  gather {times[1]:7.1f} us ({byts/times[1]/1e6:5.2f} TB/s = {byts/times[1]/8e6:.3f} of 8 TB/s)"
               f"  | bytes differing: {(d > 0).mean():.2e}, max {d.max()} LSB", flush=True)
