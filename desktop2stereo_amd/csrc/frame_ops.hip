@@ -346,606 +346,11 @@ stereo_warp_generic(const void* __restrict__ rgb, const float* __restrict__ dept
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fast path (the bench configuration): u8 HWC in, u8 HWC out, no padding, W % 4 == 0.
-// One thread per 4 consecutive SOURCE pixels of one row: the depth sample / shift is computed once
-// and shared by both eyes; the source row window is staged through LDS with coalesced dword reads;
-// each eye's 4 (Full) or 2 (Half-SBS) output pixels leave as one 12-/6-byte store.
-// Block = 256 threads = 1024 source pixels of one row.
-// ------------------------------------------------------------------------------------------------
-constexpr int FP_PX = 4;                    // source pixels per thread
-constexpr int FP_TW = 256 * FP_PX;          // tile width in source pixels
-constexpr int FP_MARGIN = 64;               // staged halo each side (pixels); beyond it -> global fallback
-
-// ------------------------------------------------------------------------------------------------
-// Streaming fast path (Full-SBS / Full-TAB / Half-SBS): persistent blocks walk (frame, row, tile) items with a
-// balanced grid; the NEXT item's source window and depth rows are prefetched into registers while
-// the current one is computed (global latency hidden, one barrier per item); the source window is
-// unpacked once into one RGBX dword per pixel in LDS, so a bilinear tap pair is two ds_read_b32
-// (+ v_cvt_f32_ubyteN) instead of six byte reads.
-// ------------------------------------------------------------------------------------------------
-constexpr int SW_LDS_PX = FP_TW + 2 * FP_MARGIN;       // 1152 pixels, multiple of 4
-constexpr int SW_DN = (FP_TW + 8 + 255) / 256;         // depth-row values per thread
-
-template <int MODE>
-__global__ void __launch_bounds__(256, 5)
-stereo_warp_stream(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
-                   int B, WarpGeom g, int ipb /* consecutive rows per block */) {
-    __shared__ __attribute__((aligned(16))) uint32_t spix[2][SW_LDS_PX];
-    __shared__ float drow[2][FP_TW + 8];
-    const int tid = threadIdx.x;
-    const int items = B * g.H;                            // rows of all frames
-    const float span = (float)(g.W - 1);
-    const long per = (long)g.out_h * g.out_w;
-
-    uint32_t pre[2][3];
-    float dpre[SW_DN], dpre2[SW_DN], dw0 = 0.f, dw1 = 0.f;   // prefetched depth rows (lerped when stored: no early wait)
-
-    // the column tile is fixed per block (blockIdx.y); items are rows (frame-major) strided by gridDim.x
-    const int xa = blockIdx.y * FP_TW;
-    const int wx0 = xa - FP_MARGIN < 0 ? 0 : xa - FP_MARGIN;
-    const int wx1 = xa + FP_TW + FP_MARGIN > g.W ? g.W : xa + FP_TW + FP_MARGIN;
-    const int xe = xa + FP_TW - 1 > g.W - 1 ? g.W - 1 : xa + FP_TW - 1;
-    const int dxa = linear_tap(xa, g.dsx, g.dw, false).i0;
-    const int dn = linear_tap(xe, g.dsx, g.dw, false).i1 - dxa + 1;
-    const int groups = (wx1 - wx0) >> 2;
-    // (frame, row) of an item are tracked incrementally: the scalar unit has no integer divide
-#define SW_DECODE(ITEM, b_, y_)                                                               \
-    const int b_ = (ITEM) == item ? cur_b : nxt_b;                                            \
-    const int y_ = (ITEM) == item ? cur_y : nxt_y;
-
-#define SW_LOAD(ITEM)                                                                         \
-    {                                                                                         \
-        SW_DECODE(ITEM, lb, ly)                                                               \
-        const uint8_t* row_ = rgb + ((long)lb * g.H + ly) * (long)g.W * 3;                    \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
-            int gi = tid + 256 * j;                                                           \
-            if (gi < groups) {                                                                \
-                const uint32_t* q = (const uint32_t*)(row_ + (long)(wx0 + 4 * gi) * 3);       \
-                pre[j][0] = q[0]; pre[j][1] = q[1]; pre[j][2] = q[2];                         \
-            }                                                                                 \
-        }                                                                                     \
-        const float* dep_ = depth + (long)lb * g.dh * g.dw;                                   \
-        Tap ty_ = linear_tap(ly, g.dsy, g.dh, false);                                         \
-        dw0 = ty_.w0; dw1 = ty_.w1;                                                           \
-        _Pragma("unroll") for (int i = 0; i < SW_DN; ++i) {                                   \
-            int di = tid + 256 * i;                                                           \
-            if (di < dn) { dpre[i] = dep_[ty_.i0 * g.dw + dxa + di]; dpre2[i] = dep_[ty_.i1 * g.dw + dxa + di]; }   /* raw: lerp at store time */ \
-        }                                                                                     \
-    }
-#define SW_STORE(ITEM, BUF)                                                                   \
-    {                                                                                         \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
-            int gi = tid + 256 * j;                                                           \
-            if (gi < groups) {                                                                \
-                uint4 px_;                                                                    \
-                px_.x = pre[j][0];                                                            \
-                px_.y = __builtin_amdgcn_alignbyte(pre[j][1], pre[j][0], 3);                  \
-                px_.z = __builtin_amdgcn_alignbyte(pre[j][2], pre[j][1], 2);                  \
-                px_.w = pre[j][2] >> 8;                                                       \
-                *(uint4*)&spix[BUF][4 * gi] = px_;                                            \
-            }                                                                                 \
-        }                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < SW_DN; ++i) {                                   \
-            int di = tid + 256 * i;                                                           \
-            if (di < dn) drow[BUF][di] = dw0 * dpre[i] + dw1 * dpre2[i];                                            \
-        }                                                                                     \
-    }
-
-    // a block walks a contiguous band of ipb rows (see stereo_warp_lanes: the band's depth rows are fetched once)
-    int item = blockIdx.x * ipb;
-    if (item >= items) return;
-    const int item_end = item + ipb < items ? item + ipb : items;
-    int cur_b = item / g.H, cur_y = item - cur_b * g.H, nxt_b = cur_b, nxt_y = cur_y;      // (one division per block)
-    // per-thread column constants: the depth taps of this thread's 4 pixels depend on x only, not on the row
-    const int x_base = xa + tid * FP_PX;
-    int li0[FP_PX], li1[FP_PX];
-    float lw0[FP_PX], lw1[FP_PX];
-#pragma unroll
-    for (int k = 0; k < FP_PX; ++k) {
-        int x = x_base + k; if (x > g.W - 1) x = g.W - 1;
-        Tap t = linear_tap(x, g.dsx, g.dw, false);
-        li0[k] = t.i0 - dxa; li1[k] = t.i1 - dxa; lw0[k] = t.w0; lw1[k] = t.w1;
-    }
-    // a wave whose 256 pixels stay more than the halo away from both frame edges never reflects and never leaves the staged
-    // window as long as |shift| < FP_MARGIN - 1: one vote for both eyes, no per-tap range logic (wave-uniform)
-    const int wave_x0 = xa + (tid & ~63) * FP_PX;
-    const bool interior = wave_x0 >= FP_MARGIN + 2 && wave_x0 + 64 * FP_PX - 1 <= g.W - 1 - (FP_MARGIN + 2);
-    SW_LOAD(item)
-    SW_STORE(item, 0)
-    __syncthreads();
-    int buf = 0;
-    while (true) {
-        const int next = item + 1;
-        const bool has = next < item_end;
-        nxt_b = cur_b; nxt_y = cur_y + 1;
-        if (nxt_y >= g.H) { nxt_y -= g.H; ++nxt_b; }
-        if (has) SW_LOAD(next)
-        {
-            SW_DECODE(item, b, y)
-            const uint8_t* src_row = rgb + ((long)b * g.H + y) * (long)g.W * 3;
-            if (x_base < g.W) {
-                float shift[FP_PX];
-                bool small = true;
-#pragma unroll
-                for (int k = 0; k < FP_PX; ++k) {
-                    float d = lw0[k] * drow[buf][li0[k]] + lw1[k] * drow[buf][li1[k]] - g.conv;
-                    shift[k] = ((-d * g.ratio) * g.max_px) * 0.05f;
-                    small = small && fabsf(shift[k]) < (float)(FP_MARGIN - 1);
-                }
-                const bool easy = interior && __all(small);
-#pragma unroll
-                for (int eye = 0; eye < 2; ++eye) {
-                    float px[FP_PX][3];
-                    if (easy) {
-                        // x + s stays inside [2, W-3] and inside the staged window: no reflection, x1 = x0 + 1 (one ds_read2_b32)
-#pragma unroll
-                        for (int k = 0; k < FP_PX; ++k) {
-                            const float sx = (float)(x_base + k) + (eye ? -shift[k] : shift[k]);
-                            const int x0 = (int)sx;
-                            const float w1 = sx - (float)x0, w0 = 1.0f - w1;
-                            const uint32_t p0 = spix[buf][x0 - wx0], p1 = spix[buf][x0 - wx0 + 1];
-                            px[k][0] = w0 * (float)(p0 & 0xffu) + w1 * (float)(p1 & 0xffu);
-                            px[k][1] = w0 * (float)((p0 >> 8) & 0xffu) + w1 * (float)((p1 >> 8) & 0xffu);
-                            px[k][2] = w0 * (float)((p0 >> 16) & 0xffu) + w1 * (float)((p1 >> 16) & 0xffu);
-                        }
-                    } else {
-                    // branch-free coordinates (at most one reflection per side); one wave-level test
-                    // decides between the LDS taps and the rare generic path (shift beyond the staged
-                    // halo, or more than one reflection)
-                    float sxv[FP_PX];
-                    bool fast = true;
-#pragma unroll
-                    for (int k = 0; k < FP_PX; ++k) {
-                        float xr = fabsf((float)(x_base + k) + (eye ? -shift[k] : shift[k]));
-                        fast = fast && (xr <= 2.f * span);
-                        sxv[k] = xr <= span ? xr : span - (xr - span);
-                        int x0 = (int)sxv[k];
-                        fast = fast && (x0 >= wx0) && (x0 + 1 < wx1 || (x0 + 1 >= g.W && x0 < wx1));
-                    }
-                    if (fast) {
-#pragma unroll
-                        for (int k = 0; k < FP_PX; ++k) {
-                            int x0 = (int)sxv[k];
-                            float w1 = sxv[k] - (float)x0, w0 = 1.0f - w1;
-                            int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
-                            uint32_t p0 = spix[buf][x0 - wx0], p1 = spix[buf][x1 - wx0];   // (a planar-by-(x&3) layout measured no faster)
-                            px[k][0] = w0 * (float)(p0 & 0xffu) + w1 * (float)(p1 & 0xffu);
-                            px[k][1] = w0 * (float)((p0 >> 8) & 0xffu) + w1 * (float)((p1 >> 8) & 0xffu);
-                            px[k][2] = w0 * (float)((p0 >> 16) & 0xffu) + w1 * (float)((p1 >> 16) & 0xffu);
-                        }
-                    } else {
-                        for (int k = 0; k < FP_PX; ++k) {
-                            float sx = reflect_clip((float)(x_base + k) + (eye ? -shift[k] : shift[k]), span);
-                            int x0 = (int)sx;
-                            float w1 = sx - (float)x0, w0 = 1.0f - w1;
-                            int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
-                            const uint8_t* q0 = src_row + (long)x0 * 3; const uint8_t* q1 = src_row + (long)x1 * 3;
-                            for (int c = 0; c < 3; ++c) px[k][c] = w0 * (float)q0[c] + w1 * (float)q1[c];
-                        }
-                    }
-                    }
-                    // values are convex combinations of bytes: already inside [0,255], round-half-even only
-                    if (x_base + FP_PX <= g.W) {
-                        if (MODE == D2S_MODE_FULL_SBS || MODE == D2S_MODE_FULL_TAB) {
-                            long row = (MODE == D2S_MODE_FULL_SBS) ? y : (long)eye * g.H + y;
-                            long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + x_base : x_base;
-                            // v_cvt_pk_u8_f32: round-half-even + saturate + byte insert in one instruction
-                            // (semantics checked on gfx950: tools/ubench/cvt_test)
-                            const float* f = &px[0][0];
-                            uint32_t* o = (uint32_t*)(out + (b * per + row * g.out_w + col) * 3);
-                            uint3 w3;
-                            w3.x = pack4_u8(f[0], f[1], f[2], f[3]);
-                            w3.y = pack4_u8(f[4], f[5], f[6], f[7]);
-                            w3.z = pack4_u8(f[8], f[9], f[10], f[11]);
-                            *(uint3*)o = w3;
-                        } else {  // HALF_SBS
-                            long col = ((long)eye * g.W + x_base) >> 1;
-                            uint16_t* o16 = (uint16_t*)(out + (b * per + (long)y * g.out_w + col) * 3);
-                            float h6[6];
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) { h6[c] = (px[0][c] + px[1][c]) * 0.5f; h6[3 + c] = (px[2][c] + px[3][c]) * 0.5f; }
-                            uint32_t lo = pack4_u8(h6[0], h6[1], h6[2], h6[3]);
-                            uint32_t hi = pack4_u8(h6[4], h6[5], 0.f, 0.f);
-                            o16[0] = (uint16_t)lo; o16[1] = (uint16_t)(lo >> 16); o16[2] = (uint16_t)hi;
-                        }
-                    } else {
-                        for (int k = 0; k < FP_PX && x_base + k < g.W; ++k) {
-                            if (MODE == D2S_MODE_FULL_SBS || MODE == D2S_MODE_FULL_TAB) {
-                                long row = (MODE == D2S_MODE_FULL_SBS) ? y : (long)eye * g.H + y;
-                                long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + x_base + k : x_base + k;
-                                uint8_t* o = out + (b * per + row * g.out_w + col) * 3;
-                                for (int c = 0; c < 3; ++c) o[c] = to_u8(px[k][c]);
-                            } else if ((k & 1) == 0 && x_base + k + 1 < g.W) {
-                                long col = ((long)eye * g.W + x_base + k) >> 1;
-                                uint8_t* o = out + (b * per + (long)y * g.out_w + col) * 3;
-                                for (int c = 0; c < 3; ++c) o[c] = to_u8((px[k][c] + px[k + 1][c]) * 0.5f);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (has) SW_STORE(next, buf ^ 1)
-        __syncthreads();
-        if (!has) break;
-        item = next; cur_b = nxt_b; cur_y = nxt_y;
-        buf ^= 1;
-    }
-#undef SW_DECODE
-#undef SW_LOAD
-#undef SW_STORE
-}
-
-// ------------------------------------------------------------------------------------------------
-// Lane-strided streaming path (Full-SBS / Full-TAB / Half-TAB, W % 64 == 0).  stereo_warp_stream above is VALU-issue bound (~680
-// instructions per thread-row of 8 output pixels: byte unpacking at every tap, unfused blends, stride-4 LDS taps).  Here
-//   * the source window is unpacked ONCE per row into three float planes (R, G, B) in LDS: a bilinear tap pair is
-//     ds_read_b32 x 2 per channel, no v_cvt_f32_ubyte / mask / shift per tap, and the 12-byte staging groups land as
-//     conflict-free ds_write_b128 (4 consecutive floats of one channel);
-//   * lane l of wave w owns pixels xa + 256 w + l + 64 k (k = 0..3): consecutive lanes tap consecutive LDS words (no
-//     bank conflicts; the 4-consecutive-pixels mapping of the older kernel strides lanes by 4 words);
-//   * the blend keeps the reference's rounding (two products, one sum, each rounded: depth.py:2164-2184 via
-//     F.grid_sample bilinear) but issues the two products as ONE v_pk_mul_f32;
-//   * results are packed to RGBX bytes, transposed through a wave-private 1 KiB LDS patch (write [l + 64 k], read
-//     [4 l .. 4 l + 3]; one wave's LDS operations execute in order, no barrier) and leave as 12-byte stores, 768
-//     contiguous bytes per wave-instruction.
-// Everything else (one item = one row of one 1024-pixel column tile, register prefetch of the next item, one barrier per
-// item, wave-uniform easy / reflecting / generic paths) is as in stereo_warp_stream.
-// ------------------------------------------------------------------------------------------------
-typedef float wl_f2 __attribute__((ext_vector_type(2)));
-constexpr int WL_PLANE = SW_LDS_PX;                    // floats per channel plane
-constexpr int WL_DN = 2;                               // depth-row values per thread (depth grid columns under a tile <= 512)
-
-typedef uint32_t wl_u3 __attribute__((ext_vector_type(3)));
-#ifdef WL_CUT_LOAD          // (tuning aid, timing only: no global loads at all -- what remains is issue / LDS time)
-__device__ __forceinline__ void wl_gload3(wl_u3& d, const void* p) { d = (wl_u3){(uint32_t)(size_t)p, 0x01020304u, 0x05060708u}; }
-__device__ __forceinline__ void wl_gload1(float& d, const void* p) { d = 0.5f + 1e-9f * (float)(uint32_t)(size_t)p; }
-#else
-__device__ __forceinline__ void wl_gload3(wl_u3& d, const void* p) { asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
-__device__ __forceinline__ void wl_gload1(float& d, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
-#endif
-// LDS-only block barrier.  __syncthreads() is a workgroup release / acquire fence over ALL address spaces: the compiler puts
-// s_waitcnt vmcnt(0) in front of it, which drains the prefetched rows and every global store of the row just written --
-// once per row.  The rows exchanged here live in LDS only.
-#ifdef WL_CUT_BARRIER       // (tuning aid, tools/build_variant.sh: timing only, results wrong -- what the per-row block barrier costs)
-__device__ __forceinline__ void wl_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
-__device__ __forceinline__ void wl_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
-
-// Round 5 (session 3): the kernel is bound by VALU issue (a wave64 VALU instruction occupies its SIMD for 4 cycles: 289 per wave-row of
-// 256 pixels x 2 eyes = 122 us of the 187 at batch 32), so the per-pixel stream is written for instruction count:
-//   * the six taps of a pixel leave as ds_read_b32 with IMMEDIATE plane offsets off one address register (ds_read2_b32's 8-bit offsets
-//     cannot reach the next plane: the compiler spent two v_add per pixel on plane bases), waited for with hand-counted lgkmcnt;
-//   * the sum of a tap pair's two products is one v_add_f32 issued from (non-volatile) inline asm: left to itself the SLP vectoriser
-//     pairs the sums of different pixels into v_pk_add_f32 and pays three v_mov per pair to line the operands up;
-//   * RGBX -> 12 bytes is three v_perm_b32; the row part of an output address is wave-uniform (SALU) and the lane part a constant.
-// WL_PLAIN_C (tools/build_variant.sh) restores the compiler-scheduled form: same bits (tools/warp_bench.py --digest).
-__device__ __forceinline__ float wl_add(float a, float b) {
-#ifdef WL_PLAIN_C
-    return a + b;
-#else
-    float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
-#endif
-}
-struct WlTaps { float r0, r1, g0, g1, b0, b1; };
-// the six taps (x, x + 1) x (R, G, B) of the pixel whose R tap 0 sits at LDS byte address a
-__device__ __forceinline__ void wl_taps_issue(WlTaps& t, uint32_t a) {
-    constexpr int P = WL_PLANE * 4;
-    asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %6 offset:4\n\tds_read_b32 %2, %6 offset:%7\n\tds_read_b32 %3, %6 offset:%8\n\t"
-                 "ds_read_b32 %4, %6 offset:%9\n\tds_read_b32 %5, %6 offset:%10"
-                 : "=&v"(t.r0), "=&v"(t.r1), "=&v"(t.g0), "=&v"(t.g1), "=&v"(t.b0), "=&v"(t.b1)
-                 : "v"(a), "n"(P), "n"(P + 4), "n"(2 * P), "n"(2 * P + 4) : "memory");
-}
-// the taps of t have landed when at most N younger LDS instructions of this wave are outstanding (LDS returns in order)
-#define WL_TAPS_WAIT(T, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(T.r0), "+v"(T.r1), "+v"(T.g0), "+v"(T.g1), "+v"(T.b0), "+v"(T.b1) :: "memory")
-
-template <int MODE>
-__global__ void __launch_bounds__(256, 4)
-stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, uint8_t* __restrict__ out,
-                  int B, WarpGeom g, int ipb /* consecutive items per block */) {
-    __shared__ __attribute__((aligned(16))) float splane[2][3][WL_PLANE];     // 27,648 B
-    __shared__ float drow[2][FP_TW + 8];                                        //  8,256 B
-    __shared__ __attribute__((aligned(16))) uint32_t tpose[4][256];            //  4,096 B  -> 4 blocks per CU
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int items = MODE == D2S_MODE_HALF_TAB ? B * (g.H / 2) : B * g.H;      // rows (row pairs) of all frames
-    const float span = (float)(g.W - 1);
-    const long per = (long)g.out_h * g.out_w;
-
-    // two register sets: the row after the one being computed (stored to LDS at the end of the iteration) and the row after
-    // that (requested at the start of the iteration).  With one row in flight per block the kernel ran at the latency of
-    // one load + the stores queued ahead of it per row (~4 us x 27 rows per block at batch 16: 2.6 TB/s whatever the
-    // instruction count was); vmcnt retires in order, so a load also waits for the older stores of the previous row.
-    wl_u3 pre[2][2];
-    float dpre[2][WL_DN], dpre2[2][WL_DN], dw0[2] = {0.f, 0.f}, dw1[2] = {0.f, 0.f};
-
-    const int xa = blockIdx.y * FP_TW;
-    const int wx0 = xa - FP_MARGIN < 0 ? 0 : xa - FP_MARGIN;
-    const int wx1 = xa + FP_TW + FP_MARGIN > g.W ? g.W : xa + FP_TW + FP_MARGIN;
-    const int xe = xa + FP_TW - 1 > g.W - 1 ? g.W - 1 : xa + FP_TW - 1;
-    const int dxa = linear_tap(xa, g.dsx, g.dw, false).i0;
-    const int dn = linear_tap(xe, g.dsx, g.dw, false).i1 - dxa + 1;
-    const int groups = (wx1 - wx0) >> 2;
-    int gofs[2], dofs[WL_DN];                              // this thread's (clamped) byte / element offsets inside a row
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { const int gi = tid + 256 * j; gofs[j] = (wx0 + 4 * (gi < groups ? gi : groups - 1)) * 3; }
-#pragma unroll
-    for (int i = 0; i < WL_DN; ++i) { const int di = tid + 256 * i; dofs[i] = di < dn ? di : dn - 1; }
-
-#define WL_LOAD(S, LB, LY)                                                                    \
-    {                                                                                         \
-        const uint8_t* row_ = rgb + ((long)(LB) * g.H + (LY)) * (long)g.W * 3;                \
-        /* The prefetch loads are issued from inline asm and waited for with a hand-counted vmcnt (WL_WAIT): the compiler's    \
-           own count for a load that crosses the loop's back edge and its branches is the minimum over all paths -- vmcnt(5)   \
-           here, which also drains the row requested a moment ago and the stores just issued.  Unconditional, at clamped        \
-           indices: every path issues the same number of vector-memory instructions. */                                        \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) wl_gload3(pre[S][j], row_ + gofs[j]);   \
-        const float* dep_ = depth + (long)(LB) * g.dh * g.dw + dxa;                           \
-        Tap ty_ = linear_tap((LY), g.dsy, g.dh, false);                                       \
-        dw0[S] = ty_.w0; dw1[S] = ty_.w1;                                                     \
-        _Pragma("unroll") for (int i = 0; i < WL_DN; ++i) {                                   \
-            wl_gload1(dpre[S][i], dep_ + ty_.i0 * g.dw + dofs[i]); wl_gload1(dpre2[S][i], dep_ + ty_.i1 * g.dw + dofs[i]); \
-        }                                                                                     \
-    }
-    // set S has landed: N = vector-memory instructions issued after its 6 loads that may stay in flight (vmcnt retires in order)
-#define WL_WAIT(S, N)                                                                         \
-    asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(pre[S][0]), "+v"(pre[S][1]), "+v"(dpre[S][0]), "+v"(dpre[S][1]),         \
-                 "+v"(dpre2[S][0]), "+v"(dpre2[S][1]) :: "memory");
-    // bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 of a 4-pixel group -> four floats per channel plane
-#define WL_UB(WORD, N) ((float)(((WORD) >> (8 * (N))) & 0xffu))
-#define WL_STORE(S, BUF)                                                                      \
-    {                                                                                         \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
-            int gi = tid + 256 * j;                                                           \
-            if (gi < groups) {                                                                \
-                const uint32_t a_ = pre[S][j][0], b_ = pre[S][j][1], c_ = pre[S][j][2];       \
-                *(float4*)&splane[BUF][0][4 * gi] = make_float4(WL_UB(a_, 0), WL_UB(a_, 3), WL_UB(b_, 2), WL_UB(c_, 1)); \
-                *(float4*)&splane[BUF][1][4 * gi] = make_float4(WL_UB(a_, 1), WL_UB(b_, 0), WL_UB(b_, 3), WL_UB(c_, 2)); \
-                *(float4*)&splane[BUF][2][4 * gi] = make_float4(WL_UB(a_, 2), WL_UB(b_, 1), WL_UB(c_, 0), WL_UB(c_, 3)); \
-            }                                                                                 \
-        }                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < WL_DN; ++i) {                                   \
-            int di = tid + 256 * i;                                                           \
-            if (di < dn) drow[BUF][di] = dw0[S] * dpre[S][i] + dw1[S] * dpre2[S][i];          \
-        }                                                                                     \
-    }
-
-    // Items are rows (Full modes) or row PAIRS (Half-TAB: output row yp = mean of rows 2 yp, 2 yp + 1); a block walks items
-    // it0, it0 + stride, ...; a "step" is one source row, so a pair is two consecutive steps.
-    constexpr bool HALF = MODE == D2S_MODE_HALF_TAB;
-    // A block walks a CONTIGUOUS band of ipb items (round 2: items it0, it0 + gridDim.x, ... -- neighbouring rows then sat on
-    // eight different XCDs, every XCD's L2 fetched every depth row, and the launch read 1.7 x its algorithmic bytes, PMC
-    // profiles/r3_04): a band's depth rows are fetched once, and the HBM pages of the band stream in order.
-    const int ipf = HALF ? g.H / 2 : g.H;                  // items per frame
-    const int it0 = blockIdx.x * ipb;
-    if (it0 >= items) return;
-    const int nsteps = (items - it0 < ipb ? items - it0 : ipb) * (HALF ? 2 : 1);
-    int cur_b = it0 / ipf, cur_y = (it0 - cur_b * ipf) * (HALF ? 2 : 1);                     // (one division per block)
-    auto advance = [&](int& rb, int& ry) {                 // (frame, row) of the next step: the next source row
-        ++ry;
-        if (ry >= g.H) { ry -= g.H; ++rb; }
-    };
-    // per-thread column constants: pixel k of this lane, its depth taps (they depend on x only) and whether it exists
-    const int wave_x0 = xa + wid * 256;
-    int li0[FP_PX], li1[FP_PX];
-    float lw0[FP_PX], lw1[FP_PX], xf[FP_PX];
-#pragma unroll
-    for (int k = 0; k < FP_PX; ++k) {
-        int x = wave_x0 + lane + 64 * k; if (x > g.W - 1) x = g.W - 1;
-        Tap t = linear_tap(x, g.dsx, g.dw, false);
-        li0[k] = t.i0 - dxa; li1[k] = t.i1 - dxa; lw0[k] = t.w0; lw1[k] = t.w1; xf[k] = (float)x;
-    }
-    const int nk = g.W - wave_x0 >= 256 ? 4 : (g.W - wave_x0 <= 0 ? 0 : (g.W - wave_x0) >> 6);   // W % 64 == 0: wave-uniform
-    // a wave whose pixels stay more than the halo away from both frame edges never reflects and never leaves the staged
-    // window as long as |shift| < FP_MARGIN - 1 (wave-uniform vote, no per-tap range logic)
-    const bool interior = wave_x0 >= FP_MARGIN + 2 && wave_x0 + 255 <= g.W - 1 - (FP_MARGIN + 2);
-    const int xs = wave_x0 + 4 * lane;                    // first of the 4 consecutive pixels this lane stores
-    uint32_t* const tp = tpose[wid];
-    const uint32_t xs3 = (uint32_t)xs * 3u;              // this lane's byte column inside an output row (one eye)
-    int n1_b = cur_b, n1_y = cur_y; advance(n1_b, n1_y);
-    int n2_b = n1_b, n2_y = n1_y; advance(n2_b, n2_y);
-    int step = 0;
-    bool has1 = 1 < nsteps, has2 = 2 < nsteps;
-    float hold[2][FP_PX][3];                               // Half-TAB: the even row's blended values wait for the odd row
-    WL_LOAD(0, cur_b, cur_y)
-    WL_LOAD(1, (has1 ? n1_b : cur_b), (has1 ? n1_y : cur_y))
-    WL_WAIT(0, 6)
-    WL_STORE(0, 0)
-    wl_sync();
-    // one iteration: request item + 2 into register set SL, compute item from LDS buffer BUF, put item + 1 (set SS) into
-    // the other LDS buffer
-#define WL_ITER(BUF, SS, SL)                                                                  \
-    {                                                                                         \
-        WL_LOAD(SL, (has2 ? n2_b : cur_b), (has2 ? n2_y : cur_y))                             \
-        wl_compute(BUF, cur_b, cur_y);                                                        \
-        if (has1) {                                                                           \
-            /* younger than set SS: the 6 loads of set SL and this row's 2 stores (waves with no pixel, and the even rows of    \
-               Half-TAB, store nothing).                                                                                    \
-               (Also letting the PREVIOUS row's 2 stores stay in flight -- vmcnt(10) from the second iteration on -- measured  \
-               no faster.) */                                                                                               \
-            if (nk > 0 && (!HALF || (cur_y & 1))) { WL_WAIT(SS, 8) } else { WL_WAIT(SS, 6) }  \
-            WL_STORE(SS, (BUF) ^ 1)                                                           \
-        }                                                                                     \
-        wl_sync();                                                                      \
-        if (!has1) break;                                                                     \
-        ++step; cur_b = n1_b; cur_y = n1_y; n1_b = n2_b; n1_y = n2_y;                         \
-        advance(n2_b, n2_y);                                                                  \
-        has1 = has2; has2 = step + 2 < nsteps;                                                \
-    }
-    auto wl_compute = [&](int buf, int b, int y) {
-#ifdef WL_CUT_COMPUTE       // (timing only: load + stage, no per-pixel work)
-        if (drow[buf][tid] == 123.456f) out[tid] = 1;
-        return;
-#endif
-        if (nk > 0) {
-            const float* dr = drow[buf];
-            const float* sp = &splane[buf][0][0] - wx0;          // plane R indexed by frame x
-            float shift[FP_PX];
-            bool small = true;
-#pragma unroll
-            for (int k = 0; k < FP_PX; ++k) {
-                const wl_f2 dd = (wl_f2){dr[li0[k]], dr[li1[k]]} * (wl_f2){lw0[k], lw1[k]};
-                const float d = wl_add(dd[0], dd[1]) - g.conv;
-                shift[k] = ((-d * g.ratio) * g.max_px) * 0.05f;
-#ifdef WL_PLAIN_C
-                small = small && fabsf(shift[k]) < (float)(FP_MARGIN - 1);
-#endif
-            }
-#ifndef WL_PLAIN_C
-            static_assert(FP_PX == 4, "the shift bound below is written for four pixels per lane");
-            small = fmaxf(fmaxf(fabsf(shift[0]), fabsf(shift[1])), fmaxf(fabsf(shift[2]), fabsf(shift[3]))) < (float)(FP_MARGIN - 1);
-#endif
-            const bool easy = interior && __all(small);
-#pragma unroll
-            for (int eye = 0; eye < 2; ++eye) {
-                float px[FP_PX][3];
-#if !defined(WL_PLAIN_C) && !defined(WL_CUT_TAPS)
-                if (easy) {
-                    const uint32_t sbase = (uint32_t)(size_t)sp;               // LDS byte address of plane R at frame x = 0 (wave-uniform)
-                    WlTaps tp_[FP_PX];
-                    wl_f2 ww[FP_PX];
-                    auto issue = [&](int k) {
-                        const float sx = eye ? xf[k] - shift[k] : xf[k] + shift[k];
-                        const float fl = floorf(sx);
-                        const float w1 = sx - fl, w0 = 1.0f - w1;
-                        ww[k] = (wl_f2){w0, w1};
-                        wl_taps_issue(tp_[k], sbase + ((uint32_t)(int)fl << 2));
-                    };
-                    auto blend = [&](int k) {
-                        const wl_f2 vr = (wl_f2){tp_[k].r0, tp_[k].r1} * ww[k], vg = (wl_f2){tp_[k].g0, tp_[k].g1} * ww[k],
-                                    vb = (wl_f2){tp_[k].b0, tp_[k].b1} * ww[k];
-                        px[k][0] = wl_add(vr[0], vr[1]); px[k][1] = wl_add(vg[0], vg[1]); px[k][2] = wl_add(vb[0], vb[1]);
-                    };
-                    // at most 12 reads in flight (lgkmcnt counts to 15); a pixel is blended while the next but one is requested
-                    issue(0); issue(1);
-                    WL_TAPS_WAIT(tp_[0], 6); blend(0);
-                    issue(2);
-                    WL_TAPS_WAIT(tp_[1], 6); blend(1);
-                    issue(3);
-                    WL_TAPS_WAIT(tp_[2], 6); blend(2);
-                    WL_TAPS_WAIT(tp_[3], 0); blend(3);
-                } else
-#endif
-                if (easy) {
-#pragma unroll
-                    for (int k = 0; k < FP_PX; ++k) {
-                        const float sx = eye ? xf[k] - shift[k] : xf[k] + shift[k];
-                        const float fl = floorf(sx);
-                        const float w1 = sx - fl, w0 = 1.0f - w1;
-                        const float* p = sp + (int)fl;
-                        const wl_f2 ww = {w0, w1};
-#ifdef WL_CUT_TAPS          // (timing only: no LDS tap reads)
-                        const wl_f2 vr = (wl_f2){fl, w1} * ww, vg = (wl_f2){w0, fl} * ww, vb = (wl_f2){w1, w0} * ww; (void)p;
-#else
-                        const wl_f2 vr = (wl_f2){p[0], p[1]} * ww, vg = (wl_f2){p[WL_PLANE], p[WL_PLANE + 1]} * ww,
-                                    vb = (wl_f2){p[2 * WL_PLANE], p[2 * WL_PLANE + 1]} * ww;
-#endif
-                        px[k][0] = vr[0] + vr[1]; px[k][1] = vg[0] + vg[1]; px[k][2] = vb[0] + vb[1];
-                    }
-                } else {
-                    // branch-free coordinates (at most one reflection per side); one wave-level test decides between the
-                    // LDS taps and the rare generic path (shift beyond the staged halo, or more than one reflection)
-                    float sxv[FP_PX];
-                    bool fast = true;
-#pragma unroll
-                    for (int k = 0; k < FP_PX; ++k) {
-                        const float xr = fabsf(eye ? xf[k] - shift[k] : xf[k] + shift[k]);
-                        fast = fast && (xr <= 2.f * span);
-                        sxv[k] = xr <= span ? xr : span - (xr - span);
-                        const int x0 = (int)sxv[k];
-                        fast = fast && (x0 >= wx0) && (x0 + 1 < wx1 || (x0 + 1 >= g.W && x0 < wx1));
-                    }
-                    if (__all(fast)) {
-#pragma unroll
-                        for (int k = 0; k < FP_PX; ++k) {
-                            const int x0 = (int)sxv[k];
-                            const float w1 = sxv[k] - (float)x0, w0 = 1.0f - w1;
-                            const int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
-                            const float *p0 = sp + x0, *p1 = sp + x1;
-                            const wl_f2 ww = {w0, w1};
-                            const wl_f2 vr = (wl_f2){p0[0], p1[0]} * ww, vg = (wl_f2){p0[WL_PLANE], p1[WL_PLANE]} * ww,
-                                        vb = (wl_f2){p0[2 * WL_PLANE], p1[2 * WL_PLANE]} * ww;
-                            px[k][0] = wl_add(vr[0], vr[1]); px[k][1] = wl_add(vg[0], vg[1]); px[k][2] = wl_add(vb[0], vb[1]);
-                        }
-                    } else {
-                        const uint8_t* src_row = rgb + ((long)b * g.H + y) * (long)g.W * 3;
-                        for (int k = 0; k < FP_PX; ++k) {
-                            const float sx = reflect_clip(eye ? xf[k] - shift[k] : xf[k] + shift[k], span);
-                            const int x0 = (int)sx;
-                            const float w1 = sx - (float)x0, w0 = 1.0f - w1;
-                            const int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
-                            const uint8_t* q0 = src_row + (long)x0 * 3; const uint8_t* q1 = src_row + (long)x1 * 3;
-                            for (int c = 0; c < 3; ++c) px[k][c] = w0 * (float)q0[c] + w1 * (float)q1[c];
-                        }
-                    }
-                }
-                if (HALF && !(y & 1)) {                   // even row of a pair: keep the blended values (F.interpolate(mode='area') averages floats)
-#pragma unroll
-                    for (int k = 0; k < FP_PX; ++k)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) hold[eye][k][c] = px[k][c];
-                    continue;
-                }
-                // values are convex combinations of bytes: already inside [0,255]; v_cvt_pk_u8_f32 rounds half-even
-                uint32_t pk[FP_PX];
-#pragma unroll
-                for (int k = 0; k < FP_PX; ++k) {
-                    if (HALF) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) px[k][c] = (hold[eye][k][c] + px[k][c]) * 0.5f;
-                    }
-                    uint32_t u = __builtin_amdgcn_cvt_pk_u8_f32(px[k][0], 0, 0);
-                    u = __builtin_amdgcn_cvt_pk_u8_f32(px[k][1], 1, u);
-                    pk[k] = __builtin_amdgcn_cvt_pk_u8_f32(px[k][2], 2, u);
-                }
-                // wave-private transpose: [l + 64 k] -> [4 l .. 4 l + 3], then 4 x RGBX -> 12 bytes
-#pragma unroll
-                for (int k = 0; k < FP_PX; ++k) tp[lane + 64 * k] = pk[k];
-                const uint4 v = *(const uint4*)&tp[4 * lane];
-                if (xs < g.W) {
-                    const long row = MODE == D2S_MODE_FULL_SBS ? y : (MODE == D2S_MODE_FULL_TAB ? (long)eye * g.H + y : (long)eye * (g.H / 2) + (y >> 1));
-                    uint3 w3;
-#ifdef WL_PLAIN_C
-                    const long col = (MODE == D2S_MODE_FULL_SBS) ? (long)eye * g.W + xs : xs;
-                    w3.x = (v.x & 0x00ffffffu) | (v.y << 24);
-                    w3.y = ((v.y >> 8) & 0x0000ffffu) | (v.z << 16);
-                    w3.z = ((v.z >> 16) & 0x000000ffu) | (v.w << 8);
-                    uint8_t* dst = out + (b * per + row * g.out_w + col) * 3;
-#else
-                    // v_perm_b32(hi, lo, sel): byte i of the result = byte sel[i] of the eight bytes lo (0-3) | hi (4-7)
-                    w3.x = __builtin_amdgcn_perm(v.y, v.x, 0x04020100u);       // R0 G0 B0 R1
-                    w3.y = __builtin_amdgcn_perm(v.z, v.y, 0x05040201u);       // G1 B1 R2 G2
-                    w3.z = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);       // B2 R3 G3 B3
-                    // wave-uniform row base (b, y, eye: scalar registers) + this lane's constant byte column
-                    // (readfirstlane: a 64-bit product added to a lane value is otherwise selected as v_mad_u64_u32 chains, six VALU per store)
-                    const long uo = ((long)b * per + row * g.out_w + (MODE == D2S_MODE_FULL_SBS ? (long)eye * g.W : 0L)) * 3;
-                    const uint32_t uo_lo = __builtin_amdgcn_readfirstlane((uint32_t)uo), uo_hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long)uo >> 32));
-                    uint8_t* dst = out + (long)(((unsigned long)uo_hi << 32) | uo_lo) + xs3;
-#endif
-#ifdef WL_CUT_STORE         // (timing only: no global stores; one conditional store keeps the values alive)
-                    if (w3.x == 0x12345678u && w3.y == 0x9abcdef0u)
-#endif
-                    *(uint3*)dst = w3;
-                }
-            }
-        }
-    };
-    while (true) {
-        WL_ITER(0, 1, 0)
-        WL_ITER(1, 0, 1)
-    }
-#undef WL_ITER
-#undef WL_WAIT
-#undef WL_LOAD
-#undef WL_STORE
-#undef WL_UB
-}
-
-// ------------------------------------------------------------------------------------------------
-// Gather path (round 6; Full-SBS / Full-TAB / Half-SBS / Half-TAB, u8 HWC in and out, W % 4 == 0, 3 dw < W).
-// stereo_warp_lanes above ends at 0.41 of the HBM rate: ~230 VALU instructions per wave-row (fp32 planes in LDS: unpack once, six
-// ds_read_b32 and six float operations per pixel and eye, a transpose through LDS for the stores) behind one block barrier per row,
-// 16 waves per CU.  This kernel has no barrier, no float blend and no shared state between waves (nothing runs in lock step):
+// Fast path (round 6; Full-SBS / Full-TAB / Half-SBS / Half-TAB, u8 HWC in and out, no padding, W % 4 == 0; depth at model resolution
+// with 3 dw < 2 W, or at the frame's size).  Rounds 2-5 ran LDS-staged float kernels here (stereo_warp_stream / stereo_warp_lanes: fp32
+// planes in LDS, six ds_read_b32 and six float operations per pixel and eye, a transpose through LDS for the stores, one block barrier
+// per row, 16 waves per CU: 0.41 of the HBM rate, docs/LAB_NOTEBOOK and profiles/r5_09); they were removed when this kernel covered
+// their inputs.  It has no barrier, no float blend and no shared state between waves (nothing runs in lock step):
 //   * a lane owns FOUR CONSECUTIVE pixels of a row and both eyes: its results are 12 contiguous bytes per eye (one 12-byte store,
 //     768 contiguous bytes per wave), no transpose;
 //   * a wave stages ITS OWN window of the source row (256 + 2 x 64 pixels) in 2 KiB of LDS as one RGBX dword per pixel -- aligned
@@ -972,6 +377,7 @@ stereo_warp_lanes(const uint8_t* __restrict__ rgb, const float* __restrict__ dep
 // (profiles/r6_01_warp_gather.md: cut-point builds, counters, what the remaining time is).
 // ------------------------------------------------------------------------------------------------
 typedef unsigned short wg_u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t wl_u3 __attribute__((ext_vector_type(3)));
 typedef __attribute__((address_space(3))) uint32_t wg_lds_u32;
 __device__ __forceinline__ uint2 wg_load8(const uint8_t* p) { uint2 d; __builtin_memcpy(&d, p, 8); return d; }     // global_load_dwordx2, any alignment
 __device__ __forceinline__ uint32_t wg_dot(uint32_t a, uint32_t w, uint32_t c) {
@@ -1119,7 +525,7 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     const uint32_t drow_b = (uint32_t)g.dw * 4u, dplane = (uint32_t)g.dh * drow_b;      // bytes of a depth row / map (the launcher keeps B * dplane < 2^32)
     // Two rows of window loads in flight (register sets A / B; the row loop is unrolled by two so that a set is a fixed group of registers):
     // the set staged at the end of row r was requested at the end of row r - 2.  All loads of the row loop are issued from inline asm and
-    // waited for with hand-counted vmcnt, as in stereo_warp_lanes: left to the compiler, a load whose result crosses the loop's back edge or
+    // waited for with hand-counted vmcnt: left to the compiler, a load whose result crosses the loop's back edge or
     // a branch gets a register copy -- and an s_waitcnt vmcnt(0) -- right behind its issue (the first builds of this kernel ran 165 us at
     // every prefetch depth and occupancy for that reason).  Every load is unconditional (clamped to the wave's last row): the counts below
     // are the same on every path.
@@ -1361,61 +767,6 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
 #undef WG_STAGE
 }
 
-// Half-TAB fast path: thread = 4 source pixels x 2 rows (y, y+1 with even y); H even.
-__global__ void __launch_bounds__(256)
-stereo_warp_fast_halftab(const uint8_t* __restrict__ rgb, const float* __restrict__ depth,
-                         uint8_t* __restrict__ out, int B, WarpGeom g) {
-    // Direct (L2-cached) reads; the two rows share the thread's column window.
-    const int tiles_x = (g.W + FP_TW - 1) / FP_TW;
-    int bid = blockIdx.x;
-    int tx = bid % tiles_x;
-    int yp = (bid / tiles_x) % (g.H / 2);
-    int b = bid / (tiles_x * (g.H / 2));
-    const int x_base = tx * FP_TW + threadIdx.x * FP_PX;
-    if (x_base >= g.W) return;
-    const float* dep = depth + (long)b * g.dh * g.dw;
-    const float span = (float)(g.W - 1);
-    const long per = (long)g.out_h * g.out_w;
-    float acc[2][FP_PX][3];
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int k = 0; k < FP_PX; ++k) acc[e][k][0] = acc[e][k][1] = acc[e][k][2] = 0.f;
-#pragma unroll
-    for (int ry = 0; ry < 2; ++ry) {
-        int y = 2 * yp + ry;
-        const uint8_t* src_row = rgb + ((long)b * g.H + y) * (long)g.W * 3;
-#pragma unroll
-        for (int k = 0; k < FP_PX; ++k) {
-            int x = x_base + k; if (x > g.W - 1) x = g.W - 1;
-            float d = depth_at(dep, g, y, x) - g.conv;
-            float shift = ((-d * g.ratio) * g.max_px) * 0.05f;
-#pragma unroll
-            for (int eye = 0; eye < 2; ++eye) {
-                float sx = reflect_clip((float)x + (eye ? -shift : shift), span);
-                int x0 = (int)sx;
-                float w1 = sx - (float)x0, w0 = 1.0f - w1;
-                int x1 = x0 + 1 < g.W ? x0 + 1 : x0;
-                const uint8_t* p0 = src_row + (long)x0 * 3;
-                const uint8_t* p1 = src_row + (long)x1 * 3;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float v = w0 * (float)p0[c] + w1 * (float)p1[c];
-                    acc[eye][k][c] = ry == 0 ? v : (acc[eye][k][c] + v) * 0.5f;
-                }
-            }
-        }
-    }
-    // cat rows: eye*H + y ; out row = (eye*H + 2*yp) / 2 = eye*H/2 + yp
-#pragma unroll
-    for (int eye = 0; eye < 2; ++eye) {
-        long row = (long)eye * (g.H / 2) + yp;
-        uint8_t* o = out + (b * per + row * g.out_w + x_base) * 3;
-        for (int k = 0; k < FP_PX && x_base + k < g.W; ++k)
-            for (int c = 0; c < 3; ++c) o[k * 3 + c] = to_u8(acc[eye][k][c]);
-    }
-}
-
 }  // namespace d2s
 
 using namespace d2s;
@@ -1567,13 +918,14 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
     hipStream_t st = (hipStream_t)stream;
     static const bool force_generic = getenv("D2S_WARP_GENERIC") && atoi(getenv("D2S_WARP_GENERIC")) != 0;
     bool nopad = (g.Hp == H && g.Wp == W);
-    bool fast_ok = !force_generic && rgb_fmt == D2S_FMT_U8_HWC && out_fmt == D2S_FMT_U8_HWC && nopad && ((long)batch * H * cdiv(W, FP_TW) < (1L << 30)) &&
+    bool fast_ok = !force_generic && rgb_fmt == D2S_FMT_U8_HWC && out_fmt == D2S_FMT_U8_HWC && nopad && ((long)batch * H * cdiv(W, 256) < (1L << 30)) &&
                    (W % 4 == 0) && dw <= W && dh <= H && ((uintptr_t)rgb % 4 == 0) && ((uintptr_t)out % 4 == 0) &&
                    ((long)H * W * 3 % 4 == 0);
     if (fast_ok && g.mode == D2S_MODE_HALF_TAB && (H % 2 != 0)) fast_ok = false;
     // round 6: the gather kernel (wave-private LDS window, fixed-point blend) serves every display mode when a lane's 4 pixels touch at most
     // 3 (3 dw < W: model-resolution depth under 1080p and larger frames) or 4 (3 dw < 2 W: 720p) depth columns, and when the depth map
-    // has the frame's size (the drop-in make_sbs(rgb, depth[H, W]) surface).  D2S_WARP_GATHER=0: the round-5 kernels (A/B, tests)
+    // has the frame's size (the drop-in make_sbs(rgb, depth[H, W]) surface); everything else -- other formats, padding, W % 4 != 0, a depth
+    // grid between 2/3 of the frame's width and the frame's width -- takes the generic kernel.  D2S_WARP_GATHER=0: generic too (tests)
     static EnvInt gather_env{"D2S_WARP_GATHER", 1};
     const bool direct = dw == W && dh == H;
     const int nc = direct ? 4 : (3L * dw < W ? 3 : (3L * dw < 2L * W ? 4 : 0));
@@ -1599,39 +951,7 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
         D2S_CHECK_LAUNCH();
         return D2S_OK;
     }
-    if (fast_ok) {
-        int tiles_x = cdiv(W, FP_TW);
-        static const bool no_lanes = getenv("D2S_WARP_LANES") && atoi(getenv("D2S_WARP_LANES")) == 0;     // (A/B switch for tests)
-        const bool lanes_ok = !no_lanes && (W % 64 == 0) && (long)dw * FP_TW <= 500L * W;      // <= WL_DN * 256 depth columns under a column tile
-        if (g.mode == D2S_MODE_HALF_TAB && lanes_ok) {
-            long pairs = (long)(H / 2) * batch;
-            long rounds = (pairs * tiles_x + 256 * 4 - 1) / (256 * 4);
-            dim3 pgrid((unsigned)((pairs + rounds - 1) / rounds), tiles_x);
-            hipLaunchKernelGGL(stereo_warp_lanes<D2S_MODE_HALF_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rounds);
-        } else if (g.mode == D2S_MODE_HALF_TAB) {
-            dim3 grid((unsigned)((long)tiles_x * (H / 2) * batch));
-            hipLaunchKernelGGL(stereo_warp_fast_halftab, grid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g);
-        } else {
-            long rows = (long)H * batch;
-            // (Half-SBS stays on stereo_warp_stream: the lane-strided kernel needs the neighbour lane's values for the 2:1 column
-            //  mean -- 24 cross-lane moves per row -- and measured 117 vs 101 us at batch 16)
-            const bool lanes = lanes_ok && (g.mode == D2S_MODE_FULL_SBS || g.mode == D2S_MODE_FULL_TAB);
-            static EnvInt bpc_env{"D2S_WARP_BPC", 0};                     // tuning aid: rows are cut into 256 * bpc block walks
-            const int bpc = bpc_env.get() > 0 ? bpc_env.get() : (lanes ? 4 : 6);   // resident blocks per CU (3 / 6 / 8 measured slower for lanes at batch 16)
-            long rounds = (rows * tiles_x + 256 * bpc - 1) / (256 * bpc);   // balanced persistent grid: every block walks `rounds` rows
-            dim3 pgrid((unsigned)((rows + rounds - 1) / rounds), tiles_x);
-            if (lanes && g.mode == D2S_MODE_FULL_SBS)
-                hipLaunchKernelGGL(stereo_warp_lanes<D2S_MODE_FULL_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rounds);
-            else if (lanes)
-                hipLaunchKernelGGL(stereo_warp_lanes<D2S_MODE_FULL_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rounds);
-            else if (g.mode == D2S_MODE_FULL_SBS)
-                hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rounds);
-            else if (g.mode == D2S_MODE_FULL_TAB)
-                hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_FULL_TAB>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rounds);
-            else
-                hipLaunchKernelGGL(stereo_warp_stream<D2S_MODE_HALF_SBS>, pgrid, dim3(256), 0, st, (const uint8_t*)rgb, depth, (uint8_t*)out, batch, g, (int)rounds);
-        }
-    } else {
+    {
         if (rgb_fmt == D2S_FMT_U8_HWC) launch_generic<D2S_FMT_U8_HWC>(rgb, depth, out, out_fmt, batch, g, st);
         else if (rgb_fmt == D2S_FMT_U8_CHW) launch_generic<D2S_FMT_U8_CHW>(rgb, depth, out, out_fmt, batch, g, st);
         else if (rgb_fmt == D2S_FMT_F32_CHW) launch_generic<D2S_FMT_F32_CHW>(rgb, depth, out, out_fmt, batch, g, st);

@@ -298,7 +298,7 @@ def test_warp_distance_from_reference_as_shipped_bf16(dev, golden_dir):
 
 
 def test_warp_fast_equals_generic_and_fused_upsample(dev):
-    """u8 fast path (LDS-staged) == generic kernel bit-for-bit on the float->u8 rounding, and the
+    """u8 fast path within 1 LSB (0.53 of a level) of the generic kernel's float result, and the
     fused model-resolution depth path == explicit upsample + warp."""
     from desktop2stereo_amd import ops, synth, _lib
     from oracle import d2s_oracle as O
@@ -329,12 +329,13 @@ def test_warp_fast_equals_generic_and_fused_upsample(dev):
 
 
 def test_warp_gather_kernel_against_staged_and_generic(dev, monkeypatch):
-    """Round 6: stereo_warp_gather (wave-private LDS window, 16.16 fixed-point dot blend) against the LDS-staged float kernels
-    (D2S_WARP_GATHER=0) and the generic per-pixel kernel, in every display mode: <= 1 LSB, and at most 1 % of the bytes differ at all
-    (the fixed-point blend is within 0.008 of a level of the exact value; the float kernels within 0.004).  Shapes: 1080p batches whose
+    """Round 6: stereo_warp_gather (wave-private LDS window, 16.16 fixed-point dot blend) against the generic per-pixel float kernel
+    (D2S_WARP_GATHER=0: its uint8 output, and its float output), in every display mode: <= 1 LSB, and at most 1 % of the bytes differ
+    at all (the fixed-point blend is within 0.008 of a level of the exact value; the float kernel within 0.004).  (Until round 5's
+    LDS-staged kernels were removed this test also held the new kernel to them: same figures, profiles/r6_01.)  Shapes: 1080p batches whose
     rows do not divide into the waves' bands, a width that is not a multiple of 256 (idle lanes in the last tile) or of 64, odd height,
     4K, a 720p frame (four depth columns per lane), depth maps of the frame's size (direct columns), a frame too small for either
-    (stays on the staged kernels), shifts beyond the staged halo (taps from global memory, reflections)
+    (takes the generic kernel either way), shifts beyond the staged halo (taps from global memory, reflections)
     and beyond the frame (the float path)."""
     from desktop2stereo_amd import ops, synth, _lib
     lib = _lib.load()
@@ -359,7 +360,7 @@ def test_warp_gather_kernel_against_staged_and_generic(dev, monkeypatch):
         (2, 1080, 1920, (1080, 1920), 0.064, 4.0, 0.05, None),  # depth at frame size (the drop-in make_sbs(rgb, depth[H, W]) surface): direct columns
         (1, 720, 1280, (720, 1280), 0.064, 40.0, 0.0, 2),       # the same with shifts beyond the halo
         (3, 90, 160, (90, 160), 0.064, 2.0, 0.0, None),         # a small frame with full-size depth
-        (2, 360, 640, (294, 518), 0.064, 4.0, 0.0, None),       # 3 dw >= 2 W: not eligible, both runs take the staged kernels
+        (2, 360, 640, (294, 518), 0.064, 4.0, 0.0, None),       # 3 dw >= 2 W: not eligible, both runs take the generic kernel
         (5, 64, 1600, (32, 400), 0.064, 4.0, 0.0, 64),          # short frames: several frames per band
     ]
     for (B, H, W, (dh, dw), ipd, ratio, conv, wpc) in cases:

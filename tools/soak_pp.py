@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Race screen for the hand-scheduled kernels of round 2: everything here must be bit-identical from run to run.
   * gemm_pp_kernel (counted vmcnt, raw barriers, K-split tail): many shapes x repeats through d2s_gemm_probe and the batched engine;
-  * stereo_warp_lanes (inline-asm prefetch with counted vmcnt, LDS-only barrier): all modes, batch 1..16, 1080p and 4K.
+  * stereo_warp_gather (inline-asm prefetch with counted vmcnt, wave-private LDS windows): all modes, batch 1..16, 1080p and 4K.
     python tools/soak_pp.py [--reps 100]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

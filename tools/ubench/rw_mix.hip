@@ -7,7 +7,7 @@
 #include <cstdint>
 struct U3 { uint32_t x, y, z; };
 __global__ void __launch_bounds__(256) rw_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int W, int nt) {
-    // one block per (row, 1024-pixel tile) item, grid-strided: same access shape as stereo_warp_lanes
+    // one block per (row, 1024-pixel tile) item, grid-strided: same access shape as round 5's stereo_warp_lanes
     const int tiles = (W + 1023) / 1024;
     for (long item = blockIdx.x; item < (long)rows * tiles; item += gridDim.x) {
         const long row = item / tiles; const int tile = (int)(item - row * tiles);

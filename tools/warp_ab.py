@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""A/B of the stereo-warp kernels on the GPU: the gather kernel (D2S_WARP_GATHER=1, round 6) against the LDS-staged kernels
-(D2S_WARP_GATHER=0) -- time per launch (HIP events, output pre-allocated) and byte differences, per display mode and batch."""
+"""A/B of the stereo-warp kernels on the GPU: the fast path (stereo_warp_gather, D2S_WARP_GATHER=1) against D2S_WARP_GATHER=0 -- the
+generic per-pixel float kernel since round 6's clean-up (until then: round 5's LDS-staged kernels, the "staged" column of
+profiles/r6_01) -- time per launch (HIP events, output pre-allocated) and byte differences, per display mode and batch."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -36,5 +37,5 @@ for B in a.batches:
             outs[gather] = out.cpu().numpy().astype(np.int16)
         d = np.abs(outs[1] - outs[0])
         byts = B * (H * W * 3 + dep.shape[-2] * dep.shape[-1] * 4 + oh * ow * 3)
-        print(f"{mode:9s} B={B:2d} {W}x{H}: staged {times[0]:7.1f} us ({byts/times[0]/1e6:5.2f} TB/s)  gather {times[1]:7.1f} us ({byts/times[1]/1e6:5.2f} TB/s = {byts/times[1]/8e6:.3f} of 8 TB/s)"
+        print(f"{mode:9s} B={B:2d} {W}x{H}: other {times[0]:7.1f} us ({byts/times[0]/1e6:5.2f} TB/s)  gather {times[1]:7.1f} us ({byts/times[1]/1e6:5.2f} TB/s = {byts/times[1]/8e6:.3f} of 8 TB/s)"
               f"  | bytes differing: {(d > 0).mean():.2e}, max {d.max()} LSB", flush=True)
