@@ -493,6 +493,16 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     wg_lds_u32* const wl1 = (wg_lds_u32*)(wbase + 4u * (uint32_t)(4 * g1 + 2 * (g1 >> 3)));
     const bool dup0 = (g0 & 7) == 0 && g0 > 0, dup1 = (g1 & 7) == 0;       // first pixel of a 32-pixel chunk: also the first pad slot of the chunk before
 
+    // The first row's window is requested BEFORE the per-lane constants are formed (a hundred-odd instructions of tap arithmetic): at one
+    // frame a wave lives for 1-3 rows and that arithmetic would otherwise sit in front of its first HBM round trip.
+    wg_gc8* srow = (wg_gc8*)rgb + (long)R0 * W3;
+    wl_u3 pwA0, pwA1, pwB0, pwB1;
+#ifdef WG_CUT_LOAD           // (tuning aid, tools/build_variant.sh: timing only -- no window loads from global memory)
+#define WG_WIN_LOAD(P0, P1, ROW_) { P0 = (wl_u3){(uint32_t)(size_t)(ROW_), 0x01020304u, 0x05060708u}; P1 = P0; }
+#else
+#define WG_WIN_LOAD(P0, P1, ROW_) { wg_gload3(P0, gofs0, (ROW_)); wg_gload3(P1, gofs1, (ROW_)); }
+#endif
+    WG_WIN_LOAD(pwA0, pwA1, srow)
     // per-lane column constants: NC depth columns c0 .. c0 + NC - 1; pixel k lerps a pair of them by w1[k].  The shift
     // is linear in depth, so the COLUMNS are turned into fixed-point shifts first (shift_fx = depth * K + ck, K = -ratio * max_px *
     // 0.05 * 65536, ck = -conv * K) and a pixel costs NC - 1 FMAs on the column differences (weights 1 below its pair, w1 on it, 0 above).
@@ -521,7 +531,6 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     // Everything about a ROW is wave-uniform and kept in scalar registers: the source row pointer advances by W * 3 (frames are contiguous:
     // the global row index runs through them), the vertical depth tap is computed on the vector unit once and read back with
     // v_readfirstlane (its row offsets then cost scalar multiplies, not v_mul_lo_u32), lanes add constant 32-bit offsets.
-    wg_gc8* srow = (wg_gc8*)rgb + (long)R0 * W3;
     const uint32_t drow_b = (uint32_t)g.dw * 4u, dplane = (uint32_t)g.dh * drow_b;      // bytes of a depth row / map (the launcher keeps B * dplane < 2^32)
     // Two rows of window loads in flight (register sets A / B; the row loop is unrolled by two so that a set is a fixed group of registers):
     // the set staged at the end of row r was requested at the end of row r - 2.  All loads of the row loop are issued from inline asm and
@@ -529,15 +538,9 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
     // a branch gets a register copy -- and an s_waitcnt vmcnt(0) -- right behind its issue (the first builds of this kernel ran 165 us at
     // every prefetch depth and occupancy for that reason).  Every load is unconditional (clamped to the wave's last row): the counts below
     // are the same on every path.
-    wl_u3 pwA0, pwA1, pwB0, pwB1;
     typename wg_vec<NC>::type dA0, dA1;                     // depth columns (rows i0 / i1 of the depth grid) of the next row to be computed, as bits:
     float dwA0, dwA1;                                       // ONE set -- a step turns them into three column shifts, then requests the next row's
                                                             // (+ their vertical weights, scalar registers)
-#ifdef WG_CUT_LOAD           // (tuning aid, tools/build_variant.sh: timing only -- no window loads from global memory)
-#define WG_WIN_LOAD(P0, P1, ROW_) { P0 = (wl_u3){(uint32_t)(size_t)(ROW_), 0x01020304u, 0x05060708u}; P1 = P0; }
-#else
-#define WG_WIN_LOAD(P0, P1, ROW_) { wg_gload3(P0, gofs0, (ROW_)); wg_gload3(P1, gofs1, (ROW_)); }
-#endif
     // The vertical depth tap of a row (ATen's source index: a dozen float operations) is computed once per row by ONE lane: lane l holds
     // the tap of the band's row 64 q + l (byte offsets of its two depth rows inside the buffer, both weights), refilled every 64 rows; a
     // row reads its lane's four values back with v_readlane (index in a scalar register).
@@ -581,7 +584,6 @@ stereo_warp_gather(const uint8_t* __restrict__ rgb, const float* __restrict__ de
         WL_[2] = __builtin_amdgcn_alignbyte(PW[2], PW[1], 2); WL_[3] = PW[2] >> 8;                \
         if (DUP_) WL_[-2] = PW[0];                                                                \
     }
-    WG_WIN_LOAD(pwA0, pwA1, srow)
     tap_fill(b, y);
     WG_DEPTH_LOAD(0, dA0, dA1, dwA0, dwA1)
     WG_WAIT(DL, DL, 0, pwA0, pwA1);
