@@ -357,6 +357,9 @@ def compact_line(res: dict, full_path: str) -> dict:
     fd = res.get("f1_dibr")
     if isinstance(fd, dict):
         out["f1_dibr_us_per_frame"] = {n: v.get("us_per_frame") for n, v in fd.items() if isinstance(v, dict)}
+    hb = res.get("host_boundary")
+    if isinstance(hb, dict):
+        out["host_boundary"] = {n: v.get("value") for n, v in hb.items() if isinstance(v, dict)} or _pick(hb, ("error",))
     ir = res.get("ingest_rank0")
     if isinstance(ir, dict):
         out["ingest_rank0"] = _pick(ir, ("value", "frames_per_step"))
@@ -830,6 +833,51 @@ def rank_body(args, engine_factory=None, device=None):
         dt_aa = timed(lambda i: eng.pipeline(pool_aa[i % 4], p_aa, sp, use_ema=False, out=out_aa), 3, st_aa)
         result["resample_bicubic_aa"] = {"value": st_aa * B / dt_aa, "unit": "stereo frames/s", "ms_per_step": 1e3 * dt_aa / st_aa,
                                          "note": "same step with d2s_pre_params.resample = D2S_RESAMPLE_BICUBIC_AA"}
+
+    if rank == 0 and world == 1 and not fake and default_run and not args.no_profile:
+        # The boundary as the reference's callers see it: predict_depth takes a HOST uint8 frame and make_sbs returns a
+        # HOST float32 HWC array (depth.py:1916-1924, 2231).  Reported beside `value`, never as `value`: (a) pinned uint8 frame in over
+        # PCIe -> d2s_pipeline -> pinned uint8 packed frame out, copies and kernels in order on one stream; (b) the same with the float32
+        # HWC result the reference's make_sbs hands back (4 x the bytes); (c) the drop-in Python surface itself, numpy in -> numpy out
+        # (desktop2stereo_amd.depth.predict_depth + make_sbs: pageable buffers, two calls, host synchronisation per call as the API implies).
+        try:
+            hb = {}
+            pin_in = [frames_for(6000 + j, B).pin_memory() for j in range(4)]
+            dev_in = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
+            out_u8 = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=dev)
+            pin_u8 = torch.empty((B, oh, ow, 3), dtype=torch.uint8).pin_memory()
+            pin_f32 = torch.empty((B, oh, ow, 3), dtype=torch.float32).pin_memory()
+            out_f32 = torch.empty((B, oh, ow, 3), dtype=torch.float32, device=dev)
+
+            def step_u8(i):
+                dev_in.copy_(pin_in[i % 4], non_blocking=True)
+                eng.pipeline(dev_in, p, sp, use_ema=False, out=out_u8)
+                pin_u8.copy_(out_u8, non_blocking=True)
+
+            def step_f32(i):
+                step_u8(i)
+                out_f32.copy_(out_u8)                               # uint8 -> float32 on the device (what chw_tensor_to_numpy's float frame holds)
+                pin_f32.copy_(out_f32, non_blocking=True)
+            nst = max(20, args.steps // 4)
+            dt_u8 = timed(step_u8, 3, nst)
+            dt_f32 = timed(step_f32, 3, nst)
+            hb["pinned_u8_in_u8_out"] = {"value": nst * B / dt_u8, "ms_per_step": 1e3 * dt_u8 / nst, "bytes_over_pcie_per_frame": H * W * 3 + oh * ow * 3}
+            hb["pinned_u8_in_f32_out"] = {"value": nst * B / dt_f32, "ms_per_step": 1e3 * dt_f32 / nst, "bytes_over_pcie_per_frame": H * W * 3 + oh * ow * 12}
+            from desktop2stereo_amd import depth as dropin
+            dropin.configure(args.model, weights, params=p, precision=args.precision, device=local_rank)
+            np_frames = [frames_for(6100 + j, 1)[0].numpy() for j in range(4)]
+
+            def step_api(i):
+                d_ = dropin.predict_depth(np_frames[i % 4], use_temporal_smooth=False)
+                dropin.make_sbs(np_frames[i % 4], d_, ipd_uv=p.ipd, depth_ratio=p.depth_strength, convergence=p.convergence, display_mode=args.mode)
+            dt_api = timed(step_api, 3, nst)
+            hb["dropin_numpy_in_numpy_f32_out"] = {"value": nst / dt_api, "ms_per_step": 1e3 * dt_api / nst}
+            hb["unit"] = "stereo frames/s"
+            hb["note"] = ("PCIe-inclusive rates of the same step, batch %d: copies and kernels serialised on one stream (no overlap of frame k's copies "
+                          "with frame k+1's kernels); `value` above is the HBM-resident region" % B)
+            result["host_boundary"] = hb
+        except Exception as ex:                                      # (a measurement aid must not take the headline down with it)
+            result["host_boundary"] = {"error": repr(ex)[:200]}
 
     if rank == 0 and world == 1 and not fake and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, weights, p, H, W, args.mode)
