@@ -157,3 +157,34 @@ def test_bench_tile_fit_batch_and_traffic_table():
     with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
         tab = json.load(f)
     assert {"gemm_linear", "stereo_warp"} <= set(tab["traffic_bytes_per_launch"])
+
+
+def test_bench_compact_line_is_small_and_complete():
+    """The driver parses the LAST stdout line of bench.py and keeps an ~8 KB tail (round 5's single 21 KB line left BENCH_r05.parsed null).
+    bench.compact_line() applied to a full report committed under profiles/ must stay below 6 000 bytes and carry the contract's keys,
+    the roofline (with traffic and its provenance) and the CPU baseline -- checked here without a GPU."""
+    import importlib.util
+    import json
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("d2s_bench_for_test", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full_path = os.path.join(repo, "profiles", "r6_05_bench_driver_cmd_full.json")
+    with open(full_path) as f:
+        full = json.load(f)
+    c = bench.compact_line(full, os.path.join(repo, "gpurun_out", "bench_full.json"))
+    line = json.dumps(c, separators=(",", ":"))
+    assert len(line.encode()) < 6000, len(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "roofline_warp", "cpu_baseline", "batched", "depth_l1_vs_ref", "warp_max_lsb", "full_report"):
+        assert k in c, k
+    assert set(c["config"]) >= {"workload", "frames_per_step_per_gpu", "timed_region"} and "model" not in c["config"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in c["roofline"], k
+    assert abs(c["roofline"]["frac"] - c["roofline"]["achieved"] / c["roofline"]["peak"]) < 1e-4
+    assert c["cpu_baseline"]["kind"] in ("port", "reference") and c["cpu_baseline"]["cores"] >= 1 and "sample" in c["cpu_baseline"]
+    assert abs(c["value"] - full["value"]) <= 1e-4 * full["value"]
+    # a report ten times as wordy must still fit (the line is built from picked keys, not from the report's size)
+    fat = dict(full, config=dict(full["config"], workload=full["config"]["workload"] * 10))
+    assert len(json.dumps(bench.compact_line(fat, "x"), separators=(",", ":")).encode()) < 6000
