@@ -196,43 +196,10 @@ __device__ __forceinline__ float smoothstep_inv(float e0, float inv, float x) {
 }
 __device__ __forceinline__ bool oob(float u, float v) { return u < 0.f || v < 0.f || u > 1.f || v > 1.f; }
 
-// push_pull_inpaint (:437-506)
+__device__ __forceinline__ float g_w_phase1(float w1i, float sdi, float cdi) { return w1i * (1.0f + (sdi - cdi) * 10.0f); }   // :459
+// phase 3 of push_pull_inpaint (:484-505): normalise + 3-tap vertical blur, or the pixel's own colour when nothing was found
 template <class S>
-__device__ void push_pull(const S& smp, const DibrGeom& g,
-                          float u, float v, float cdi, float parx, float pary, float sweep_sign, float out[3]) {
-    // (roll == 0: sy == 0, every sweep tap lies on the pixel's own row pair -- the samplers' own_* taps)
-    auto depth_at = [&](float su, float sv) { return smp.own_depth(su, sv); };
-    auto color_at = [&](float su, float sv, float* o) { smp.own_color(su, sv, o); };
-    float best[3] = {0.f, 0.f, 0.f}, bw = 0.f, col[3];
-    const float sx = parx * g.psx * sweep_sign, sy = pary * g.psx * sweep_sign;      // both use pixel_size.x (:442)
-    // (Requesting the sweep's depth taps four at a time before testing them -- same values, same order of the sums -- was built and
-    //  measured: no faster in the row kernel, 5-9 % slower in the gather kernels, and 30 more VGPRs took the row kernel from 7 to 4
-    //  waves per SIMD.  The loops stay as the shader writes them.)
-    for (int i = 1; i <= g.search; ++i) {                                             // phase 1 (:445-466)
-        float su = u + sx * (float)i, sv = v + sy * (float)i;
-        if (oob(su, sv)) continue;
-        float sdi = 1.0f - depth_at(su, sv);
-        if (sdi > cdi + g.tol) {
-            color_at(su, sv, col);
-            float w = g.w1[i] * (1.0f + (sdi - cdi) * 10.0f);
-            best[0] += col[0] * w; best[1] += col[1] * w; best[2] += col[2] * w;
-            bw += w;
-            if (bw > 5.0f) break;
-        }
-    }
-    if (bw < 2.0f) {                                                                  // phase 2 (:469-481)
-        for (int i = 1; i <= g.search; ++i) {
-            float su = u - sx * (float)i, sv = v - sy * (float)i;
-            if (oob(su, sv)) continue;
-            float sdi = 1.0f - depth_at(su, sv);
-            if (sdi > cdi + g.tol) {
-                color_at(su, sv, col);
-                float w = g.w2[i];
-                best[0] += col[0] * w; best[1] += col[1] * w; best[2] += col[2] * w;
-                bw += w;
-            }
-        }
-    }
+__device__ __forceinline__ void push_pull_finish(const S& smp, const DibrGeom& g, float u, float v, float cdi, const float best[3], float bw, float out[3]) {
     if (bw > 0.01f) {                                                                 // phase 3 (:484-502)
         float va[3] = {best[0] / bw * 0.5f, best[1] / bw * 0.5f, best[2] / bw * 0.5f}, vw = 0.5f;
         // the two vertical taps touch other texture rows: global gathers.  All six of their loads are requested before the first is
@@ -257,14 +224,81 @@ __device__ void push_pull(const S& smp, const DibrGeom& g,
         out[0] = va[0] / vw; out[1] = va[1] / vw; out[2] = va[2] / vw;
         return;
     }
-    color_at(u, v, out);                                                              // :505
+    smp.own_color(u, v, out);                                                         // :505
+}
+
+// push_pull_inpaint (:437-506)
+template <class S>
+__device__ void push_pull(const S& smp, const DibrGeom& g,
+                          float u, float v, float cdi, float parx, float pary, float sweep_sign, float out[3]) {
+    // (roll == 0: sy == 0, every sweep tap lies on the pixel's own row pair -- the samplers' own_* taps)
+    auto depth_at = [&](float su, float sv) { return smp.own_depth(su, sv); };
+    auto color_at = [&](float su, float sv, float* o) { smp.own_color(su, sv, o); };
+    float best[3] = {0.f, 0.f, 0.f}, bw = 0.f, col[3];
+    const float sx = parx * g.psx * sweep_sign, sy = pary * g.psx * sweep_sign;      // both use pixel_size.x (:442)
+    // (Requesting the sweep's depth taps four at a time before testing them -- same values, same order of the sums -- was built and
+    //  measured: no faster in the row kernel, 5-9 % slower in the gather kernels, and 30 more VGPRs took the row kernel from 7 to 4
+    //  waves per SIMD.  The loops stay as the shader writes them.)
+    for (int i = 1; i <= g.search; ++i) {                                             // phase 1 (:445-466)
+        float su = u + sx * (float)i, sv = v + sy * (float)i;
+        if (oob(su, sv)) continue;
+        float sdi = 1.0f - depth_at(su, sv);
+        if (sdi > cdi + g.tol) {
+            color_at(su, sv, col);
+            float w = g_w_phase1(g.w1[i], sdi, cdi);
+            best[0] += col[0] * w; best[1] += col[1] * w; best[2] += col[2] * w;
+            bw += w;
+            if (bw > 5.0f) break;
+        }
+    }
+    if (bw < 2.0f) {                                                                  // phase 2 (:469-481)
+        for (int i = 1; i <= g.search; ++i) {
+            float su = u - sx * (float)i, sv = v - sy * (float)i;
+            if (oob(su, sv)) continue;
+            float sdi = 1.0f - depth_at(su, sv);
+            if (sdi > cdi + g.tol) {
+                color_at(su, sv, col);
+                float w = g.w2[i];
+                best[0] += col[0] * w; best[1] += col[1] * w; best[2] += col[2] * w;
+                bw += w;
+            }
+        }
+    }
+    push_pull_finish(smp, g, u, v, cdi, best, bw, out);
+}
+
+// roll == 0: the five depth taps of a pixel that do not depend on its shift -- the centre, the smoothing pair at -+1.5 pixel_size
+// and the confidence pair at -+2 pixel_size along the parallax direction -- are the SAME texture positions for the two eyes:
+// sg(right) = -sg(left), and a negation is exact through (c * sg) * pixel_size * k, so u - dsx(right) is bit for bit u + dsx(left).
+// They are evaluated once per output column with the left eye's offsets and handed to both eyes (dm / dp change places for the right
+// eye, |a - b| == |b - a|): 5 taps instead of 10 per column of the row kernel, the same bits.
+struct PixTaps { float d0, dA, dB, jA, jB; };      // depth at u, u - dsx(left), u + dsx(left), u - s2x(left), u + s2x(left)
+template <class S>
+__device__ __forceinline__ PixTaps pix_taps(const S& smp, const DibrGeom& g, int x, int y) {
+    const float eye_offset = -g.half_ipd;
+    const float sg = eye_offset > 0.f ? 1.f : (eye_offset < 0.f ? -1.f : 0.f);
+    const float parx = g.c * sg;
+    const float u = ((float)x + 0.5f) / (float)g.ow, v = ((float)y + 0.5f) / (float)g.oh;
+    const float dsx = parx * g.psx * 1.5f, s2x = parx * g.psx * 2.0f;
+    // (One window test for the five taps instead of a branch pair per tap: measured, no faster, 12 bytes of scratch.)
+    PixTaps t;
+    t.d0 = smp.own_depth(u, v);
+    t.dA = smp.own_depth(u - dsx, v);
+    t.dB = smp.own_depth(u + dsx, v);
+    t.jA = smp.own_depth(u - s2x, v);
+    t.jB = smp.own_depth(u + s2x, v);
+    return t;
 }
 
 // one output pixel of one eye: FRAGMENT_SHADER.main (:533-631) -> colour * alpha
 // DEFER: return true WITHOUT a result when the pixel needs the in-painting (the caller queues it for a second, lane-compacted pass
 // that calls this function again with DEFER = false: the same expressions on the same inputs -> the same bits).
-template <bool DEFER = false, class S>
-__device__ __forceinline__ bool dibr_pixel(const S& smp, const DibrGeom& g, int x, int y, int eye, float outc[4]) {
+// sh: the column's five shift-independent depth taps (roll == 0 only, pix_taps) or nullptr = take them here.
+// FX = false: u_feather_enabled == 0 and u_corner_radius == 0 (the desktop viewer's state) as a compile-time fact.  As run-time branches
+// the two blocks depend on the column and row only, so the compiler hoists them out of the eye loop and -- free of side effects --
+// speculates them: every pixel paid for four IEEE divisions, a powf and a sqrtf it did not use (~250 of ~900 instructions of pass 1).
+template <bool DEFER = false, bool SHARED = false, bool FX = true, class S>
+__device__ __forceinline__ bool dibr_pixel(const S& smp, const DibrGeom& g, int x, int y, int eye, float outc[4], const PixTaps* sh = nullptr) {
     const float eye_offset = eye ? g.half_ipd : -g.half_ipd;                          // :2701, 2714
     const float sg = eye_offset > 0.f ? 1.f : (eye_offset < 0.f ? -1.f : 0.f);
     const float parx = g.c * sg, pary = g.s * sg;                                     // :540
@@ -273,9 +307,9 @@ __device__ __forceinline__ bool dibr_pixel(const S& smp, const DibrGeom& g, int 
     auto depth_at = [&](float su, float sv) { return smp.own_depth(su, sv); };       // (roll == 0: v - 0 * k == v, every tap below shares the row pair)
     // 3-tap depth smoothing along the parallax direction (:545-549)
     const float dsx = parx * g.psx * 1.5f, dsy = pary * g.psy * 1.5f;
-    float d0 = depth_at(u, v);
-    float dm = depth_at(u - dsx, v - dsy);
-    float dp = depth_at(u + dsx, v + dsy);
+    float d0, dm, dp;
+    if constexpr (SHARED) { d0 = sh->d0; dm = eye ? sh->dB : sh->dA; dp = eye ? sh->dA : sh->dB; }
+    else { d0 = depth_at(u, v); dm = depth_at(u - dsx, v - dsy); dp = depth_at(u + dsx, v + dsy); }
     float d = d0 * 0.7f + dm * 0.15f + dp * 0.15f;
 #if defined(DIBR_CUT) && DIBR_CUT == 1      // (tuning aid, timing only: stop after the three smoothing taps)
     outc[0] = outc[1] = outc[2] = d; outc[3] = 1.f; return false;
@@ -295,7 +329,9 @@ __device__ __forceinline__ bool dibr_pixel(const S& smp, const DibrGeom& g, int 
 #endif
     else {
         const float s2x = parx * g.psx * 2.0f, s2y = pary * g.psy * 2.0f;
-        float jump = fabsf(depth_at(u - s2x, v - s2y) - depth_at(u + s2x, v + s2y));
+        float jump;
+        if constexpr (SHARED) jump = eye ? fabsf(sh->jB - sh->jA) : fabsf(sh->jA - sh->jB);
+        else jump = fabsf(depth_at(u - s2x, v - s2y) - depth_at(u + s2x, v + s2y));
         conf = SMOOTHSTEP_C(0.04f, 0.10f, jump);
     }
 #if defined(DIBR_CUT) && DIBR_CUT == 2      // (timing only: stop after the confidence taps)
@@ -323,7 +359,7 @@ __device__ __forceinline__ bool dibr_pixel(const S& smp, const DibrGeom& g, int 
         float by = SMOOTHSTEP_C(-0.001f, 0.001f, sv) * SMOOTHSTEP_C(1.001f, 0.999f, sv);
         alpha = fminf(bx, by);
     }
-    if (g.feather) {                                                                   // :587-616
+    if (FX && g.feather) {                                                             // :587-616
         // (gl_FragCoord.xy - u_viewport.xy) / u_viewport.zw; gl_FragCoord is y-up, pixel centres at +0.5
         float fu = (((float)x + 0.5f) - g.vpx) / g.vpw, fv = (((float)g.oh - ((float)y + 0.5f)) - g.vpy) / g.vph, fw = g.feather_w;
         float fo = smoothstepf(0.f, fw, fu) * smoothstepf(0.f, fw, 1.0f - fu) * smoothstepf(0.f, fw, fv) * smoothstepf(0.f, fw, 1.0f - fv);
@@ -331,7 +367,7 @@ __device__ __forceinline__ bool dibr_pixel(const S& smp, const DibrGeom& g, int 
 #pragma unroll
         for (int k = 0; k < 3; ++k) col[k] *= sh;
     }
-    if (g.corner_r > 0.f) {
+    if (FX && g.corner_r > 0.f) {
         // rounded-box SDF over the quad's own uv (the shader's inner `uv` of the feather block shadows only that block), :617-624
         const float dx = fabsf(u - 0.5f) - 0.5f + g.corner_r, dy = fabsf(v - 0.5f) - 0.5f + g.corner_r;
         const float mx = fmaxf(dx, 0.f), my = fmaxf(dy, 0.f);
@@ -395,10 +431,10 @@ dibr_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ dep_a
 // gather kernel: bit-identical (tests/test_gpu_dibr.py).  The gather kernel spent ~600 VALU instructions per pixel, most of them
 // address arithmetic of its ~14 eight-byte gathers (64-bit row bases, GL_REPEAT wraps, byte unpacking).
 #ifndef DIBR_WAVES
-#define DIBR_WAVES 7                  // (72 VGPRs + 96 B of scratch instead of 86: 5 -> 7 waves per SIMD, 73.8 -> 69.0 us; 8: no faster)
+#define DIBR_WAVES 7                  // (<= 72 VGPRs: 5 -> 7 waves per SIMD, 73.8 -> 69.0 us in round 5; 8: no faster.  FX = false: 71 VGPRs, no scratch)
 #endif
-template <int OUT_FMT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIBR_WAVES, 8)))
+template <int OUT_FMT, bool FX>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIBR_WAVES)))
 dibr_rows_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ dep_all, void* __restrict__ out_all, DibrGeom g, int margin, int WW) {
     extern __shared__ float dibr_win[];                // [2][WW] the row pair of the depth texture | [6][WW] R0 G0 B0 R1 G1 B1 as floats
     __shared__ int queue[512], qn;                     // column - xb | eye << 8 of the pixels that need the in-painting
@@ -412,9 +448,14 @@ dibr_rows_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ 
     smp.rc = row_ctx(dep, g.H, g.W, ((float)y + 0.5f) / (float)g.oh);         // block-uniform (the v dibr_pixel forms)
     smp.dwin = dibr_win; smp.cwin = dibr_win + 2 * WW; smp.WW = WW;
     smp.wx0 = (int)floorf((((float)xb + 0.5f) / (float)g.ow) * (float)g.W - 0.5f) - margin;
+    // (Four texels per thread -- 16-byte depth loads, 12-byte colour loads, vector LDS writes, a sixth of the load instructions -- was
+    //  built and measured: 54.2 us against 51.6 at 1080p Full-SBS; a quarter of the threads then carry the whole round trip.)
+#if defined(DIBR_CUT) && (DIBR_CUT == 8 || DIBR_CUT == 10)      // (timing only: no staging, no second pass)
+    for (int j = tid; j < 0; j += 256) {
+#else
     for (int j = tid; j < WW; j += 256) {
-        int xs = (smp.wx0 + j) % g.W;
-        if (xs < 0) xs += g.W;
+#endif
+        const int xs = wrapi(smp.wx0 + j, g.W);        // (one conditional add / subtract unless the window is wider than the texture: then the modulo)
         dibr_win[j] = smp.rc.d0[xs];
         dibr_win[WW + j] = smp.rc.d1[xs];
         const uint8_t* p0 = rgb + smp.rc.c0 + xs * 3;
@@ -429,31 +470,46 @@ dibr_rows_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ 
         const int ox = sbs ? eye * g.ow + px : px, oy = sbs ? y : eye * g.oh + y;
         return (((long)b * g.out_h + oy) * g.out_w + ox) * nch;
     };
+#if defined(DIBR_CUT) && DIBR_CUT == 9      // (timing only: the staging and one dword store per thread)
+    if (x < g.ow) ((float*)out_all)[((long)b * g.out_h + y) * g.out_w * nch / 4 + x] = dibr_win[tid] + dibr_win[WW + tid] + dibr_win[2 * WW + tid];
+    if (qn >= 0) return;
+#endif
+#if defined(DIBR_CUT) && (DIBR_CUT == 7 || DIBR_CUT == 10)      // (timing only: the staging and the stores / 10: the stores)
+    if (x < g.ow) {
+        for (int eye = 0; eye < 2; ++eye) {
+            const float c[4] = {dibr_win[tid + eye], dibr_win[WW + tid], dibr_win[2 * WW + tid], 1.f};
+            dibr_store<OUT_FMT>(out_all, out_index(x, eye), nch, c);
+        }
+    }
+    if (qn >= 0) return;
+#endif
     // pass 1: every pixel up to the in-painting decision.  Disocclusions are thin (0.3-0.5 % of the pixels of a 1080p scene, but a
     // vertical depth edge crosses every row: 5-8 % of the waves): run in place, a wave with three such lanes walks the whole 24-tap
     // sweep at 5 % lane occupancy.  Those pixels are queued instead ...
     if (x < g.ow) {
+        const PixTaps taps = pix_taps(smp, g, x, y);
 #pragma unroll
         for (int eye = 0; eye < 2; ++eye) {
             float c[4];
-            if (dibr_pixel<true>(smp, g, x, y, eye, c)) queue[atomicAdd(&qn, 1)] = tid | (eye << 8);
+            if (dibr_pixel<true, true, FX>(smp, g, x, y, eye, c, &taps)) queue[atomicAdd(&qn, 1)] = tid | (eye << 8);
             else dibr_store<OUT_FMT>(out_all, out_index(x, eye), nch, c);
         }
     }
     __syncthreads();
-#if defined(DIBR_CUT) && DIBR_CUT == 6      // (timing only: no second pass)
+#if defined(DIBR_CUT) && (DIBR_CUT == 6 || DIBR_CUT == 8)      // (timing only: no second pass)
     if (qn >= 0) return;
 #endif
     // ... and pass 2 gives each queued pixel a lane of its own: the whole pixel function again, in-painting included (same inputs,
     // same expressions: the same bits as the single-pass kernel; the order of the queue does not matter, every entry is independent).
     // Measured at 1080p Full-SBS (tools/dibr_bench.py): in place 85.6 us, queued 73.7; everything but this pass 45 us -- what is left
-    // is one mostly-empty wave per block walking ~2 500 instructions.  Tried on top of it and not kept: queues shared by 2-8 rows with
+    // is one mostly-empty wave per block walking ~2 500 instructions.  Round 6 (profiles/r6_06): 50.5 us, 25 of them this pass; a
+    // launch-wide queue finished by a second kernel (one lane or sixteen lanes per pixel) was built and lost (31-47 us for that kernel).  Tried on top of it and not kept: queues shared by 2-8 rows with
     // the rows' windows kept in LDS or pass-2 taps by gather (fewer second-pass waves, but 99 VGPRs / 25 KB of LDS per block halve
     // the resident waves: 69-101 us at one frame, 45-98 us Half-SBS), sweep taps requested four at a time (no faster, +30 VGPRs).
     for (int q = tid; q < qn; q += 256) {
         const int e = queue[q], px = xb + (e & 255), eye = e >> 8;
         float c[4];
-        dibr_pixel<false>(smp, g, px, y, eye, c);
+        dibr_pixel<false, false, FX>(smp, g, px, y, eye, c);
         dibr_store<OUT_FMT>(out_all, out_index(px, eye), nch, c);
     }
 }
@@ -518,8 +574,14 @@ extern "C" int d2s_dibr_warp(const uint8_t* rgb, const float* depth, int batch, 
     if (roll0 && !no_rows.get() && WW <= 2048 && g.oh <= 65535) {
         dim3 rgrid(cdiv(g.ow, 256), g.oh, batch);
         const size_t lds = (size_t)8 * WW * sizeof(float);
-        if (out_fmt == D2S_FMT_U8_HWC) hipLaunchKernelGGL((dibr_rows_kernel<D2S_FMT_U8_HWC>), rgrid, block, lds, (hipStream_t)stream, rgb, depth, out, g, margin, WW);
-        else hipLaunchKernelGGL((dibr_rows_kernel<D2S_FMT_F32_HWC>), rgrid, block, lds, (hipStream_t)stream, rgb, depth, out, g, margin, WW);
+        const bool fx = g.feather || g.corner_r > 0.f;
+        if (out_fmt == D2S_FMT_U8_HWC) {
+            if (fx) hipLaunchKernelGGL((dibr_rows_kernel<D2S_FMT_U8_HWC, true>), rgrid, block, lds, (hipStream_t)stream, rgb, depth, out, g, margin, WW);
+            else hipLaunchKernelGGL((dibr_rows_kernel<D2S_FMT_U8_HWC, false>), rgrid, block, lds, (hipStream_t)stream, rgb, depth, out, g, margin, WW);
+        } else {
+            if (fx) hipLaunchKernelGGL((dibr_rows_kernel<D2S_FMT_F32_HWC, true>), rgrid, block, lds, (hipStream_t)stream, rgb, depth, out, g, margin, WW);
+            else hipLaunchKernelGGL((dibr_rows_kernel<D2S_FMT_F32_HWC, false>), rgrid, block, lds, (hipStream_t)stream, rgb, depth, out, g, margin, WW);
+        }
     } else if (out_fmt == D2S_FMT_U8_HWC) {
         if (roll0) hipLaunchKernelGGL((dibr_kernel<D2S_FMT_U8_HWC, true>), grid, block, 0, (hipStream_t)stream, rgb, depth, out, g);
         else hipLaunchKernelGGL((dibr_kernel<D2S_FMT_U8_HWC, false>), grid, block, 0, (hipStream_t)stream, rgb, depth, out, g);
