@@ -8,13 +8,17 @@
 // jcmarker.c), so the stream is BYTE-IDENTICAL to libjpeg-turbo's (oracle/jpeg_oracle.py pins that).
 //
 // Stages (all HBM-/latency-bound byte work; one grid dimension = frame; no single-block pass, no host sync):
-//   1 jpeg_dct_kernel            16 MCUs (256x16 px) per block: RGB -> YCbCr (+h2v2), FDCT, quantise, zigzag, dummy
+//   1 jpeg_dct_kernel            8 MCUs (128x16 px) per block: RGB -> YCbCr (+h2v2), FDCT, quantise, zigzag, dummy
 //                                blocks; writes int16 coefficients [mcu][6][64] and the DCs [mcu][8]
 //   2 jpeg_count_kernel          (round 5) the AC bit count of a block is taken in stage 1 while the block is in LDS; this pass adds the
-//                                DC term (needs the predecessor's DC) -> bits per block, bits per 256-block tile
-//   3 jpeg_zero_kernel           zero the words of the (unstuffed) bit stream that will be used; publish the total
-//   4 jpeg_entropy_kernel<true>  same walk, emitting: offset = tile prefix + in-block scan; whole words are plain
-//                                stores, the two edge words of a block are atomic ORs
+//                                DC term (needs the predecessor's DC) -> bits per block, bits per 256-block tile, and (round 6) the first
+//                                bit of every block within its tile
+//   3 jpeg_zero_kernel           zero the words of the (unstuffed) bit stream that will be used; publish the total and (round 6) the
+//                                first bit of every tile
+//   4 jpeg_emit8_kernel          (round 6, up to a few frames per launch) eight lanes per 8x8 block, runs from the block's non-zero mask,
+//                                the thread block's span of the stream assembled in LDS and written out as whole words;
+//     jpeg_entropy_kernel<true>  (larger batches) one lane per block walks it: offset = tile prefix + in-block scan; whole words are
+//                                plain stores, the two edge words of a block are atomic ORs
 //   5 jpeg_ffcount_kernel        0xFF bytes per 64-byte chunk and per 256-chunk tile
 //   6 jpeg_stuff_kernel          byte-stuffed copy behind the header (+ header, EOI, size from block 0), staged through LDS so that
 //                                global memory sees aligned 16-byte stores (round 5)
@@ -120,7 +124,7 @@ struct JpegGeom {
     int ybw, ybh;                    // real luma blocks across / down
     int He;                          // H rounded up to even (the rows the chroma planes are derived from)
     long ws_frame;                   // workspace bytes per frame
-    long off_blkbits, off_dcs, off_tiles, off_total, off_stream, off_ffcnt, off_fftiles;
+    long off_blkbits, off_dcs, off_tiles, off_total, off_stream, off_ffcnt, off_fftiles, off_blkoff, off_tpre;
     long cap_words;                  // words of the unstuffed stream buffer
     int n_chunks;                    // 64-byte chunks of it
 };
@@ -142,12 +146,17 @@ static JpegGeom make_geom(int H, int W) {
     g.off_stream = o; o = al(o + g.cap_words * 4);
     g.off_ffcnt = o; o = al(o + (long)(g.n_chunks + 1) * 4);
     g.off_fftiles = o; o = al(o + ((long)g.n_chunks / 256 + 2) * 4);
+    g.off_blkoff = o; o = al(o + (long)g.nmcu * 6 * 4 + 16);         // first bit of every block within its 256-block tile (round 6)
+    g.off_tpre = o; o = al(o + ((long)g.nmcu * 6 / 256 + 2) * 4);     // first bit of every tile (round 6)
     g.ws_frame = o;
     return g;
 }
 
 // ---- stage 1 -----------------------------------------------------------------------------------
-constexpr int DCT_MCUS = 16;             // MCUs per thread block (256 px x 16 rows)
+#ifndef D2S_DCT_MCUS
+#define D2S_DCT_MCUS 8             // (round 6, 3840x1080 q90: 16 -> 28.1 us, 8 -> 27.1, 4 -> 25.8 at one frame; 16 frames: 32.1 / 29.9 / 32.5 us per frame)
+#endif
+constexpr int DCT_MCUS = D2S_DCT_MCUS;   // MCUs per thread block (128 px x 16 rows)
 constexpr int DCT_BLOCKS = DCT_MCUS * 6;
 
 template <int FMT>
@@ -507,6 +516,140 @@ jpeg_entropy_kernel(uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
     if (s.fill > 0 && s.acc) atomicOr(&s.stream[s.w], s.acc);
 }
 
+// stage 4, round 6: EIGHT lanes per 8x8 block.  The one-lane-per-block walk above is a serial chain of 63 table look-ups and
+// data-dependent word stores per lane, on 97 200 threads for a 3840x1080 frame (0.37 of the chip's thread slots): latency, 24.6 us.
+// Here lane j of a group of eight owns the zigzag coefficients 8j .. 8j+7 (one 16-byte load):
+//   * the group ORs its lanes' non-zero masks into one 64-bit mask; the zero run in front of coefficient k is then the distance to the
+//     next lower set bit (bit 0 = the DC stands in for "no run pending"), so no lane waits for its predecessor -- ZRL codes (run > 15)
+//     and the end-of-block code (coefficient 63 is zero) fall out of the same mask, exactly as jchuff.c encode_one_block emits them;
+//   * a lane works out its codes once (registers), an exclusive scan of the lanes' bit totals places it, and it ORs every code into an
+//     LDS image of the thread block's span of the stream (32 blocks, <= 32 * BLK_WORDS words), at most two words per code;
+//   * the image goes out as whole words: plain stores, except the first and the last word, which the neighbouring thread blocks share
+//     (atomic OR into the zeroed stream: two per thread block instead of two per 8x8 block).
+// The same bits as jpeg_entropy_kernel<true> (D2S_JPEG_EMIT8=0 selects it; tests/test_gpu_jpeg.py compares the two and Pillow).
+constexpr int EMIT8_BLOCKS = 32;                          // 8x8 blocks per thread block
+constexpr int EMIT8_WORDS = EMIT8_BLOCKS * BLK_WORDS;     // the LDS image (worst case: every block at its 1 660-bit maximum)
+
+// one code (len <= 27 bits, MSB first) at bit p of the LDS image: at most two words
+__device__ __forceinline__ void put8(uint32_t* img, uint32_t& p, uint32_t val, int len) {
+    const unsigned long long x = (unsigned long long)val << (64 - (int)(p & 31u) - len);
+    const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+    if (hi) atomicOr(&img[p >> 5], hi);
+    if (lo) atomicOr(&img[(p >> 5) + 1], lo);
+    p += (uint32_t)len;
+}
+// the codes of a lane's eight coefficients c[0..7] = zigzag 8j .. 8j+7 (lane 0: c[0] is the DC, coded from dcdiff), worked out ONCE:
+// code / length per coefficient (length 0: a zero), the ZRL codes in front of it, the lane's total -- then emitted from these registers
+struct Lane8 { uint32_t code[8]; uint8_t len[8], zrl[8]; uint32_t dccode, eob; int dclen, eoblen; uint32_t total; };
+__device__ __forceinline__ void analyse_lane8(Lane8& L, int j, const int (&c)[8], unsigned long long mask, int dcdiff,
+                                              const uint32_t* dc, const uint32_t* ac) {
+    L.total = 0; L.dclen = 0; L.dccode = 0; L.eoblen = 0; L.eob = 0;
+    if (j == 0) {
+        const int a = dcdiff < 0 ? -dcdiff : dcdiff, t2 = dcdiff < 0 ? dcdiff - 1 : dcdiff;
+        const int nb = a ? 32 - __builtin_clz(a) : 0;
+        const uint32_t e = dc[nb];
+        L.dccode = ((e & 0xffffu) << nb) | ((uint32_t)t2 & ((1u << nb) - 1u));
+        L.dclen = (int)(e >> 16) + nb;
+        L.total = (uint32_t)L.dclen;
+    }
+    const unsigned long long mx = mask | 1ull;                                       // bit 0: the DC ends every run
+    const uint32_t zrl_len = ac[0xF0] >> 16;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int v = c[t], k = 8 * j + t;
+        L.len[t] = 0; L.zrl[t] = 0; L.code[t] = 0;
+        if (v == 0 || k == 0) continue;
+        const unsigned long long below = mx & ((1ull << k) - 1ull);
+        const int run = k - (63 - __builtin_clzll(below)) - 1;
+        const int a = v < 0 ? -v : v, t2 = v < 0 ? v - 1 : v;
+        const int nb = 32 - __builtin_clz(a);
+        const uint32_t e = ac[((run & 15) << 4) | nb];
+        L.code[t] = ((e & 0xffffu) << nb) | ((uint32_t)t2 & ((1u << nb) - 1u));
+        L.len[t] = (uint8_t)((e >> 16) + (uint32_t)nb);
+        L.zrl[t] = (uint8_t)(run >> 4);                                              // jchuff.c: while (r > 15) emit 0xF0
+        L.total += (uint32_t)L.len[t] + (uint32_t)L.zrl[t] * zrl_len;
+    }
+    if (j == 7 && !(mask >> 63)) { L.eob = ac[0] & 0xffffu; L.eoblen = (int)(ac[0] >> 16); L.total += (uint32_t)L.eoblen; }   // end of block
+}
+__device__ __forceinline__ void emit_lane8(const Lane8& L, uint32_t* img, uint32_t& p, const uint32_t* ac) {
+    if (L.dclen) put8(img, p, L.dccode, L.dclen);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (!L.len[t]) continue;
+        for (int z = 0; z < (int)L.zrl[t]; ++z) put8(img, p, ac[0xF0] & 0xffffu, (int)(ac[0xF0] >> 16));
+        put8(img, p, L.code[t], (int)L.len[t]);
+    }
+    if (L.eoblen) put8(img, p, L.eob, L.eoblen);
+}
+
+__global__ void __launch_bounds__(256)
+jpeg_emit8_kernel(uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
+    __shared__ uint32_t sAc[2][256];
+    __shared__ uint32_t sDc[2][12];
+    __shared__ uint32_t img[EMIT8_WORDS + 1];
+    const int tid = threadIdx.x, grp = tid >> 3, j = tid & 7;
+    for (int i = tid; i < 512; i += 256) sAc[i >> 8][i & 255] = tb.ac[i >> 8][i & 255];
+    if (tid < 24) sDc[tid / 12][tid % 12] = tb.dc[tid / 12][tid % 12];
+    for (int i = tid; i < EMIT8_WORDS + 1; i += 256) img[i] = 0;
+    uint8_t* wsf = ws + (long)blockIdx.y * g.ws_frame;
+    const long nblk = (long)g.nmcu * 6;
+    const long gb0 = (long)blockIdx.x * EMIT8_BLOCKS, gb = gb0 + grp;
+    const bool active = gb < nblk;
+    const long gbc = active ? gb : nblk - 1;
+    const uint16_t* blkbits = (const uint16_t*)(wsf + g.off_blkbits);
+    // where the blocks start: the tile's first bit (jpeg_zero_kernel) + the block's first bit within its tile (jpeg_count_kernel)
+    const long m = gbc / 6;
+    const int b = (int)(gbc % 6), tbl = b >= 4;
+    const uint4 q = ((const uint4*)wsf)[gbc * 8 + j];                  // (requested before the barrier: one round trip for everything)
+    const uint32_t* blkoff = (const uint32_t*)(wsf + g.off_blkoff);
+    const uint32_t* tpre = (const uint32_t*)(wsf + g.off_tpre);
+    const long gbl = min(gb0 + EMIT8_BLOCKS, nblk) - 1;                // the span's last block (same tile: 256 % 32 == 0)
+    const uint32_t t0 = tpre[gb0 >> 8];
+    const uint32_t G0 = t0 + blkoff[gb0];                              // first bit of the span; the image's word 0 is stream word G0 >> 5
+    const uint32_t Gb = t0 + blkoff[gbc];                              // first bit of this group's block
+    uint32_t span = t0 + blkoff[gbl] + (uint32_t)blkbits[gbl] - G0;
+    const int pred = j == 0 ? dc_pred((const short*)(wsf + g.off_dcs), m, b) : 0;
+    __syncthreads();
+    const bool last_tb = gb0 + EMIT8_BLOCKS >= nblk;
+    const uint32_t pad = last_tb ? (8u - ((G0 + span) & 7u)) & 7u : 0u;                               // jchuff.c flush_bits
+    // this lane's coefficients, the block's non-zero mask
+    const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+    int c[8];
+    uint32_t m8 = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        c[t] = (int)(short)((t & 1) ? (qw[t >> 1] >> 16) : (qw[t >> 1] & 0xffffu));
+        m8 |= (uint32_t)(c[t] != 0) << t;
+    }
+    if (j == 0) m8 &= ~1u;
+    uint32_t mlo = j < 4 ? m8 << (8 * j) : 0u, mhi = j >= 4 ? m8 << (8 * (j - 4)) : 0u;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { mlo |= __shfl_xor(mlo, o); mhi |= __shfl_xor(mhi, o); }
+    const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+    const int dcdiff = c[0] - pred;                                     // (lane 0 only)
+    Lane8 L;
+    analyse_lane8(L, j, c, mask, dcdiff, sDc[tbl], sAc[tbl]);
+    uint32_t inc = L.total;                                            // exclusive scan over the group's eight lanes
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (j >= o) inc += u; }
+    if (active) {
+        uint32_t pos = Gb - (G0 & ~31u) + inc - L.total;               // bit position in the image
+        emit_lane8(L, img, pos, sAc[tbl]);
+        if (pad && gb == nblk - 1 && j == 7) put8(img, pos, (1u << pad) - 1u, (int)pad);
+    }
+    __syncthreads();
+    span += pad;
+    uint32_t* stream = (uint32_t*)(wsf + g.off_stream) + (G0 >> 5);
+    const uint32_t endbit = (G0 & 31u) + span;
+    const int nwords = (int)((endbit + 31u) >> 5);
+    for (int i = tid; i < nwords; i += 256) {
+        const uint32_t v = img[i];
+        const bool shared = (i == 0 && (G0 & 31u)) || (i == nwords - 1 && (endbit & 31u));
+        if (shared) { if (v) atomicOr(&stream[i], v); }
+        else stream[i] = v;
+    }
+}
+
 // stage 2 (round 5): bits per block = the AC bits jpeg_dct_kernel left in blkbits[] + the DC term (needs the predecessor's DC, which
 // may belong to another thread block of stage 1); bits per 256-block tile.  Reads 2 + 2 bytes per block instead of 128.
 __global__ void __launch_bounds__(256)
@@ -529,6 +672,8 @@ jpeg_count_kernel(uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
         bits = (uint32_t)blkbits[gb] + (tb.dc[tbl][nb] >> 16) + (uint32_t)nb;
         blkbits[gb] = (uint16_t)bits;
     }
+    const uint32_t off = block256_exscan(bits, s_w);                   // (round 6) where the block starts within its tile: the emit reads it
+    if (active) ((uint32_t*)(wsf + g.off_blkoff))[gb] = off;
     const uint32_t sum = block256_sum(bits, s_w);
     if (tid == 0) ((uint32_t*)(wsf + g.off_tiles))[blockIdx.x] = sum;
 }
@@ -542,6 +687,19 @@ jpeg_zero_kernel(uint8_t* __restrict__ ws, JpegGeom g) {
     tile_prefix((const uint32_t*)(wsf + g.off_tiles), cdiv_dev((long)g.nmcu * 6, 256), 0, s_w, prefix, total);
     total = (total + 7u) & ~7u;                                       // flush_bits pads the last byte with 1-bits
     if (blockIdx.x == 0 && threadIdx.x == 0) *(uint32_t*)(wsf + g.off_total) = total;
+    if (blockIdx.x == 0) {                                            // (round 6) first bit of every tile, for the emit
+        const uint32_t* tiles = (const uint32_t*)(wsf + g.off_tiles);
+        uint32_t* tpre = (uint32_t*)(wsf + g.off_tpre);
+        const int n = cdiv_dev((long)g.nmcu * 6, 256);
+        uint32_t carry = 0;
+        for (int base = 0; base < n; base += 256) {                   // (block-uniform trip count)
+            const int i = base + (int)threadIdx.x;
+            const uint32_t v = i < n ? tiles[i] : 0u;
+            const uint32_t ex = block256_exscan(v, s_w);
+            if (i < n) tpre[i] = carry + ex;
+            carry += block256_sum(v, s_w);
+        }
+    }
     long used = ((long)total + 31) / 32 + 4;                          // + slack: the last chunk is read whole
     used = min((used + 15) / 16 * 16, g.cap_words);
     const long base = (long)blockIdx.x * 4096;                        // 4096 words per block, 4 x 16 bytes per thread
@@ -687,7 +845,13 @@ extern "C" int d2s_jpeg_encode(const void* frames, int fmt, int batch, int H, in
     const dim3 ge(cdiv((long)g.nmcu * 6, 256), batch), gc(cdiv(g.n_chunks, 256), batch);
     hipLaunchKernelGGL(jpeg_count_kernel, ge, dim3(256), 0, st, ws, g, tb);
     hipLaunchKernelGGL(jpeg_zero_kernel, dim3(cdiv(g.cap_words, 4096), batch), dim3(256), 0, st, ws, g);
-    hipLaunchKernelGGL(jpeg_entropy_kernel<true>, ge, dim3(256), 0, st, ws, g, tb);
+    // Eight lanes per block when the launch would otherwise leave the chip short of threads (one lane per block: 97 200 threads for a
+    // 3840x1080 frame; 23.2 -> 15.8 us); from a few frames per launch on, the one-lane walk fills the chip by itself and issues fewer
+    // instructions on sparse blocks (16 frames of a smooth scene: 28.5 against 35.3 us per frame).  D2S_JPEG_EMIT8 = 0 / 1 forces one.
+    static EnvInt emit8_env{"D2S_JPEG_EMIT8", -1};
+    const bool emit8 = emit8_env.get() < 0 ? (long)batch * g.nmcu * 6 < 300000 : emit8_env.get() != 0;
+    if (emit8) hipLaunchKernelGGL(jpeg_emit8_kernel, dim3(cdiv((long)g.nmcu * 6, EMIT8_BLOCKS), batch), dim3(256), 0, st, ws, g, tb);
+    else hipLaunchKernelGGL(jpeg_entropy_kernel<true>, ge, dim3(256), 0, st, ws, g, tb);
     hipLaunchKernelGGL(jpeg_ffcount_kernel, gc, dim3(256), 0, st, ws, g);
     hipLaunchKernelGGL(jpeg_stuff_kernel, gc, dim3(256), 0, st, (const uint8_t*)ws, g, tb, out, (long)out_stride, sizes);
     D2S_CHECK_LAUNCH();

@@ -165,3 +165,49 @@ def test_property_gpu_equals_libjpeg_turbo():
         assert sink.encode_jpeg(frame, q) == buf.getvalue(), (h, w, q, kind, as_float)
 
     check()
+
+
+def test_eight_lane_emit_equals_the_one_lane_emit(monkeypatch):
+    """Round 6: stage 4 (the entropy emit) gives every 8x8 block eight lanes -- runs from the block's non-zero mask, lane offsets from a
+    scan, an LDS image of the thread block's span written out as whole words.  D2S_JPEG_EMIT8=0 is the one-lane-per-block walk of rounds
+    1-5: the same bytes, on noise (dense codes), flat frames (4-6 bits per block: many blocks per stream word), smooth content at low
+    quality (zero runs > 15: ZRL codes), sizes that end a thread block after one 8x8 block, and a batch."""
+    from desktop2stereo_amd import ops
+    rng = np.random.default_rng(5)
+    frames = []
+    for (H, W, kind) in [(8, 8, "noise"), (16, 16, "flat"), (17, 33, "noise"), (64, 48, "smooth"), (120, 200, "flat"), (270, 480, "noise"),
+                         (270, 480, "smooth"), (1080, 3840, "noise"), (1080, 3840, "smooth"), (96, 96, "edges")]:
+        if kind == "noise":
+            f = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        elif kind == "flat":
+            f = np.full((H, W, 3), 77, np.uint8)
+        elif kind == "smooth":
+            yy, xx = np.mgrid[0:H, 0:W]
+            f = np.stack([(xx // 3) % 256, (yy // 2) % 256, ((xx + yy) // 5) % 256], -1).astype(np.uint8)
+        else:
+            f = np.zeros((H, W, 3), np.uint8); f[::7, ::5] = 255; f[3::11] = 200
+        frames.append(f)
+    try:
+        for f in frames:
+            for q in (90, 100, 25, 5):
+                dev = torch.from_numpy(f).cuda()[None]
+                res = {}
+                for flag in ("1", "0"):
+                    monkeypatch.setenv("D2S_JPEG_EMIT8", flag)
+                    ops.reload_env()
+                    out, sizes = ops.jpeg_encode(dev, q)
+                    n = int(sizes[0])
+                    assert n > 0
+                    res[flag] = out[0, :n].cpu().numpy().tobytes()
+                assert res["1"] == res["0"], (f.shape, q, len(res["1"]), len(res["0"]))
+        batch = torch.from_numpy(np.stack([rng.integers(0, 256, (136, 248, 3), dtype=np.uint8) for _ in range(5)])).cuda()
+        got = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("D2S_JPEG_EMIT8", flag)
+            ops.reload_env()
+            out, sizes = ops.jpeg_encode(batch, 80)
+            got[flag] = [out[i, :int(sizes[i])].cpu().numpy().tobytes() for i in range(5)]
+        assert got["1"] == got["0"]
+    finally:
+        monkeypatch.delenv("D2S_JPEG_EMIT8", raising=False)
+        ops.reload_env()
