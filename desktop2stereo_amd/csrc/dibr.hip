@@ -433,12 +433,14 @@ dibr_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ dep_a
 #ifndef DIBR_WAVES
 #define DIBR_WAVES 7                  // (<= 72 VGPRs: 5 -> 7 waves per SIMD, 73.8 -> 69.0 us in round 5; 8: no faster.  FX = false: 71 VGPRs, no scratch)
 #endif
-template <int OUT_FMT, bool FX>
+// COLS (round 6): output columns per block, 256 per thread-pass.  The second pass costs one mostly-empty wave per block that has
+// queued pixels whatever their number; a block twice as wide halves those waves (and stages a window 2 x as wide once).
+template <int OUT_FMT, bool FX, int COLS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIBR_WAVES)))
 dibr_rows_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ dep_all, void* __restrict__ out_all, DibrGeom g, int margin, int WW) {
     extern __shared__ float dibr_win[];                // [2][WW] the row pair of the depth texture | [6][WW] R0 G0 B0 R1 G1 B1 as floats
-    __shared__ int queue[512], qn;                     // column - xb | eye << 8 of the pixels that need the in-painting
-    const int tid = threadIdx.x, xb = blockIdx.x * 256, x = xb + tid;
+    __shared__ int queue[2 * COLS], qn;                // (column - xb) * 2 + eye of the pixels that need the in-painting
+    const int tid = threadIdx.x, xb = blockIdx.x * COLS;
     const int y = blockIdx.y, b = blockIdx.z;
     const uint8_t* rgb = rgb_all + (long)b * g.H * g.W * 3;
     const float* dep = dep_all + (long)b * g.H * g.W;
@@ -470,6 +472,9 @@ dibr_rows_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ 
         const int ox = sbs ? eye * g.ow + px : px, oy = sbs ? y : eye * g.oh + y;
         return (((long)b * g.out_h + oy) * g.out_w + ox) * nch;
     };
+#if defined(DIBR_CUT)
+    const int x = xb + tid;
+#endif
 #if defined(DIBR_CUT) && DIBR_CUT == 9      // (timing only: the staging and one dword store per thread)
     if (x < g.ow) ((float*)out_all)[((long)b * g.out_h + y) * g.out_w * nch / 4 + x] = dibr_win[tid] + dibr_win[WW + tid] + dibr_win[2 * WW + tid];
     if (qn >= 0) return;
@@ -486,12 +491,14 @@ dibr_rows_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ 
     // pass 1: every pixel up to the in-painting decision.  Disocclusions are thin (0.3-0.5 % of the pixels of a 1080p scene, but a
     // vertical depth edge crosses every row: 5-8 % of the waves): run in place, a wave with three such lanes walks the whole 24-tap
     // sweep at 5 % lane occupancy.  Those pixels are queued instead ...
-    if (x < g.ow) {
+    for (int cx = tid; cx < COLS; cx += 256) {
+        const int x = xb + cx;
+        if (x >= g.ow) break;
         const PixTaps taps = pix_taps(smp, g, x, y);
 #pragma unroll
         for (int eye = 0; eye < 2; ++eye) {
             float c[4];
-            if (dibr_pixel<true, true, FX>(smp, g, x, y, eye, c, &taps)) queue[atomicAdd(&qn, 1)] = tid | (eye << 8);
+            if (dibr_pixel<true, true, FX>(smp, g, x, y, eye, c, &taps)) queue[atomicAdd(&qn, 1)] = cx * 2 + eye;
             else dibr_store<OUT_FMT>(out_all, out_index(x, eye), nch, c);
         }
     }
@@ -507,7 +514,7 @@ dibr_rows_kernel(const uint8_t* __restrict__ rgb_all, const float* __restrict__ 
     // the rows' windows kept in LDS or pass-2 taps by gather (fewer second-pass waves, but 99 VGPRs / 25 KB of LDS per block halve
     // the resident waves: 69-101 us at one frame, 45-98 us Half-SBS), sweep taps requested four at a time (no faster, +30 VGPRs).
     for (int q = tid; q < qn; q += 256) {
-        const int e = queue[q], px = xb + (e & 255), eye = e >> 8;
+        const int e = queue[q], px = xb + (e >> 1), eye = e & 1;
         float c[4];
         dibr_pixel<false, false, FX>(smp, g, px, y, eye, c);
         dibr_store<OUT_FMT>(out_all, out_index(px, eye), nch, c);
@@ -572,16 +579,23 @@ extern "C" int d2s_dibr_warp(const uint8_t* rgb, const float* depth, int batch, 
     const int margin = (int)ceil(reach) + 2;
     const int WW = (int)ceil(255.0 * (double)W / (double)g.ow) + 2 * margin + 4;
     if (roll0 && !no_rows.get() && WW <= 2048 && g.oh <= 65535) {
-        dim3 rgrid(cdiv(g.ow, 256), g.oh, batch);
-        const size_t lds = (size_t)8 * WW * sizeof(float);
+        // columns per block: 512 while the window stays <= 640 texels (20 KB of LDS: seven blocks per CU either way).  1080p Full-SBS
+        // 50.8 -> 46.8 us (half the second-pass waves); Half-SBS (two source texels per column) keeps 256: 24.4 us against 26.8;
+        // 1024 columns: 63.9 us (34 KB per block).  D2S_DIBR_COLS = 256 | 512 | 1024 caps it (A/B aid).
+        static EnvInt cols_env{"D2S_DIBR_COLS", 512};
+        int cols = cols_env.get() >= 1024 ? 1024 : (cols_env.get() >= 512 ? 512 : 256);
+        auto win_words = [&](int c) { return (int)ceil((double)(c - 1) * (double)W / (double)g.ow) + 2 * margin + 4; };
+        while (cols > 256 && (win_words(cols) > (cols_env.get() >= 1024 ? 2048 : 640) || g.ow <= cols / 2)) cols >>= 1;
+        const int WWc = win_words(cols);
+        dim3 rgrid(cdiv(g.ow, cols), g.oh, batch);
+        const size_t lds = (size_t)8 * WWc * sizeof(float);
         const bool fx = g.feather || g.corner_r > 0.f;
-        if (out_fmt == D2S_FMT_U8_HWC) {
-            if (fx) hipLaunchKernelGGL((dibr_rows_kernel<D2S_FMT_U8_HWC, true>), rgrid, block, lds, (hipStream_t)stream, rgb, depth, out, g, margin, WW);
-            else hipLaunchKernelGGL((dibr_rows_kernel<D2S_FMT_U8_HWC, false>), rgrid, block, lds, (hipStream_t)stream, rgb, depth, out, g, margin, WW);
-        } else {
-            if (fx) hipLaunchKernelGGL((dibr_rows_kernel<D2S_FMT_F32_HWC, true>), rgrid, block, lds, (hipStream_t)stream, rgb, depth, out, g, margin, WW);
-            else hipLaunchKernelGGL((dibr_rows_kernel<D2S_FMT_F32_HWC, false>), rgrid, block, lds, (hipStream_t)stream, rgb, depth, out, g, margin, WW);
-        }
+#define DIBR_ROWS(FMT, FXV, COLS) hipLaunchKernelGGL((dibr_rows_kernel<FMT, FXV, COLS>), rgrid, block, lds, (hipStream_t)stream, rgb, depth, out, g, margin, WWc)
+#define DIBR_ROWS_C(FMT, FXV) do { if (cols == 1024) DIBR_ROWS(FMT, FXV, 1024); else if (cols == 512) DIBR_ROWS(FMT, FXV, 512); else DIBR_ROWS(FMT, FXV, 256); } while (0)
+        if (out_fmt == D2S_FMT_U8_HWC) { if (fx) DIBR_ROWS_C(D2S_FMT_U8_HWC, true); else DIBR_ROWS_C(D2S_FMT_U8_HWC, false); }
+        else { if (fx) DIBR_ROWS_C(D2S_FMT_F32_HWC, true); else DIBR_ROWS_C(D2S_FMT_F32_HWC, false); }
+#undef DIBR_ROWS_C
+#undef DIBR_ROWS
     } else if (out_fmt == D2S_FMT_U8_HWC) {
         if (roll0) hipLaunchKernelGGL((dibr_kernel<D2S_FMT_U8_HWC, true>), grid, block, 0, (hipStream_t)stream, rgb, depth, out, g);
         else hipLaunchKernelGGL((dibr_kernel<D2S_FMT_U8_HWC, false>), grid, block, 0, (hipStream_t)stream, rgb, depth, out, g);

@@ -157,11 +157,12 @@ def test_dibr_matches_reference_shader_renders(dev, golden_dir):
 def test_dibr_row_kernels_are_bit_identical_to_the_gather_kernel(dev, monkeypatch):
     """roll == 0 (the desktop viewer) has two faster paths: the gather kernel forming the y half of every texture tap once per pixel
     (row_ctx), and the LDS-window kernel (a block stages its two texture rows once, both eyes; taps are LDS reads at a window index,
-    taps beyond the window fall back to the row gather).  Same expressions on the same operands, so all three must agree bit for bit --
+    taps beyond the window fall back to the row gather; 256, 512 or 1 024 output columns per block; the five shift-independent depth
+    taps of a column shared by its two eyes; feather / corner code compiled out when both are off).  Same expressions on the same operands, so all three must agree bit for bit --
     float32 output, all four modes, hard depth edges (the in-painting's sweeps), convergence, feathering + rounded corners, a
     non-default u_resolution, rgba, a strong parallax, and a depth map beyond 0..1 (shifts past the window margin: the fallback)."""
     from desktop2stereo_amd import ops, synth
-    keys = ("D2S_DIBR_NO_ROLL0", "D2S_DIBR_NO_ROWS")
+    keys = ("D2S_DIBR_NO_ROLL0", "D2S_DIBR_NO_ROWS", "D2S_DIBR_COLS")
     try:
         for (H, W, seed, dscale, kw) in [(270, 480, 3, 1.0, {}), (180, 322, 4, 1.0, dict(convergence=0.03, feather=True, corner_radius=0.03)),
                                          (1080, 1920, 5, 1.0, dict(depth_ratio=3.0)), (200, 300, 6, 1.0, dict(resolution=(640.0, 360.0), alpha="rgba")),
@@ -171,14 +172,15 @@ def test_dibr_row_kernels_are_bit_identical_to_the_gather_kernel(dev, monkeypatc
             for mode in ("Full-SBS", "Half-SBS", "Full-TAB", "Half-TAB"):
                 dp = ops.dibr_params(display_mode=mode, **kw)
                 outs = {}
-                for name, env in (("rows", {}), ("row_gather", {"D2S_DIBR_NO_ROWS": "1"}), ("general", {"D2S_DIBR_NO_ROLL0": "1"})):
+                for name, env in (("rows", {}), ("rows_256", {"D2S_DIBR_COLS": "256"}), ("rows_1024", {"D2S_DIBR_COLS": "1024"}),
+                                  ("row_gather", {"D2S_DIBR_NO_ROWS": "1"}), ("general", {"D2S_DIBR_NO_ROLL0": "1"})):
                     for k in keys:
                         monkeypatch.delenv(k, raising=False)
                     for k, v in env.items():
                         monkeypatch.setenv(k, v)
                     ops.reload_env()
                     outs[name] = ops.dibr_warp(f, d, dp, out_u8=False).cpu().numpy()
-                for name in ("rows", "row_gather"):
+                for name in ("rows", "rows_256", "rows_1024", "row_gather"):
                     assert np.array_equal(outs[name], outs["general"]), (H, W, mode, kw, name, float(np.abs(outs[name] - outs["general"]).max()))
                 u8 = ops.dibr_warp(f, d, dp).cpu().numpy()              # (env: general) and the uint8 store of the window kernel
                 for k in keys:
