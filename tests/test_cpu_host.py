@@ -170,7 +170,8 @@ def test_bench_compact_line_is_small_and_complete():
     spec = importlib.util.spec_from_file_location("d2s_bench_for_test", os.path.join(repo, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    full_path = os.path.join(repo, "profiles", "r6_05_bench_driver_cmd_full.json")
+    import glob
+    full_path = sorted(glob.glob(os.path.join(repo, "profiles", "r*_bench_driver_cmd_full.json")))[-1]      # the latest evidence round's report
     with open(full_path) as f:
         full = json.load(f)
     c = bench.compact_line(full, os.path.join(repo, "gpurun_out", "bench_full.json"))
