@@ -176,7 +176,7 @@ def test_eight_lane_emit_equals_the_one_lane_emit(monkeypatch):
     rng = np.random.default_rng(5)
     frames = []
     for (H, W, kind) in [(8, 8, "noise"), (16, 16, "flat"), (17, 33, "noise"), (64, 48, "smooth"), (120, 200, "flat"), (270, 480, "noise"),
-                         (270, 480, "smooth"), (1080, 3840, "noise"), (1080, 3840, "smooth"), (96, 96, "edges")]:
+                         (270, 480, "smooth"), (1080, 3840, "noise"), (1080, 3840, "smooth"), (96, 96, "edges"), (2160, 3840, "noise"), (2161, 3833, "smooth")]:
         if kind == "noise":
             f = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         elif kind == "flat":
