@@ -220,8 +220,11 @@ __global__ void __launch_bounds__(256)
 jpeg_dct_kernel(const void* __restrict__ frames, uint8_t* __restrict__ ws, JpegGeom g, JpegTables tb) {
     __shared__ __attribute__((aligned(16))) uint8_t sY[16][DCT_MCUS * 16];
     __shared__ __attribute__((aligned(16))) uint8_t sC[2][8][DCT_MCUS * 8];
-    __shared__ short sW[DCT_BLOCKS][64];       // row-pass output: |x| <= 1024 << PASS1_BITS, fits int16
-    __shared__ __attribute__((aligned(16))) short sZ[DCT_BLOCKS][64];
+    // (round 6: rows of 72 shorts = 36 dwords.  With 64-short rows the eight 8x8 blocks of a wave sit 32 dwords apart -- two bank
+    //  positions for eight blocks -- and the column reads of pass 2 / the zigzag writes ran 4-way conflicted: PMC, LDS bank conflict
+    //  cycles 0.48 of the active ones.  36 b mod 64 puts the eight blocks on eight disjoint groups of four banks.)
+    __shared__ __attribute__((aligned(16))) short sW[DCT_BLOCKS][72];       // row-pass output: |x| <= 1024 << PASS1_BITS, fits int16
+    __shared__ __attribute__((aligned(16))) short sZ[DCT_BLOCKS][72];
     __shared__ uint16_t sQ8[2][64];
     __shared__ uint32_t sMagic[2][64];
     __shared__ uint8_t sN2Z[64];
@@ -279,7 +282,10 @@ jpeg_dct_kernel(const void* __restrict__ frames, uint8_t* __restrict__ ws, JpegG
         const uint2 px = b < 4 ? *(const uint2*)&sY[(b >> 1) * 8 + r][m * 16 + (b & 1) * 8] : *(const uint2*)&sC[b - 4][r][m * 8];
         for (int i = 0; i < 4; ++i) { d[i] = (int)((px.x >> (8 * i)) & 255) - 128; d[4 + i] = (int)((px.y >> (8 * i)) & 255) - 128; }
         fdct8<true>(d);
-        for (int i = 0; i < 8; ++i) sW[blk][r * 8 + i] = (short)d[i];
+        uint4 pk;                                                     // the row's eight int16 as one 16-byte store
+        pk.x = ((uint32_t)d[0] & 0xffffu) | ((uint32_t)d[1] << 16); pk.y = ((uint32_t)d[2] & 0xffffu) | ((uint32_t)d[3] << 16);
+        pk.z = ((uint32_t)d[4] & 0xffffu) | ((uint32_t)d[5] << 16); pk.w = ((uint32_t)d[6] & 0xffffu) | ((uint32_t)d[7] << 16);
+        *(uint4*)&sW[blk][r * 8] = pk;
     }
     __syncthreads();
     // pass 2 (columns) + quantise (jcdctmgr.c: sign * ((|x| + q8/2) / q8)) + zigzag
