@@ -585,7 +585,7 @@ extern "C" int d2s_dibr_warp(const uint8_t* rgb, const float* depth, int batch, 
         static EnvInt cols_env{"D2S_DIBR_COLS", 512};
         int cols = cols_env.get() >= 1024 ? 1024 : (cols_env.get() >= 512 ? 512 : 256);
         auto win_words = [&](int c) { return (int)ceil((double)(c - 1) * (double)W / (double)g.ow) + 2 * margin + 4; };
-        while (cols > 256 && (win_words(cols) > (cols_env.get() >= 1024 ? 2048 : 640) || g.ow <= cols / 2)) cols >>= 1;
+        while (cols > 256 && (win_words(cols) > (cols_env.get() >= 1024 ? 1536 : 640) || g.ow <= cols / 2)) cols >>= 1;   // (1536: 48 KB + the queue stay under 64 KB)
         const int WWc = win_words(cols);
         dim3 rgrid(cdiv(g.ow, cols), g.oh, batch);
         const size_t lds = (size_t)8 * WWc * sizeof(float);
