@@ -934,8 +934,11 @@ extern "C" int d2s_make_sbs(const void* rgb, int rgb_fmt, const float* depth, in
     if (fast_ok && gather_env.get() && nc && dw >= nc && W >= 8 && W < 16384 && (long)batch * dh * dw * 4 < (1L << 32)) {
         const int ntx = cdiv(W, 256);
         const long rows = (long)H * batch;
-        static EnvInt wpc_env{"D2S_WARP_WPC", 32};                 // resident waves per CU the grid is cut for
-        long rpw = cdiv(rows * ntx, 256L * wpc_env.get());
+        // resident waves per CU the grid is cut for: 32 (tuned at batch 32); a launch of <= 12 288 row tiles (one 1080p frame: 8 640) is cut
+        // for 12 -- three rows per wave instead of two amortise the per-wave set-up: 10.5 -> 9.7 us at 1080p batch 1 (profiles/r6_01)
+        static EnvInt wpc_env{"D2S_WARP_WPC", 0};
+        const long wpc = wpc_env.get() > 0 ? wpc_env.get() : (rows * ntx <= 12288 ? 12 : 32);
+        long rpw = cdiv(rows * ntx, 256L * wpc);
         if (g.mode == D2S_MODE_HALF_TAB) rpw += rpw & 1;           // whole row pairs (H is even)
         const long waves = cdiv(rows, rpw) * ntx;
         const dim3 grid((unsigned)cdiv(waves, 4L)), block(256);
